@@ -1,0 +1,191 @@
+"""The oracle (oracle/) against the golden vectors captured from the reference's own modules.
+
+These pin the oracle; they run on CPU.  Tolerance: fp32 round-off only (2e-5 relative to max|ref|).
+"""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from oracle import models as om
+from oracle import ops as oo
+from oracle import train as ot
+
+TOL = 2e-5
+UPFIRDN_CASES = ["g_blur_pad21_gain4", "g_skip_up2_pad21", "d_blur_pad22_odd", "bwd_of_up2_down2",
+                 "asym_blur_pad21", "asym_up2_pad21", "asym_down2_pad12", "blur_pad11"]
+
+
+@pytest.mark.parametrize("case", UPFIRDN_CASES)
+def test_upfirdn2d(golden, case):
+    z = golden("upfirdn2d")
+    up, down, p0, p1 = [int(v) for v in z[case + ".cfg"]]
+    x = z[case + ".x"].requires_grad_(True)
+    gy = z[case + ".gy"].requires_grad_(True)
+    y = oo.upfirdn2d(x, z[case + ".fir"], up=up, down=down, pad=(p0, p1))
+    gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+    ggy, = torch.autograd.grad(gx, gy, z[case + ".ggx"])
+    assert rel_err(y, z[case + ".y"]) < TOL
+    assert rel_err(gx, z[case + ".gx"]) < TOL
+    assert rel_err(ggy, z[case + ".ggy"]) < TOL
+    lit = oo.upfirdn2d_scalar(x.detach().reshape(-1, *x.shape[2:]), z[case + ".fir"], up, down, p0, p1)
+    assert rel_err(lit.reshape(y.shape), z[case + ".y"]) < TOL
+
+
+@pytest.mark.parametrize("case", ["mlp_2d", "conv_4d", "conv_4d_sqrt2"])
+def test_fused_leaky_relu(golden, case):
+    z = golden("fused_act")
+    x, b = z[case + ".x"].requires_grad_(True), z[case + ".b"].requires_grad_(True)
+    gy = z[case + ".gy"].requires_grad_(True)
+    y = oo.fused_leaky_relu(x, b, 0.2, float(z[case + ".scale"]))
+    gx, gb = torch.autograd.grad(y, (x, b), gy, create_graph=True)
+    ggy, = torch.autograd.grad((gx, gb), gy, (z[case + ".ggx"], z[case + ".ggb"]))
+    for got, key in ((y, "y"), (gx, "gx"), (gb, "gb"), (ggy, "ggy")):
+        assert rel_err(got, z[f"{case}.{key}"]) < TOL, key
+
+
+MODCONV = {"conv3x3_demod": dict(kernel_size=(3, 3), demodulate=True, upsampling=False),
+           "up2x2_demod": dict(kernel_size=(2, 2), demodulate=True, upsampling=True),
+           "torgb1x1_nodemod": dict(kernel_size=(1, 1), demodulate=False, upsampling=False)}
+
+
+@pytest.mark.parametrize("kind", list(MODCONV))
+@pytest.mark.parametrize("mapped", [True, False])
+def test_modulated_conv(golden, kind, mapped):
+    z = golden("modconv")
+    name = f"{kind}.{'map' if mapped else 'nomap'}"
+    out_c = 3 if kind.startswith("torgb") else 12
+    m = om.ModulatedConv2d(8, out_c, 10, modulation_mapping=mapped, **MODCONV[kind])
+    m.load_state_dict(z.state_dict(name + ".sd."))
+    x, st = z[name + ".x"].requires_grad_(True), z[name + ".style"].requires_grad_(True)
+    res = m(x, st)
+    y = res[0] if mapped else res
+    gx, gst, gw = torch.autograd.grad(y, (x, st, m.weight), z[name + ".gy"], create_graph=True)
+    gg, = torch.autograd.grad(gx.square().sum(), st)
+    assert rel_err(y, z[name + ".y"]) < TOL
+    assert rel_err(gx, z[name + ".gx"]) < TOL
+    assert rel_err(gst, z[name + ".gstyle"]) < TOL
+    assert rel_err(gw, z[name + ".gweight"]) < TOL
+    assert rel_err(gg, z[name + ".gg_style"]) < 1e-4
+    if mapped:
+        assert rel_err(res[1], z[name + ".style_out"]) < TOL
+
+
+def test_small_layers(golden):
+    z = golden("layers")
+    assert rel_err(oo.equalized_linear(z["eqlinear.x"], z["eqlinear.w"], z["eqlinear.b"]), z["eqlinear.y"]) < TOL
+    for name in ("eqconv3x3", "eqconv3x3_s2_bias", "eqconv1x1"):
+        stride, pad = [int(v) for v in z[name + ".cfg"]]
+        b = z[name + ".b"] if name + ".b" in z.keys() else None
+        x, w = z[name + ".x"].requires_grad_(True), z[name + ".w"].requires_grad_(True)
+        y = oo.equalized_conv2d(x, w, b, stride, pad)
+        gx, gw = torch.autograd.grad(y, (x, w), z[name + ".gy"])
+        assert rel_err(y, z[name + ".y"]) < TOL and rel_err(gx, z[name + ".gx"]) < TOL
+        assert rel_err(gw, z[name + ".gw"]) < TOL
+    assert rel_err(oo.pixel_norm(z["pixelnorm.x"]), z["pixelnorm.y"]) < TOL
+    assert rel_err(oo.minibatch_stddev(z["mbstd.x"]), z["mbstd.y"]) < TOL
+    for name, blk in (("nonlocal", om.NonLocalBlock(8, 16)), ("resnet_mbstd", om.ResNetBlock(8, 12, True))):
+        blk.load_state_dict(z.state_dict(name + ".sd."))
+        x = z[name + ".x"].requires_grad_(True)
+        y = blk(x)
+        gx, = torch.autograd.grad(y, x, z[name + ".gy"])
+        assert rel_err(y, z[name + ".y"]) < TOL and rel_err(gx, z[name + ".gx"]) < TOL
+
+
+def _tiny(golden):
+    from tools.gen_golden import TINY_D, TINY_G
+    z = golden("tiny_models")
+    g, d = om.Generator(TINY_G), om.Discriminator(TINY_D, no_rfp=True)
+    g.load_state_dict(z.state_dict("tinyG.sd.")); d.load_state_dict(z.state_dict("tinyD.sd."))
+    return z, g, d
+
+
+def test_tiny_generator(golden):
+    z, g, _ = _tiny(golden)
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    zs = [z["tinyG.z0"], z["tinyG.z1"]]
+    noise = [z[f"tinyG.noise{i}"] for i in range(7)]
+    img, lat = g(zs, return_main_style_vectors=True, noise=noise, inject_index=3)
+    assert rel_err(img, z["tinyG.image"]) < TOL and rel_err(lat, z["tinyG.latent"]) < TOL
+    img.backward(z["tinyG.gimage"])
+    none_grad = sorted(n for n, p in g.named_parameters() if p.grad is None)
+    assert none_grad == man["tinyG.none_grad"]          # quirk Q1: the dead second stream
+    params = dict(g.named_parameters())
+    for key in z.keys("tinyG.grad."):
+        assert rel_err(params[key[len("tinyG.grad."):]].grad, z[key]) < 1e-4, key
+    g.zero_grad()
+    im, la = g(zs, return_main_style_vectors=True, noise=noise, inject_index=3)
+    gr, = torch.autograd.grad((im * z["tinyG.pl_image_noise"]).sum() / math.sqrt(3 * 32 * 32), la, create_graph=True)
+    pl = torch.sqrt(gr.pow(2).sum(2).mean(1) + 1e-8).mean()
+    pl.backward()
+    assert rel_err(gr, z["tinyG.pl_grads"]) < 1e-4 and rel_err(pl, z["tinyG.pl"]) < 1e-4
+    for key in z.keys("tinyG.plgrad."):
+        assert rel_err(params[key[len("tinyG.plgrad."):]].grad, z[key]) < 2e-4, key
+
+
+def test_tiny_discriminator(golden):
+    z, _, d = _tiny(golden)
+    x = z["tinyD.x"].requires_grad_(True)
+    s, px = d(x)
+    assert rel_err(s, z["tinyD.scalar"]) < TOL and rel_err(px, z["tinyD.pixel"]) < TOL
+    gin, = torch.autograd.grad((s, px), x, (z["tinyD.gs"], z["tinyD.gpx"]), create_graph=True)
+    assert rel_err(gin, z["tinyD.gin"]) < 1e-4
+    r1 = 0.5 * gin.pow(2).reshape(3, -1).sum(1).mean()
+    r1.backward()
+    assert rel_err(r1, z["tinyD.r1"]) < 1e-4
+    params = dict(d.named_parameters())
+    for key in z.keys("tinyD.r1grad."):
+        assert rel_err(params[key[len("tinyD.r1grad."):]].grad, z[key]) < 2e-4, key
+
+
+def test_state_dict_manifest():
+    """API parity: key/shape set of the default 256^2 models equals the reference's (201 / 72 entries)."""
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    g, d = om.Generator(), om.Discriminator(no_rfp=True)
+    assert {k: list(v.shape) for k, v in g.state_dict().items()} == man["generator"]
+    assert {k: list(v.shape) for k, v in d.state_dict().items()} == man["discriminator"]
+    assert len(man["generator"]) == 201 and len(man["discriminator"]) == 72
+    assert sum(p.numel() for p in g.parameters()) == man["generator_params"] == 53018664
+    assert sum(p.numel() for p in d.parameters()) == man["discriminator_params"] == 50855682
+
+
+def load_train_draws(z, step, ot_mod=ot):
+    pre = f"train.it{step}."
+    def lst(key):
+        return [z[k] for k in sorted(z.keys(pre + key + "."), key=lambda s: int(s.rsplit(".", 1)[1]))]
+    zg = lst("z_g")
+    return z[pre + "real"], ot_mod.Draws(
+        z_d=lst("z_d"), inject_d=2, noise_d=lst("noise_d"), z_g=zg[0] if len(zg) == 1 else zg, noise_g=lst("noise_g"),
+        z_pl=lst("z_pl"), inject_pl=4, noise_pl=lst("noise_pl"), pl_image_noise=z[pre + "pl_image_noise"])
+
+
+def test_train_iteration(golden):
+    """Two iterations (1 and 16): losses, R1, path length and post-step parameters."""
+    import copy
+    from tools.gen_golden import TINY_D, TINY_G
+    z = golden("train_step")
+    g, d = om.Generator(TINY_G), om.Discriminator(TINY_D, no_rfp=True)
+    g.load_state_dict(z.state_dict("train.G0.")); d.load_state_dict(z.state_dict("train.D0."))
+    dead0 = g.main_convolutions_2[3].modulated_convolution.weight.detach().clone()
+    g_ema = copy.deepcopy(g)
+    og, od = ot.make_optimizers(g, d)
+    pl = ot.PathLength()
+    for step, iteration in enumerate((1, 16)):
+        real, draws = load_train_draws(z, step)
+        log = ot.train_iteration(g, d, g_ema, og, od, pl, real, iteration, draws)
+        pre = f"train.it{step}."
+        for key in z.keys(pre + "log."):
+            want = float(z[key])
+            assert abs(log[key[len(pre + "log."):]] - want) <= 2e-4 * max(1.0, abs(want)), key
+        gp, dp, ep = dict(g.named_parameters()), dict(d.named_parameters()), dict(g_ema.named_parameters())
+        for key in z.keys(pre + "G."):
+            assert rel_err(gp[key[len(pre + "G."):]], z[key]) < 1e-4, key
+        for key in z.keys(pre + "Gema."):
+            assert rel_err(ep[key[len(pre + "Gema."):]], z[key]) < 1e-4, key
+        for key in z.keys(pre + "D."):
+            assert rel_err(dp[key[len(pre + "D."):]], z[key]) < 1e-4, key
+    assert rel_err(pl.mean_path_length, z["train.it1.mean_path_length"]) < 1e-4
+    assert torch.equal(g.main_convolutions_2[3].modulated_convolution.weight, dead0)   # dead branch untouched

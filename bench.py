@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Benchmark of the Multi-StyleGAN G+D training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full adversarial training iteration (D step, G step, EMA, lazy R1 / path-length regularisers at
+their natural 1-in-16 cadence) on a synthetic batch that is already resident in HBM.  Default workload =
+BASELINE.json configs[1]: 256x256, seq 3 x 2 channels, batch 16 per GPU, bf16 storage / fp32 accumulate, fp32
+master weights.  Weak scaling: every rank runs the same per-GPU batch; gradients are averaged over RCCL.
+
+Rank 0 prints ONE JSON line; besides the contract's keys it carries
+  roofline      the dominant hand-written kernel, timed per launch with HIP events inside the timed region
+  cpu_baseline  the CPU oracle (oracle/) timed on this host on a bounded sample of the workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--resolution", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--elide-dead-work", action="store_true",
+                    help="skip work whose results the reference discards (dead 2nd-stream convs, D weight grads in "
+                         "the G step); identical training trajectory, not used for the headline value")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-clock", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(iters: int):
+    """The CPU oracle on BASELINE config 1 (64x64, 5 x 512 channels, B=4): `iters` plain iterations after one
+    warm-up.  A bounded sample: the 256^2 workload itself takes minutes per iteration on a CPU."""
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    from oracle import models as om, train as ot
+    import copy
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+    g, d = om.Generator(generator_config_for_resolution(64)), om.Discriminator(no_rfp=True)
+    g_ema = copy.deepcopy(g)
+    og, od = ot.make_optimizers(g, d)
+    pl = ot.PathLength()
+    real = torch.rand(4, 2, 3, 64, 64)
+    ot.train_iteration(g, d, g_ema, og, od, pl, real, 1)
+    t0 = time.perf_counter()
+    for it in range(iters):
+        ot.train_iteration(g, d, g_ema, og, od, pl, real, 2 + it)
+    dt = time.perf_counter() - t0
+    return {"value": round(4 * iters / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} plain training iterations (no lazy regulariser) of the CPU oracle at 64x64, batch 4 "
+                      f"(BASELINE config 1), torch {torch.__version__}, {threads} threads"}
+
+
+def main():
+    args = parse_args()
+    from multi_stylegan_amd import dist as msg_dist
+    rank, world, local_rank = msg_dist.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd import _lib
+    from multi_stylegan_amd.config import generator_config_for_resolution
+
+    torch.manual_seed(1234)                                   # same init on every rank (and broadcast anyway)
+    gen = m.MultiStyleGANGenerator(generator_config_for_resolution(args.resolution))
+    dis = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    gen.compute_dtype = dis.compute_dtype = dtype
+    gen.elide_dead_branch = args.elide_dead_work
+    trainer = m.ModelWrapper(gen, dis, device=dev,
+                             skip_discriminator_weight_grads_in_generator_step=args.elide_dead_work)
+    trainer.generator_ema.compute_dtype = dtype
+    torch.manual_seed(1234 + rank)                            # different data / z / noise per rank
+    import random
+    random.seed(1234 + rank)
+    real = torch.rand(args.batch, 2, 3, args.resolution, args.resolution, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.train_iteration(real)
+    trainer.pop_logs()
+    _lib.kernel_clock.reset(enabled=not args.no_kernel_clock)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_iteration(real)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    clock = _lib.kernel_clock.summary()
+    _lib.kernel_clock.reset(enabled=False)
+    logs = trainer.pop_logs()
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+
+    if rank == 0:
+        value = world * args.batch * args.steps / elapsed
+        # dominant hand-written kernel of this build: the 4x4 FIR blur of upfirdn2d (HBM-bound)
+        key = f"upfirdn2d/{args.dtype}/up1down1/vec"
+        roof = None
+        if key in clock:
+            c = clock[key]
+            gbs = c["work"] / (c["total_ms"] * 1e-3) / 1e9
+            roof = {"kernel": "upfirdn2d_vec_kernel<up=1,down=1> (4x4 FIR blur, channels-last)", "bound": "hbm",
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": None, "launches": c["launches"], "avg_us": round(c["avg_us"], 2),
+                    "algorithmic_bytes_per_launch": round(c["work"] / c["launches"])}
+        kernels = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                       "GB/s": round(v["work"] / (v["total_ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(clock.items())}
+        out = {
+            "metric": "training images/sec (G+D step, 256^2, seq=3x2ch)", "value": round(value, 3), "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.resolution}x{args.resolution}, seq_len=3, 2 channels, batch={args.batch}/GPU "
+                                   f"(BASELINE configs[1]); full iteration: D step + G step + EMA, lazy R1 and "
+                                   f"path-length every 16th", "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}", "dead_work_elided": bool(args.elide_dead_work)},
+            "roofline": roof, "kernels": kernels, "peak_mem_GiB": round(peak_mem, 2),
+            "loss_d_real_last": round(logs["loss_discriminator_real"][-1], 4) if logs else None,
+        }
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

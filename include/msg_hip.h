@@ -1,0 +1,92 @@
+/*
+ * msg_hip.h -- C ABI of libmsg_hip.so: the MI355X (gfx950) kernels behind the
+ * Multi-StyleGAN generator/discriminator hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless it is named host_*;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it,
+ *     nothing here synchronises, allocates or keeps state between calls;
+ *   - inputs are borrowed, outputs are caller-allocated and fully overwritten
+ *     unless the entry says "accumulates";
+ *   - return value: MSG_OK (0) or a negative MSG_E* code -- an unsupported
+ *     configuration is an error, never a silent no-op (the reference silently
+ *     launches nothing for unmatched modes: op_static/upfirdn2d_kernel.cu:172-211);
+ *   - dtype: MSG_F32 or MSG_BF16 storage; arithmetic is always fp32.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef MSG_HIP_H
+#define MSG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MSG_OK = 0, MSG_EINVAL = -1, MSG_EUNSUPPORTED = -2, MSG_ELAUNCH = -3 };
+enum { MSG_F32 = 0, MSG_BF16 = 1 };
+
+/* Library/ABI version and the code-object architecture it was built for ("gfx950"). */
+int msg_abi_version(void);
+const char* msg_build_arch(void);
+/* Text for a MSG_E* code. */
+const char* msg_strerror(int code);
+
+/* ---------------------------------------------------------------------------
+ * a1  upfirdn2d -- replaces upfirdn2d_cuda.upfirdn2d
+ *     (multi_stylegan/op_static/upfirdn2d.cpp:12-19 -> upfirdn2d_op,
+ *      multi_stylegan/op_static/upfirdn2d_kernel.cu:140-272).
+ * x   [major, in_h, in_w, minor]   (NCHW planes: major=B*C, minor=1;
+ *                                   channels-last: major=B, minor=C)
+ * fir [kh, kw] float32 (un-flipped, exactly what the reference passes)
+ * y   [major, out_h, out_w, minor], out = (in*up + pad0 + pad1 - k) / down + 1
+ * Zero-insert by up, pad (negative = crop), true convolution with fir, keep
+ * every down-th sample.  Any up/down/pad/k combination is accepted (fast
+ * paths: k<=4x4 with (up,down) in {(1,1),(2,1),(1,2)} and minor % vec == 0).
+ * ------------------------------------------------------------------------- */
+int msg_upfirdn2d(const void* x, const float* fir, void* y, int dtype,
+                  int major, int in_h, int in_w, int minor, int kh, int kw,
+                  int up_x, int up_y, int down_x, int down_y,
+                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a2  fused bias + (noise) + leaky-ReLU -- replaces fused_act_cuda.fused_bias_act
+ *     (multi_stylegan/op_static/fused_bias_act.cpp:11-17 -> fused_bias_act_op,
+ *      multi_stylegan/op_static/fused_bias_act_kernel.cu:18-99) and fuses the
+ *     NoiseInjection add in front of it (multi_stylegan_generator.py:288-292).
+ * x, y   flat [size_x]; bias index of element i is (i / step_b) % size_b
+ *        (NCHW: step_b = H*W; channels-last or [B,C]: step_b = 1).
+ * bias   [size_b] float32 or NULL.
+ * ref    flat [size_x] or NULL; with grad=1 the slope is chosen by sign(ref)
+ *        (the saved forward OUTPUT) instead of sign(x+b): kernel.cu:44.
+ * noise  NULL, or float32 [noise_batch(1 or B), pix] added as
+ *        (*noise_weight) * noise[pixel(i)] before the bias; pixel(i) is
+ *        (i / step_b / size_b) * pix + i % step_b   for NCHW  (pix = step_b)
+ *        i / size_b                                  for channels-last (step_b == 1)
+ *        and wraps modulo `pix` when noise_batch == 1.
+ * act    3 = leaky ReLU (the only activation the reference ever uses), 1 = linear.
+ * grad   0 forward, 1 first derivative (needs ref), 2 -> zeros.
+ * y = act(x + w*noise + b) * scale, computed in fp32.
+ * ------------------------------------------------------------------------- */
+int msg_fused_bias_act(const void* x, const float* bias, const void* ref, void* y, int dtype,
+                       long long size_x, int step_b, int size_b,
+                       const float* noise, const float* noise_weight, int noise_batch, int pix,
+                       int act, int grad, float alpha, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a2  backward of the above with its reductions -- replaces
+ *     FusedLeakyReLUFunctionBackward.forward (multi_stylegan/op_static/fused_act.py:24-42:
+ *     one fused_bias_act(grad=1) call + grad_input.sum(dim) in PyTorch).
+ * gx = gy * scale * (out > 0 ? 1 : alpha);  grad_bias[c] += sum gx;
+ * grad_noise_weight[0] += sum gx * noise[pixel]   (if noise != NULL).
+ * grad_bias / grad_noise_weight are float32 and ACCUMULATED into (zero them first).
+ * ------------------------------------------------------------------------- */
+int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
+                          long long size_x, int step_b, int size_b,
+                          float* grad_bias, const float* noise, float* grad_noise_weight,
+                          int noise_batch, int pix, float alpha, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSG_HIP_H */

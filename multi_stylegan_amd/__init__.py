@@ -1,0 +1,10 @@
+"""Multi-StyleGAN generator + discriminator training hot path, MI355X-native (gfx950 HIP kernels behind the
+reference's nn.Module / op_static API).  See DESIGN.md.  Public names follow multi_stylegan/__init__.py."""
+from .config import (generation_hyperparameters, multi_style_gan_generator_config,
+                     u_net_2d_discriminator_config)
+from .model_wrapper import Draws, ModelWrapper
+from .multi_stylegan_generator import Generator as MultiStyleGANGenerator
+from .u_net_2d_discriminator import Discriminator as MultiStyleGANDiscriminator
+
+__all__ = ["MultiStyleGANGenerator", "MultiStyleGANDiscriminator", "ModelWrapper", "Draws",
+           "multi_style_gan_generator_config", "u_net_2d_discriminator_config", "generation_hyperparameters"]

@@ -1,0 +1,147 @@
+"""ctypes binding of libmsg_hip.so (C ABI: include/msg_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call reports
+an error this raises.  Tensors are passed as raw device pointers together with
+the HIP stream torch is currently recording on, so launches interleave
+correctly with torch's own kernels.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsg_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msg_hip.h")
+
+MSG_F32, MSG_BF16 = 0, 1
+_c = ctypes
+_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_longlong, _c.c_float
+
+_SIGNATURES = {
+    "msg_abi_version": (_I, []),
+    "msg_build_arch": (_c.c_char_p, []),
+    "msg_strerror": (_c.c_char_p, [_I]),
+    "msg_upfirdn2d": (_I, [_P, _P, _P, _I] + [_I] * 14 + [_P]),
+    "msg_fused_bias_act": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "msg_bias_act_backward": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _I, _F, _F, _P]),
+}
+
+
+def declared_symbols():
+    """Every function the public header declares (used by the CPU-side export test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msg_[a-z0-9_]+)\s*\(", text)))
+
+
+class MsgHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsgHipError(f"{LIB_PATH} is missing: build it with `python -m multi_stylegan_amd.build` "
+                              "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise MsgHipError(f"{what}: {lib().msg_strerror(code).decode()} (code {code})")
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return MSG_F32
+    if t.dtype == torch.bfloat16:
+        return MSG_BF16
+    raise MsgHipError(f"dtype {t.dtype} is not supported by the gfx950 kernels (float32 / bfloat16 only)")
+
+
+def require_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise MsgHipError("multi_stylegan_amd ops need tensors on an MI355X (ROCm 'cuda' device); "
+                              "got a CPU tensor and there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise MsgHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class KernelClock:
+    """Optional per-launch timing with HIP events on the stream the kernels are launched on (bench.py's roofline
+    leg).  Off by default: when off, ``span`` is a no-op and costs one attribute test."""
+
+    def __init__(self):
+        self.enabled = False
+        self.spans = {}
+
+    def reset(self, enabled: bool):
+        self.enabled, self.spans = enabled, {}
+
+    def span(self, key: str, work: float):
+        return _Span(self, key, work) if self.enabled else _NULL_SPAN
+
+    def summary(self):
+        """-> {key: dict(launches, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""
+        out = {}
+        for key, items in self.spans.items():
+            total_ms = sum(a.elapsed_time(b) for a, b, _ in items)
+            work = sum(w for _, _, w in items)
+            out[key] = {"launches": len(items), "total_ms": total_ms, "avg_us": 1e3 * total_ms / len(items),
+                        "work": work}
+        return out
+
+
+class _Span:
+    __slots__ = ("clock", "key", "work", "start")
+
+    def __init__(self, clock, key, work):
+        self.clock, self.key, self.work = clock, key, work
+
+    def __enter__(self):
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.start.record()
+
+    def __exit__(self, *exc):
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.clock.spans.setdefault(self.key, []).append((self.start, end, self.work))
+        return False
+
+
+class _NullSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_SPAN = _NullSpan()
+kernel_clock = KernelClock()

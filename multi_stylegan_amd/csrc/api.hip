@@ -1,0 +1,14 @@
+// Library identity and error strings of the C ABI (include/msg_hip.h).
+#include "msg_common.h"
+
+extern "C" int msg_abi_version(void) { return 1; }
+extern "C" const char* msg_build_arch(void) { return "gfx950"; }
+extern "C" const char* msg_strerror(int code) {
+    switch (code) {
+        case MSG_OK: return "ok";
+        case MSG_EINVAL: return "invalid argument (null pointer, non-positive extent or inconsistent sizes)";
+        case MSG_EUNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+        case MSG_ELAUNCH: return "kernel launch failed (hipGetLastError != hipSuccess)";
+        default: return "unknown msg_hip error code";
+    }
+}

@@ -1,0 +1,301 @@
+// a2: fused (noise +) bias + leaky-ReLU for gfx950, forward / first derivative / reductions.
+// Replaces multi_stylegan/op_static/fused_bias_act_kernel.cu:18-99 and folds the NoiseInjection add
+// (multi_stylegan_generator.py:288-292) and the PyTorch-side grad_bias sum (op_static/fused_act.py:35-40)
+// into the same pass.  HBM-bound: one 16-byte access per lane per tensor, fp32 arithmetic.
+#include "msg_common.h"
+
+struct BiasActParams {
+    long long size_x;
+    int step_b, size_b, noise_batch, pix, act, grad;
+    float alpha, scale;
+};
+
+__device__ __forceinline__ float act_apply(float v, float gate, int act, float alpha, float scale) {
+    // fused_bias_act_kernel.cu:36-47: act*10+grad in {30,31}: slope chosen by sign of x (fwd) or of ref (grad)
+    if (act == 3) v = (gate > 0.f) ? v : v * alpha;
+    return v * scale;
+}
+
+// ---- generic scalar path (any step_b / size_b) ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_scalar_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                              const T* __restrict__ ref, T* __restrict__ y,
+                                                              const float* __restrict__ noise,
+                                                              const float* __restrict__ noise_w, BiasActParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.size_x) return;
+    float v = load_as_f32(x + i);
+    if (p.grad == 2) { store_from_f32(y + i, 0.f); return; }
+    const long long q = i / p.step_b;
+    if (noise) {
+        const long long b = q / p.size_b;
+        long long pixel = (p.step_b == 1) ? q / p.size_b : b * p.pix + (i - q * p.step_b);
+        if (p.noise_batch == 1) pixel %= p.pix;
+        v = fmaf(noise_w[0], noise[pixel], v);
+    }
+    if (bias) v += bias[q % p.size_b];
+    const float gate = (p.grad == 1 && ref) ? load_as_f32(ref + i) : v;
+    store_from_f32(y + i, act_apply(v, gate, p.act, p.alpha, p.scale));
+}
+
+// ---- vector paths ---------------------------------------------------------------------------------------------
+// CL = true : channels-last / [B,C] (step_b == 1, size_b % VEC == 0): one bias vector, one noise scalar per lane
+// CL = false: planar NCHW (step_b % VEC == 0): one bias scalar, one noise vector per lane
+template <typename T, bool CL>
+__global__ __launch_bounds__(256) void bias_act_vec_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                           const T* __restrict__ ref, T* __restrict__ y,
+                                                           const float* __restrict__ noise,
+                                                           const float* __restrict__ noise_w, BiasActParams p) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    const long long nvec = p.size_x / VEC;
+    const float nw = noise ? noise_w[0] : 0.f;
+    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * 256) {
+        const long long i = vi * VEC;
+        V v, r, o;
+        v.raw = *reinterpret_cast<const uint4*>(x + i);
+        const bool use_ref = (p.grad == 1) && ref;
+        if (use_ref) r.raw = *reinterpret_cast<const uint4*>(ref + i);
+        float f[VEC], add[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) add[e] = 0.f;
+        if (CL) {
+            const long long q = i / p.size_b;                    // pixel (or row) index
+            const int c0 = (int)(i - q * p.size_b);
+            if (noise) {
+                const float nv = nw * noise[p.noise_batch == 1 ? q % p.pix : q];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) add[e] = nv;
+            }
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + c0 + e);
+                    add[e] += b4.x; add[e + 1] += b4.y; add[e + 2] += b4.z; add[e + 3] += b4.w;
+                }
+            }
+        } else {
+            const long long q = i / p.step_b;                    // plane index b*C + c
+            const int off = (int)(i - q * p.step_b);
+            if (noise) {
+                const long long base = (p.noise_batch == 1 ? 0 : (q / p.size_b) * p.pix) + off;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) add[e] = nw * noise[base + e];
+            }
+            if (bias) {
+                const float bv = bias[q % p.size_b];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) add[e] += bv;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float val = v.get(e) + add[e];
+            f[e] = (p.grad == 2) ? 0.f : act_apply(val, use_ref ? r.get(e) : val, p.act, p.alpha, p.scale);
+        }
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+        }
+        *reinterpret_cast<uint4*>(y + i) = o.raw;
+    }
+}
+
+template <typename T>
+static int fwd_dispatch(const void* x, const float* bias, const void* ref, void* y, const float* noise,
+                        const float* noise_w, const BiasActParams& p, hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)ref) & 15u) == 0 &&
+                         (((uintptr_t)bias) & 15u) == 0;
+    const bool cl = p.step_b == 1 && p.size_b % VEC == 0;
+    const bool planar = p.step_b % VEC == 0 && (!noise || p.pix == p.step_b);
+    if (aligned && p.size_x % VEC == 0 && (cl || planar)) {
+        const long long nvec = p.size_x / VEC;
+        const unsigned blocks = (unsigned)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
+        if (cl)
+            hipLaunchKernelGGL((bias_act_vec_kernel<T, true>), dim3(blocks), dim3(256), 0, s, (const T*)x, bias,
+                               (const T*)ref, (T*)y, noise, noise_w, p);
+        else
+            hipLaunchKernelGGL((bias_act_vec_kernel<T, false>), dim3(blocks), dim3(256), 0, s, (const T*)x, bias,
+                               (const T*)ref, (T*)y, noise, noise_w, p);
+    } else {
+        const long long blocks = (p.size_x + 255) / 256;
+        if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
+        hipLaunchKernelGGL((bias_act_scalar_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, bias,
+                           (const T*)ref, (T*)y, noise, noise_w, p);
+    }
+    return MSG_CHECK_LAUNCH();
+}
+
+extern "C" int msg_fused_bias_act(const void* x, const float* bias, const void* ref, void* y, int dtype,
+                                  long long size_x, int step_b, int size_b,
+                                  const float* noise, const float* noise_weight, int noise_batch, int pix,
+                                  int act, int grad, float alpha, float scale, void* stream) {
+    if (size_x == 0) return MSG_OK;
+    if (!x || !y || size_x < 0 || step_b <= 0 || size_b <= 0 || (act != 1 && act != 3) || grad < 0 || grad > 2)
+        return MSG_EINVAL;
+    if (noise && (!noise_weight || pix <= 0 || noise_batch <= 0)) return MSG_EINVAL;
+    if (grad == 1 && act == 3 && !ref) return MSG_EINVAL;
+    if (size_x == 0) return MSG_OK;
+    BiasActParams p{size_x, step_b, size_b, noise_batch, pix, act, grad, alpha, scale};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_F32) return fwd_dispatch<float>(x, bias, ref, y, noise, noise_weight, p, s);
+    if (dtype == MSG_BF16) return fwd_dispatch<bf16_t>(x, bias, ref, y, noise, noise_weight, p, s);
+    return MSG_EUNSUPPORTED;
+}
+
+// ---- backward with reductions ---------------------------------------------------------------------------------
+// Channels-last: block = LC channel-vectors x (256/LC) pixel lanes; every lane keeps its VEC channels across its
+// pixel loop, partial sums meet in LDS, one float atomic per channel per block.
+template <typename T, bool HAS_NOISE>
+__global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restrict__ gy, const T* __restrict__ out,
+                                                              T* __restrict__ gx, float* __restrict__ grad_bias,
+                                                              const float* __restrict__ noise,
+                                                              float* __restrict__ grad_nw, BiasActParams p,
+                                                              int lanes_c, long long npix, long long pix_per_block) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    __shared__ float red[256 * VEC + 256];
+    const int lc = threadIdx.x % lanes_c, pl = threadIdx.x / lanes_c, npl = 256 / lanes_c;
+    const int cv = blockIdx.x * lanes_c + lc;
+    const long long p0 = (long long)blockIdx.y * pix_per_block;
+    const long long p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+    float sb[VEC], sn = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sb[e] = 0.f;
+    for (long long q = p0 + pl; q < p1; q += npl) {
+        const long long i = q * p.size_b + (long long)cv * VEC;
+        V g, o, r;
+        g.raw = *reinterpret_cast<const uint4*>(gy + i);
+        o.raw = *reinterpret_cast<const uint4*>(out + i);
+        float f[VEC], rowsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            f[e] = g.get(e) * p.scale * ((o.get(e) > 0.f || p.act != 3) ? 1.f : p.alpha);
+            sb[e] += f[e];
+            rowsum += f[e];
+        }
+        if (HAS_NOISE) sn = fmaf(rowsum, noise[p.noise_batch == 1 ? q % p.pix : q], sn);
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r.set(e, f[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r.set2(e, f[2 * e], f[2 * e + 1]);
+        }
+        *reinterpret_cast<uint4*>(gx + i) = r.raw;
+    }
+    if (grad_bias) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[(pl * lanes_c + lc) * VEC + e] = sb[e];
+    }
+    if (HAS_NOISE) red[256 * VEC + threadIdx.x] = sn;
+    __syncthreads();
+    if (grad_bias) {
+        for (int j = threadIdx.x; j < lanes_c * VEC; j += 256) {
+            float s = 0.f;
+            for (int k = 0; k < npl; ++k) s += red[k * lanes_c * VEC + j];
+            atomicAdd(grad_bias + blockIdx.x * lanes_c * VEC + j, s);
+        }
+    }
+    if (HAS_NOISE && threadIdx.x < 64) {
+        float s = red[256 * VEC + threadIdx.x] + red[256 * VEC + threadIdx.x + 64] +
+                  red[256 * VEC + threadIdx.x + 128] + red[256 * VEC + threadIdx.x + 192];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) atomicAdd(grad_nw, s);
+    }
+}
+
+// Planar / generic: grid.x = plane (b*C + c) when step_b > 1, scalar loads, block reduction, one atomic per block.
+template <typename T, bool HAS_NOISE>
+__global__ __launch_bounds__(256) void bias_act_bwd_planar_kernel(const T* __restrict__ gy, const T* __restrict__ out,
+                                                                  T* __restrict__ gx, float* __restrict__ grad_bias,
+                                                                  const float* __restrict__ noise,
+                                                                  float* __restrict__ grad_nw, BiasActParams p) {
+    __shared__ float red[8];
+    const long long plane = blockIdx.x;
+    const int c = (int)(plane % p.size_b);
+    const long long b = plane / p.size_b;
+    const long long base = plane * p.step_b;
+    // noise index of element j of this plane: planar -> b*pix + j; channels-last scalar fallback (step_b == 1,
+    // "plane" = one element) -> its pixel index b
+    const long long nbase = (p.step_b == 1) ? (p.noise_batch == 1 ? b % p.pix : b)
+                                            : (p.noise_batch == 1 ? 0 : b * p.pix);
+    float sb = 0.f, sn = 0.f;
+    for (int j = blockIdx.y * 256 + threadIdx.x; j < p.step_b; j += gridDim.y * 256) {
+        const float f = load_as_f32(gy + base + j) * p.scale *
+                        ((load_as_f32(out + base + j) > 0.f || p.act != 3) ? 1.f : p.alpha);
+        store_from_f32(gx + base + j, f);
+        sb += f;
+        if (HAS_NOISE) sn = fmaf(f, noise[nbase + j], sn);
+    }
+    sb = wave_sum(sb);
+    if (HAS_NOISE) sn = wave_sum(sn);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w] = sb; red[4 + w] = sn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (grad_bias) atomicAdd(grad_bias + c, red[0] + red[1] + red[2] + red[3]);
+        if (HAS_NOISE) atomicAdd(grad_nw, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+template <typename T>
+static int bwd_dispatch(const void* gy, const void* out, void* gx, float* grad_bias, const float* noise,
+                        float* grad_nw, const BiasActParams& p, hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    const bool aligned = (((uintptr_t)gy | (uintptr_t)out | (uintptr_t)gx) & 15u) == 0;
+    const bool has_noise = noise && grad_nw;
+    if (p.step_b == 1 && p.size_b % VEC == 0 && aligned) {
+        const int nvec = p.size_b / VEC;
+        int lanes_c = 1;
+        while (lanes_c < 64 && nvec % (lanes_c * 2) == 0) lanes_c *= 2;
+        const long long npix = p.size_x / p.size_b;
+        const int gx_blocks = nvec / lanes_c;
+        long long want_y = 1024 / gx_blocks; if (want_y < 1) want_y = 1;
+        const long long npl = 256 / lanes_c;
+        long long ppb = (npix + want_y - 1) / want_y;
+        ppb = ((ppb + npl - 1) / npl) * npl;
+        const long long gy_blocks = (npix + ppb - 1) / ppb;
+        dim3 grid(gx_blocks, (unsigned)gy_blocks);
+        if (has_noise)
+            hipLaunchKernelGGL((bias_act_bwd_cl_kernel<T, true>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
+                               (T*)gx, grad_bias, noise, grad_nw, p, lanes_c, npix, ppb);
+        else
+            hipLaunchKernelGGL((bias_act_bwd_cl_kernel<T, false>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
+                               (T*)gx, grad_bias, noise, grad_nw, p, lanes_c, npix, ppb);
+    } else {
+        // planar NCHW (or odd channel counts, treated as planes of step_b elements)
+        const long long planes = p.size_x / p.step_b;
+        if (planes >= (1ll << 31)) return MSG_EUNSUPPORTED;
+        int chunks = (p.step_b + 4095) / 4096; if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
+        dim3 grid((unsigned)planes, chunks);
+        if (has_noise)
+            hipLaunchKernelGGL((bias_act_bwd_planar_kernel<T, true>), grid, dim3(256), 0, s, (const T*)gy,
+                               (const T*)out, (T*)gx, grad_bias, noise, grad_nw, p);
+        else
+            hipLaunchKernelGGL((bias_act_bwd_planar_kernel<T, false>), grid, dim3(256), 0, s, (const T*)gy,
+                               (const T*)out, (T*)gx, grad_bias, noise, grad_nw, p);
+    }
+    return MSG_CHECK_LAUNCH();
+}
+
+extern "C" int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
+                                     long long size_x, int step_b, int size_b,
+                                     float* grad_bias, const float* noise, float* grad_noise_weight,
+                                     int noise_batch, int pix, float alpha, float scale, void* stream) {
+    if (size_x == 0) return MSG_OK;
+    if (!gy || !out || !gx || size_x < 0 || step_b <= 0 || size_b <= 0) return MSG_EINVAL;
+    if (size_x % ((long long)step_b * size_b) != 0) return MSG_EINVAL;
+    if (noise && grad_noise_weight && (pix <= 0 || noise_batch <= 0)) return MSG_EINVAL;
+    if (noise && grad_noise_weight && step_b > 1 && pix != step_b) return MSG_EINVAL;
+    if (size_x == 0) return MSG_OK;
+    BiasActParams p{size_x, step_b, size_b, noise_batch, pix, 3, 1, alpha, scale};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_F32) return bwd_dispatch<float>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
+    if (dtype == MSG_BF16) return bwd_dispatch<bf16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
+    return MSG_EUNSUPPORTED;
+}

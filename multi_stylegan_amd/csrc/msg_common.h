@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 kernels (wave64, fp32 arithmetic, f32/bf16 storage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "../../include/msg_hip.h"
+
+typedef float  f32x4 __attribute__((ext_vector_type(4)));
+typedef float  f32x16 __attribute__((ext_vector_type(16)));
+typedef short  bf16x8 __attribute__((ext_vector_type(8)));
+typedef short  bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __hip_bfloat16 h = __float2bfloat16(f);      // RNE; keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+    return *reinterpret_cast<bf16_t*>(&h);
+}
+
+// 16-byte vector of storage elements <-> fp32 lanes.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    uint4 raw;
+    __device__ __forceinline__ void zero() { raw = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ float get(int i) const { return __uint_as_float((&raw.x)[i]); }
+    __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = __float_as_uint(v); }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    uint4 raw;
+    __device__ __forceinline__ void zero() { raw = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ float get(int i) const {
+        uint32_t w = (&raw.x)[i >> 1];
+        return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+    }
+    __device__ __forceinline__ void set2(int pair, float lo, float hi) {
+        (&raw.x)[pair] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+};
+
+template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
+template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void store_from_f32(T* p, float v);
+template <> __device__ __forceinline__ void store_from_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// XCD-aware bijective block remap: blocks that share an XCD (bid % 8) get one
+// contiguous chunk of the logical grid so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u;
+    const unsigned base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+#define MSG_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? MSG_OK : MSG_ELAUNCH)

@@ -1,0 +1,201 @@
+// a1: upfirdn2d for gfx950 -- zero-insert x up, pad/crop, 2-D FIR (true convolution), decimate x down.
+// Replaces the reference's CUDA extension (multi_stylegan/op_static/upfirdn2d_kernel.cu:52-272); the
+// design is different: no LDS tile.  The op is a pure HBM stream (16 MAC per output against 2 accesses), so
+// the fast path keeps the channel vector of one pixel on the wave (16 B per lane, 1 KiB per wave-load when
+// minor >= 512 B), register-tiles TH x TW outputs per lane so each input vector is fetched from L1/L2 a few
+// times instead of 16, keeps the 16 FIR taps in SGPRs, and remaps blocks so that one XCD's L2 sees a
+// contiguous band of tiles.  Arithmetic is fp32 whatever the storage type.
+#include "msg_common.h"
+
+struct UpfirdnParams {
+    int major, in_h, in_w, minor, out_h, out_w;
+    int up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw;
+    unsigned nvec, tiles_x, tiles_y, total;
+};
+
+// out[o] = sum_t z[o*down + t - pad0] * fir[k-1-t], z = zero-inserted input (z[i*up] = x[i]).
+// (same index math as upfirdn2d_kernel.cu:114-133, derived from the definition rather than its tile form)
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const T* __restrict__ x, const float* __restrict__ fir,
+                                                                T* __restrict__ y, UpfirdnParams p, long long total) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int m = (int)(i % p.minor);
+    long long t = i / p.minor;
+    const int ox = (int)(t % p.out_w); t /= p.out_w;
+    const int oy = (int)(t % p.out_h);
+    const long long mj = t / p.out_h;
+    const T* xb = x + mj * (long long)p.in_h * p.in_w * p.minor + m;
+    float acc = 0.f;
+    for (int ty = 0; ty < p.kh; ++ty) {
+        const int py = oy * p.down_y + ty - p.pad_y0;
+        if (py < 0 || py % p.up_y) continue;
+        const int iy = py / p.up_y;
+        if (iy >= p.in_h) continue;
+        for (int tx = 0; tx < p.kw; ++tx) {
+            const int px = ox * p.down_x + tx - p.pad_x0;
+            if (px < 0 || px % p.up_x) continue;
+            const int ix = px / p.up_x;
+            if (ix >= p.in_w) continue;
+            acc += load_as_f32(xb + ((long long)iy * p.in_w + ix) * p.minor) *
+                   fir[(p.kh - 1 - ty) * p.kw + (p.kw - 1 - tx)];
+        }
+    }
+    store_from_f32(y + i, acc);
+}
+
+// Fast path: k <= 4x4, (UP,DOWN) in {(1,1),(1,2),(2,1)}, minor a multiple of the 16-byte vector.
+// One lane = one 16-byte channel vector of a TH x TW output tile.  For UP == 2 tiles start on even outputs,
+// so which taps meet which input sample depends only on the parity PY/PX of (-pad0): a template constant.
+template <typename T, int UP, int DOWN, int PY, int PX, int TH, int TW>
+__global__ __launch_bounds__(256) void upfirdn2d_vec_kernel(const T* __restrict__ x, const float* __restrict__ fir,
+                                                            T* __restrict__ y, UpfirdnParams p) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    constexpr int NR = (UP == 1) ? (TH - 1) * DOWN + 4 : (TH + 3) / 2 + 1;
+    constexpr int NC = (UP == 1) ? (TW - 1) * DOWN + 4 : (TW + 3) / 2 + 1;
+
+    float w[4][4];                                   // flipped FIR, zero-padded to 4x4 (uniform -> SGPRs)
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx)
+            w[ty][tx] = (ty < p.kh && tx < p.kw) ? fir[(p.kh - 1 - ty) * p.kw + (p.kw - 1 - tx)] : 0.f;
+
+    const unsigned idx = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    if (idx >= p.total) return;
+    const unsigned cv = idx % p.nvec;
+    unsigned t = idx / p.nvec;
+    const unsigned tx_ = t % p.tiles_x; t /= p.tiles_x;
+    const unsigned ty_ = t % p.tiles_y;
+    const unsigned mj = t / p.tiles_y;
+    const int oy0 = (int)ty_ * TH, ox0 = (int)tx_ * TW;
+    int iy_lo, ix_lo;
+    if (UP == 1) {
+        iy_lo = oy0 * DOWN - p.pad_y0;
+        ix_lo = ox0 * DOWN - p.pad_x0;
+    } else {
+        iy_lo = (oy0 - p.pad_y0 - PY) >> 1;          // exact: the numerator is even
+        ix_lo = (ox0 - p.pad_x0 - PX) >> 1;
+    }
+    const T* xb = x + (size_t)mj * p.in_h * p.in_w * p.minor + (size_t)cv * VEC;
+
+    float acc[TH][TW][VEC];
+#pragma unroll
+    for (int a = 0; a < TH; ++a)
+#pragma unroll
+        for (int b = 0; b < TW; ++b)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[a][b][e] = 0.f;
+
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int iy = iy_lo + r;
+        const bool row_ok = (iy >= 0) & (iy < p.in_h);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ix = ix_lo + c;
+            V v;
+            if (row_ok & (ix >= 0) & (ix < p.in_w))
+                v.raw = *reinterpret_cast<const uint4*>(xb + ((size_t)iy * p.in_w + ix) * p.minor);
+            else
+                v.zero();
+#pragma unroll
+            for (int a = 0; a < TH; ++a) {
+                const int tap_y = (UP == 1) ? r - a * DOWN : 2 * r - a - PY;
+                if (tap_y < 0 || tap_y > 3) continue;
+#pragma unroll
+                for (int b = 0; b < TW; ++b) {
+                    const int tap_x = (UP == 1) ? c - b * DOWN : 2 * c - b - PX;
+                    if (tap_x < 0 || tap_x > 3) continue;
+                    const float wv = w[tap_y][tap_x];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[a][b][e] = fmaf(v.get(e), wv, acc[a][b][e]);
+                }
+            }
+        }
+    }
+
+    T* yb = y + (size_t)mj * p.out_h * p.out_w * p.minor + (size_t)cv * VEC;
+#pragma unroll
+    for (int a = 0; a < TH; ++a) {
+        const int oy = oy0 + a;
+        if (oy >= p.out_h) continue;
+#pragma unroll
+        for (int b = 0; b < TW; ++b) {
+            const int ox = ox0 + b;
+            if (ox >= p.out_w) continue;
+            V o;
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set(e, acc[a][b][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set2(e, acc[a][b][2 * e], acc[a][b][2 * e + 1]);
+            }
+            *reinterpret_cast<uint4*>(yb + ((size_t)oy * p.out_w + ox) * p.minor) = o.raw;
+        }
+    }
+}
+
+template <typename T, int UP, int DOWN, int PY, int PX>
+static void launch_vec(const void* x, const float* fir, void* y, UpfirdnParams& p, hipStream_t s) {
+    constexpr int TH = 2, TW = 2;
+    p.nvec = p.minor / Vec16<T>::N;
+    p.tiles_x = (p.out_w + TW - 1) / TW;
+    p.tiles_y = (p.out_h + TH - 1) / TH;
+    p.total = (unsigned)p.major * p.tiles_y * p.tiles_x * p.nvec;
+    const unsigned blocks = (p.total + 255u) / 256u;
+    hipLaunchKernelGGL((upfirdn2d_vec_kernel<T, UP, DOWN, PY, PX, TH, TW>), dim3(blocks), dim3(256), 0, s,
+                       (const T*)x, fir, (T*)y, p);
+}
+
+template <typename T>
+static int dispatch(const void* x, const float* fir, void* y, UpfirdnParams& p, hipStream_t s) {
+    const int vec = Vec16<T>::N;
+    const long long n_out = (long long)p.major * p.out_h * p.out_w * p.minor;
+    const long long n_tiles = (long long)p.major * ((p.out_h + 1) / 2) * ((p.out_w + 1) / 2) * (p.minor / vec + 1);
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
+    const bool square = p.up_x == p.up_y && p.down_x == p.down_y;
+    const bool fast = aligned && square && p.kh <= 4 && p.kw <= 4 && p.minor % vec == 0 && n_tiles < (1ll << 31) &&
+                      ((p.up_x == 1 && (p.down_x == 1 || p.down_x == 2)) || (p.up_x == 2 && p.down_x == 1));
+    if (fast) {
+        if (p.up_x == 1 && p.down_x == 1) launch_vec<T, 1, 1, 0, 0>(x, fir, y, p, s);
+        else if (p.up_x == 1) launch_vec<T, 1, 2, 0, 0>(x, fir, y, p, s);
+        else {
+            const int py = p.pad_y0 & 1, px = p.pad_x0 & 1;   // parity of (even tile origin - pad0)
+            if (!py && !px) launch_vec<T, 2, 1, 0, 0>(x, fir, y, p, s);
+            else if (!py && px) launch_vec<T, 2, 1, 0, 1>(x, fir, y, p, s);
+            else if (py && !px) launch_vec<T, 2, 1, 1, 0>(x, fir, y, p, s);
+            else launch_vec<T, 2, 1, 1, 1>(x, fir, y, p, s);
+        }
+    } else {
+        const long long blocks = (n_out + 255) / 256;
+        if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
+        hipLaunchKernelGGL((upfirdn2d_generic_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const T*)x, fir, (T*)y, p, n_out);
+    }
+    return MSG_CHECK_LAUNCH();
+}
+
+extern "C" int msg_upfirdn2d(const void* x, const float* fir, void* y, int dtype,
+                             int major, int in_h, int in_w, int minor, int kh, int kw,
+                             int up_x, int up_y, int down_x, int down_y,
+                             int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    if (major == 0 && fir && in_h > 0 && in_w > 0 && minor > 0) return MSG_OK;     // empty batch: nothing to do
+    if (!x || !fir || !y || major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 ||
+        up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
+        return MSG_EINVAL;
+    UpfirdnParams p{};
+    p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.kh = kh; p.kw = kw;
+    p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
+    // upfirdn2d_kernel.cu:167-168
+    p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+    p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+    if (p.out_h <= 0 || p.out_w <= 0) return MSG_EINVAL;
+    if (major == 0) return MSG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_F32) return dispatch<float>(x, fir, y, p, s);
+    if (dtype == MSG_BF16) return dispatch<bf16_t>(x, fir, y, p, s);
+    return MSG_EUNSUPPORTED;
+}

@@ -1,0 +1,26 @@
+"""Hot-path helpers with the reference's names: style-mixing noise and the EMA step
+(multi_stylegan/misc.py:183-199, 238-252)."""
+import random
+from typing import List, Union
+
+import torch
+
+
+def get_noise(batch_size: int, latent_dimension, p_mixed_noise: float = 0.9, device: str = "cuda") -> Union[
+        torch.Tensor, List]:
+    if (p_mixed_noise > 0) and (random.random() < p_mixed_noise):
+        return list(torch.randn(2, batch_size, latent_dimension, dtype=torch.float32, device=device).unbind(0))
+    return torch.randn(batch_size, latent_dimension, dtype=torch.float32, device=device)
+
+
+@torch.no_grad()
+def exponential_moving_average(model_ema, model_train, decay: float = 0.999) -> None:
+    """ema <- decay * ema + (1 - decay) * train over the named parameters, as ONE multi-tensor launch."""
+    assert type(model_ema) is type(model_train), "EMA can only be performed on networks of the same type!"
+    train = dict(model_train.named_parameters())
+    ema_params, src = [], []
+    for name, p in model_ema.named_parameters():
+        ema_params.append(p.data)
+        src.append(train[name].data)
+    torch._foreach_mul_(ema_params, decay)
+    torch._foreach_add_(ema_params, src, alpha=1 - decay)

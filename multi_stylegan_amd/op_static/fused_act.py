@@ -1,0 +1,133 @@
+"""Fused (noise +) bias + leaky-ReLU as a twice-differentiable autograd op on the gfx950 kernels.
+
+Drop-in for the reference's op_static/fused_act.py:22-89 (``FusedLeakyReLU`` module default scale 1.0, free
+function default sqrt(2)).  ``fused_bias_noise_leaky_relu`` additionally folds the generator's
+``NoiseInjection`` (multi_stylegan_generator.py:288-292) into the same pass; its parameters stay where the
+reference keeps them (``noise_injection.weight``, ``activation.bias``).
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _layout(x):
+    """-> (contiguous-in-its-own-layout tensor, step_b, pixels per sample, channels_last?)"""
+    if x.ndim == 2:
+        return x.contiguous(), 1, 1, True
+    if x.ndim != 4:
+        x = x.reshape(x.shape[0], x.shape[1], -1, 1)
+    cl = x.shape[1] > 1 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+    if not cl:
+        x = x.contiguous()
+    pix = x.shape[2] * x.shape[3]
+    return x, (1 if cl else pix), pix, cl
+
+
+def _noise_args(noise, x):
+    if noise is None:
+        return None, 1
+    if noise.shape[0] not in (1, x.shape[0]) or noise.shape[1] != 1 or noise.shape[2:] != x.shape[2:]:
+        raise _lib.MsgHipError(f"noise shape {tuple(noise.shape)} does not match input {tuple(x.shape)}")
+    return noise.to(torch.float32).contiguous(), noise.shape[0]
+
+
+def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
+    """y = act(x + w*noise + b) * scale  (grad=0), or the same with the slope taken from sign(ref) (grad=1)."""
+    shape = x.shape
+    x, step_b, pix, _ = _layout(x)
+    dev = _lib.require_gpu(x, bias, ref, noise, noise_weight)
+    if ref is not None:
+        ref = ref.reshape(x.shape).contiguous(memory_format=torch.channels_last if step_b == 1 and x.ndim == 4
+                                             else torch.contiguous_format)
+    y = torch.empty_like(x)
+    nz, nb = _noise_args(noise, x)
+    b32 = None if bias is None else bias.to(torch.float32).contiguous()
+    nw32 = None if noise_weight is None else noise_weight.to(torch.float32).contiguous()
+    nbytes = (2 + (ref is not None)) * x.numel() * x.element_size()
+    with torch.cuda.device(dev), _lib.kernel_clock.span(f"bias_act_fwd/{x.dtype}", nbytes):
+        code = _lib.lib().msg_fused_bias_act(
+            x.data_ptr(), _lib.ptr(b32), _lib.ptr(ref), y.data_ptr(), _lib.dtype_code(x), x.numel(), step_b,
+            x.shape[1], _lib.ptr(nz), _lib.ptr(nw32), nb, pix, act, grad, float(alpha), float(scale),
+            _lib.stream_of(dev))
+    _lib.check(code, "msg_fused_bias_act")
+    return y.reshape(shape) if y.shape != shape else y
+
+
+class FusedLeakyReLUFunctionBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, out, noise, need_bias, negative_slope, scale):
+        g, step_b, pix, _ = _layout(grad_output)
+        dev = _lib.require_gpu(g, out, noise)
+        o = out.reshape(g.shape)
+        o = o.contiguous(memory_format=torch.channels_last) if (step_b == 1 and g.ndim == 4) else o.contiguous()
+        gx = torch.empty_like(g)
+        channels = g.shape[1]
+        gb = torch.zeros(channels, dtype=torch.float32, device=dev) if need_bias else None
+        nz, nb = _noise_args(noise, g)
+        gnw = torch.zeros(1, dtype=torch.float32, device=dev) if noise is not None else None
+        with torch.cuda.device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
+            code = _lib.lib().msg_bias_act_backward(
+                g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g), g.numel(), step_b, channels,
+                _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
+                _lib.stream_of(dev))
+        _lib.check(code, "msg_bias_act_backward")
+        ctx.save_for_backward(out, noise)
+        ctx.cfg = (negative_slope, scale)
+        gx = gx.reshape(grad_output.shape)
+        if gb is None:
+            gb = torch.zeros(0, device=dev)
+        if gnw is None:
+            gnw = torch.zeros(0, device=dev)
+        return gx, gb, gnw
+
+    @staticmethod
+    def backward(ctx, gg_input, gg_bias, gg_noise_weight):
+        out, noise = ctx.saved_tensors
+        negative_slope, scale = ctx.cfg
+        if gg_input is None:
+            gg_input = torch.zeros_like(out)
+        ggb = gg_bias if (gg_bias is not None and gg_bias.numel()) else None
+        ggw = gg_noise_weight if (noise is not None and gg_noise_weight is not None
+                                  and gg_noise_weight.numel()) else None
+        # linear in (gg_input, gg_bias, gg_noise_weight); the mask has zero derivative (reference fused_act.py:45-51)
+        gg_out = _bias_act(gg_input, ggb, out, noise if ggw is not None else None, ggw, 1, negative_slope, scale)
+        return gg_out, None, None, None, None, None
+
+
+class FusedLeakyReLUFunction(Function):
+    @staticmethod
+    def forward(ctx, x, bias, noise, noise_weight, negative_slope, scale):
+        out = _bias_act(x, bias, None, noise, noise_weight, 0, negative_slope, scale)
+        ctx.save_for_backward(out, noise)
+        ctx.cfg = (negative_slope, scale, bias is not None, noise_weight is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        out, noise = ctx.saved_tensors
+        negative_slope, scale, has_bias, has_nw = ctx.cfg
+        gx, gb, gnw = FusedLeakyReLUFunctionBackward.apply(grad_output, out, noise if has_nw else None, has_bias,
+                                                           negative_slope, scale)
+        return gx, (gb if has_bias else None), None, (gnw if has_nw else None), None, None
+
+
+def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+    return FusedLeakyReLUFunction.apply(input, bias, None, None, negative_slope, scale)
+
+
+def fused_bias_noise_leaky_relu(input, bias, noise, noise_weight, negative_slope=0.2, scale=1.0):
+    """lrelu(input + noise_weight * noise + bias) * scale in one pass; noise is [B or 1, 1, H, W] (no grad)."""
+    return FusedLeakyReLUFunction.apply(input, bias, noise, noise_weight, negative_slope, scale)
+
+
+class FusedLeakyReLU(nn.Module):
+    def __init__(self, channel, negative_slope=0.2, scale=1.):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input):
+        return fused_leaky_relu(input, self.bias, self.negative_slope, self.scale)

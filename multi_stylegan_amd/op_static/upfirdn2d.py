@@ -1,0 +1,98 @@
+"""``upfirdn2d`` as a twice-differentiable autograd op on the gfx950 kernel.
+
+Mirrors the public interface of the reference's op_static/upfirdn2d.py:148-153.  The backward of an
+(up, down, pad) FIR pass is another FIR pass with up and down swapped, the FIR flipped and the padding of
+upfirdn2d.py:114-119; the backward of that is the original configuration again (upfirdn2d.py:66-88), so one
+native entry point serves all three orders.
+
+Memory layout: a channels-last input ([B,C,H,W] with NHWC strides) is handed to the kernel as
+``major = B, minor = C``, anything else as NCHW planes ``major = B*C, minor = 1`` -- the two layouts the
+reference's native signature already distinguishes (upfirdn2d.cpp:12-19).
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _is_channels_last(x):
+    return x.shape[1] > 1 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
+def _out_size(n, up, down, p0, p1, k):
+    return (n * up + p0 + p1 - k) // down + 1
+
+
+def _launch(x, fir, up, down, pad):
+    """x [B,C,H,W] (either layout), fir [kh,kw] fp32 on the same device -> y, same layout and dtype as x."""
+    up_x, up_y = up
+    down_x, down_y = down
+    px0, px1, py0, py1 = pad
+    dev = _lib.require_gpu(x, fir)
+    b, c, h, w = x.shape
+    kh, kw = fir.shape
+    oh, ow = _out_size(h, up_y, down_y, py0, py1, kh), _out_size(w, up_x, down_x, px0, px1, kw)
+    if oh <= 0 or ow <= 0:
+        raise _lib.MsgHipError(f"upfirdn2d: empty output {oh}x{ow}")
+    fir = fir.to(torch.float32).contiguous()
+    if _is_channels_last(x):
+        major, minor = b, c
+        y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+    else:
+        x = x.contiguous()
+        major, minor = b * c, 1
+        y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev)
+    key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up{up_x}down{down_x}/" \
+          f"{'vec' if minor % (16 // x.element_size()) == 0 and kh <= 4 and kw <= 4 else 'generic'}"
+    with torch.cuda.device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
+        code = _lib.lib().msg_upfirdn2d(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x),
+                                        major, h, w, minor, kh, kw, up_x, up_y, down_x, down_y,
+                                        px0, px1, py0, py1, _lib.stream_of(dev))
+    _lib.check(code, "msg_upfirdn2d")
+    return y
+
+
+class UpFirDn2dBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, fir, fir_flipped, up, down, pad, g_pad, in_hw):
+        ctx.save_for_backward(fir)
+        ctx.cfg = (up, down, pad)
+        gin = _launch(grad_output, fir_flipped, down, up, g_pad)       # up <-> down swapped
+        assert gin.shape[2:] == tuple(in_hw), (gin.shape, in_hw)
+        return gin
+
+    @staticmethod
+    def backward(ctx, gradgrad_input):
+        fir, = ctx.saved_tensors
+        up, down, pad = ctx.cfg
+        return UpFirDn2d.apply(gradgrad_input, fir, up, down, pad), None, None, None, None, None, None, None
+
+
+class UpFirDn2d(Function):
+    @staticmethod
+    def forward(ctx, x, fir, up, down, pad):
+        up_x, up_y = up
+        down_x, down_y = down
+        px0, px1, py0, py1 = pad
+        kh, kw = fir.shape
+        h, w = x.shape[2:]
+        y = _launch(x, fir, up, down, pad)
+        oh, ow = y.shape[2:]
+        # padding of the adjoint pass (reference op_static/upfirdn2d.py:114-119)
+        ctx.g_pad = (kw - px0 - 1, w * up_x - ow * down_x + px0 - up_x + 1,
+                     kh - py0 - 1, h * up_y - oh * down_y + py0 - up_y + 1)
+        ctx.cfg = (up, down, pad, (h, w))
+        ctx.save_for_backward(fir, torch.flip(fir, [0, 1]))
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        fir, fir_flipped = ctx.saved_tensors
+        up, down, pad, in_hw = ctx.cfg
+        gin = UpFirDn2dBackward.apply(grad_output, fir, fir_flipped, up, down, pad, ctx.g_pad, in_hw)
+        return gin, None, None, None, None
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    """FIR resampling of a [B,C,H,W] tensor; same arguments as the reference wrapper."""
+    return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

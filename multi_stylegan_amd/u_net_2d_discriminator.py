@@ -1,0 +1,162 @@
+"""U-Net discriminator on the gfx950 kernels, with the reference's nn.Module surface
+(multi_stylegan/u_net_2d_discriminator.py:14-381): same class names, constructor / forward signatures and
+state_dict keys.  Feature maps run channels-last (optionally bf16); the 6-channel input image and the two
+heads' outputs stay fp32."""
+import math
+from typing import Any, Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import conv_ops, equalized_layer
+from .op_static import FusedLeakyReLU, upfirdn2d
+
+
+def _fir2d(taps, gain=1.0):
+    t = torch.tensor(list(taps), dtype=torch.float32)
+    k = torch.outer(t, t)
+    return k / k.sum() * gain
+
+
+class Upsample(nn.Module):
+    def __init__(self, blur_kernel: List[int] = [1, 3, 3, 1], factor: int = 2) -> None:
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", _fir2d(blur_kernel))
+        p = len(blur_kernel) - factor
+        self.padding = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return upfirdn2d(input, self.kernel, up=self.factor, pad=self.padding)
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel: List[int] = [1, 3, 3, 1], sampling_factor: int = 1,
+                 sampling_factor_padding: int = 2, kernel_size: int = 3) -> None:
+        super().__init__()
+        p = (len(kernel) - sampling_factor_padding) + (kernel_size - 1)
+        self.padding = ((p + 1) // 2, p // 2)
+        self.register_buffer("kernel", _fir2d(kernel, float(sampling_factor ** 2) if sampling_factor > 1 else 1.0))
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return upfirdn2d(input, self.kernel, pad=self.padding)
+
+
+class MinibatchStdDev(nn.Module):
+    """Appends one plane holding the mean (over c,h,w) of the per-position std over the batch; statistics in
+    fp32.  The whole per-process batch is one group, as in the reference (:205-217)."""
+
+    def __init__(self, alpha: float = 1e-8) -> None:
+        super().__init__()
+        self.alpha = alpha
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        x = input.float()
+        var = (x - x.mean(dim=0, keepdim=True)).square().mean(dim=0)
+        stat = torch.sqrt(var.clamp(min=self.alpha)).mean()
+        plane = stat.to(input.dtype).reshape(1, 1, 1, 1).expand(input.shape[0], 1, input.shape[2], input.shape[3])
+        return conv_ops.to_compute_layout(torch.cat([input, plane], dim=1))
+
+
+class ResNetBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, mini_batch_std_dev: bool = False) -> None:
+        super().__init__()
+        self.mini_batch_std_dev = MinibatchStdDev() if mini_batch_std_dev else nn.Identity()
+        self.main_mapping = nn.Sequential(
+            equalized_layer.EqualizedConv2d(in_channels + 1 if mini_batch_std_dev else in_channels, out_channels,
+                                            kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False),
+            FusedLeakyReLU(out_channels),
+            equalized_layer.EqualizedConv2d(out_channels, out_channels, kernel_size=(3, 3), stride=(1, 1),
+                                            padding=(1, 1), bias=False),
+            FusedLeakyReLU(out_channels))
+        self.residual_mapping = equalized_layer.EqualizedConv2d(
+            in_channels, out_channels, kernel_size=1, stride=1, padding=0,
+            bias=False) if in_channels != out_channels else nn.Identity()
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        output = self.main_mapping(self.mini_batch_std_dev(input))
+        return (output + self.residual_mapping(input)) * (1.0 / math.sqrt(2))
+
+
+class NonLocalBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int) -> None:
+        super().__init__()
+        conv1x1 = lambda i, o: equalized_layer.EqualizedConv2d(i, o, kernel_size=(1, 1), padding=(0, 0), bias=False)
+        self.theta = conv1x1(in_channels, out_channels // 8)
+        self.phi = conv1x1(in_channels, out_channels // 8)
+        self.g = conv1x1(in_channels, out_channels // 2)
+        self.o = conv1x1(out_channels // 2, out_channels)
+        self.residual_mapping = conv1x1(in_channels, out_channels) if in_channels != out_channels else nn.Identity()
+        self.register_parameter(name="gamma", param=nn.Parameter(torch.tensor(0.), requires_grad=True))
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        bsz, _, height, width = input.shape
+        theta = self.theta(input).flatten(start_dim=2)
+        phi = F.max_pool2d(self.phi(input), kernel_size=2, stride=2).flatten(start_dim=2)
+        g = F.max_pool2d(self.g(input), kernel_size=2, stride=2).flatten(start_dim=2)
+        beta = torch.softmax(torch.bmm(theta.transpose(1, 2), phi).float(), dim=-1).to(input.dtype)
+        attended = torch.bmm(g, beta.transpose(1, 2)).view(bsz, -1, height, width)
+        output = self.o(conv_ops.to_compute_layout(attended))
+        return (self.gamma.to(input.dtype) * output + self.residual_mapping(input)) * (1.0 / math.sqrt(2))
+
+
+class Discriminator(nn.Module):
+    def __init__(self, config: Dict[str, Any], no_rfp: bool = False, no_gfp: bool = False) -> None:
+        super().__init__()
+        encoder_channels: Tuple[Tuple[int, int], ...] = config["encoder_channels"]
+        decoder_channels: Tuple[Tuple[int, int], ...] = config["decoder_channels"]
+        self.fft: bool = config["fft"]
+        if self.fft:
+            raise NotImplementedError("the fft input branch is off in the reference config (config.py:12) and is "
+                                      "outside the hot-path scope (DESIGN.md)")
+        input_channels = 3 if no_gfp else (6 if no_rfp else 9)
+        self.encoder_blocks = nn.ModuleList()
+        for index, (c_in, c_out) in enumerate(encoder_channels):
+            if index == 0:
+                self.encoder_blocks.append(ResNetBlock(input_channels, c_out))
+            elif index == 2:
+                self.encoder_blocks.append(NonLocalBlock(c_in, c_out))
+            else:
+                self.encoder_blocks.append(ResNetBlock(c_in, c_out,
+                                                       mini_batch_std_dev=index >= len(encoder_channels) - 2))
+        self.downscale_convolutions = nn.ModuleList([
+            nn.Sequential(equalized_layer.EqualizedConv2d(c, c, kernel_size=(3, 3), stride=(2, 2), padding=(0, 0)),
+                          Blur()) for _, c in encoder_channels[:-1]])
+        self.classification_head = nn.Sequential(
+            nn.AdaptiveAvgPool2d(output_size=(1, 1)), nn.Flatten(start_dim=1),
+            equalized_layer.EqualizedLinear(encoder_channels[-1][-1], 128, bias=False),
+            FusedLeakyReLU(channel=128),
+            equalized_layer.EqualizedLinear(128, 1, bias=False))
+        self.decoder_blocks = nn.ModuleList([
+            NonLocalBlock(c_in, c_out) if index == 1 else ResNetBlock(c_in, c_out)
+            for index, (c_in, c_out) in enumerate(decoder_channels)])
+        self.transposed_convolutions = nn.ModuleList()
+        for current, past, decoder in zip(reversed(encoder_channels[1:]), reversed(encoder_channels[:-1]),
+                                          decoder_channels):
+            self.transposed_convolutions.append(nn.Sequential(
+                Upsample(),
+                equalized_layer.EqualizedConv2d(current[-1], decoder[0] - past[-1], kernel_size=(1, 1),
+                                                stride=(1, 1), padding=(0, 0), bias=False)))
+        self.final_mapping = nn.Sequential(
+            FusedLeakyReLU(channel=decoder_channels[-1][-1]),
+            equalized_layer.EqualizedConv2d(decoder_channels[-1][-1], 1, kernel_size=(1, 1), stride=(1, 1),
+                                            padding=(0, 0), bias=False))
+        self.compute_dtype = torch.float32          # MI355X-side knob; default reproduces the reference
+
+    def forward(self, input: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = input.flatten(start_dim=1, end_dim=2)
+        x = conv_ops.to_compute_layout(x, self.compute_dtype)
+        skips = []
+        last = len(self.encoder_blocks) - 1
+        for index, block in enumerate(self.encoder_blocks):
+            x = block(x)
+            if index != last:
+                skips.append(x)
+                x = self.downscale_convolutions[index](x)
+        classification = self.classification_head(x.float()) if x.dtype != torch.float32 else \
+            self.classification_head(x)
+        for block, up, skip in zip(self.decoder_blocks, self.transposed_convolutions, reversed(skips)):
+            x = block(conv_ops.to_compute_layout(torch.cat([up(x), skip], dim=1)))
+        pixel_wise = self.final_mapping(x).float().contiguous().unsqueeze(dim=2)
+        return classification, pixel_wise

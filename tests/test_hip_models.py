@@ -1,0 +1,154 @@
+"""Whole-model and training-step parity on the GPU: product modules (multi_stylegan_amd) against golden vectors
+captured from the reference's modules.  Tolerance 1e-3 relative (fp32 path), as BASELINE.json states."""
+import copy
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+def _models(golden, which="tiny_models", gp="tinyG.sd.", dp="tinyD.sd."):
+    from tools.gen_golden import TINY_D, TINY_G
+    import multi_stylegan_amd as m
+    z = golden(which)
+    g, d = m.MultiStyleGANGenerator(TINY_G), m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True)
+    g.load_state_dict(z.state_dict(gp)); d.load_state_dict(z.state_dict(dp))
+    return z, g.to(DEV), d.to(DEV)
+
+
+@pytest.mark.parametrize("elide", [False, True])
+def test_tiny_generator(golden, elide):
+    z, g, _ = _models(golden)
+    g.elide_dead_branch = elide
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    zs = [z["tinyG.z0"].to(DEV), z["tinyG.z1"].to(DEV)]
+    noise = [z[f"tinyG.noise{i}"].to(DEV) for i in range(7)]
+    img, lat = g(zs, return_main_style_vectors=True, noise=noise, inject_index=3)
+    assert img.shape == (3, 2, 3, 32, 32)
+    assert rel_err(img, z["tinyG.image"]) < TOL and rel_err(lat, z["tinyG.latent"]) < TOL
+    img.backward(z["tinyG.gimage"].to(DEV))
+    none_grad = sorted(n for n, p in g.named_parameters() if p.grad is None)
+    assert none_grad == man["tinyG.none_grad"]
+    params = dict(g.named_parameters())
+    for key in z.keys("tinyG.grad."):
+        assert rel_err(params[key[len("tinyG.grad."):]].grad, z[key]) < TOL, key
+    # path-length style double backward (create_graph through every custom op)
+    g.zero_grad()
+    im, la = g(zs, return_main_style_vectors=True, noise=noise, inject_index=3)
+    gr, = torch.autograd.grad((im * z["tinyG.pl_image_noise"].to(DEV)).sum() / math.sqrt(3 * 32 * 32), la,
+                              create_graph=True)
+    pl = torch.sqrt(gr.pow(2).sum(2).mean(1) + 1e-8).mean()
+    pl.backward()
+    assert rel_err(gr, z["tinyG.pl_grads"]) < TOL and rel_err(pl, z["tinyG.pl"]) < TOL
+    for key in z.keys("tinyG.plgrad."):
+        assert rel_err(params[key[len("tinyG.plgrad."):]].grad, z[key]) < TOL, key
+
+
+def test_generator_path_length_entry(golden):
+    """Generator.forward(return_path_length_grads=True) with the image noise supplied."""
+    z, g, _ = _models(golden)
+    zs = [z["tinyG.z0"].to(DEV), z["tinyG.z1"].to(DEV)]
+    noise = [z[f"tinyG.noise{i}"].to(DEV) for i in range(7)]
+    gr = g(zs, noise=noise, inject_index=3, return_path_length_grads=True,
+           path_length_noise=z["tinyG.pl_image_noise"].to(DEV))
+    assert rel_err(gr, z["tinyG.pl_grads"]) < TOL
+
+
+def test_tiny_discriminator(golden):
+    z, _, d = _models(golden)
+    x = z["tinyD.x"].to(DEV).requires_grad_(True)
+    s, px = d(x)
+    assert s.shape == (3, 1) and px.shape == (3, 1, 1, 32, 32)
+    assert rel_err(s, z["tinyD.scalar"]) < TOL and rel_err(px, z["tinyD.pixel"]) < TOL
+    gin, = torch.autograd.grad((s, px), x, (z["tinyD.gs"].to(DEV), z["tinyD.gpx"].to(DEV)), create_graph=True)
+    assert rel_err(gin, z["tinyD.gin"]) < TOL
+    r1 = 0.5 * gin.pow(2).reshape(3, -1).sum(1).mean()
+    r1.backward()
+    assert rel_err(r1, z["tinyD.r1"]) < TOL
+    params = dict(d.named_parameters())
+    for key in z.keys("tinyD.r1grad."):
+        assert rel_err(params[key[len("tinyD.r1grad."):]].grad, z[key]) < TOL, key
+
+
+def test_bf16_models_track_fp32(golden):
+    """bf16 storage path: same graph, looser documented tolerance (5e-2 of max|ref|)."""
+    z, g, d = _models(golden)
+    g.compute_dtype = d.compute_dtype = torch.bfloat16
+    zs = [z["tinyG.z0"].to(DEV), z["tinyG.z1"].to(DEV)]
+    noise = [z[f"tinyG.noise{i}"].to(DEV) for i in range(7)]
+    img = g(zs, noise=noise, inject_index=3)
+    assert img.dtype == torch.float32 and rel_err(img, z["tinyG.image"]) < 5e-2
+    s, px = d(z["tinyD.x"].to(DEV))
+    assert rel_err(s, z["tinyD.scalar"]) < 5e-2 and rel_err(px, z["tinyD.pixel"]) < 5e-2
+
+
+def test_train_iteration(golden):
+    """ModelWrapper.train_iteration x2 (iterations 1 and 16 -> R1 and path length fire) vs the reference-driven
+    golden run: four D losses, R1, G losses, path length + running mean, post-step parameters, EMA, and the dead
+    second-stream weights staying bit-identical."""
+    import multi_stylegan_amd as m
+    from test_oracle_golden import load_train_draws
+    z, g, d = _models(golden, "train_step", "train.G0.", "train.D0.")
+    dead0 = g.main_convolutions_2[3].modulated_convolution.weight.detach().clone()
+    trainer = m.ModelWrapper(g, d, device=DEV)
+    names = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_discriminator_fake",
+             "loss_d_real_px": "loss_discriminator_real_pixel_wise", "loss_d_fake_px": "loss_discriminator_fake_pixel_wise",
+             "r1": "loss_discriminator_regularization", "loss_g": "loss_generator",
+             "loss_g_px": "loss_generator_pixel_wise", "path_length": "path_length",
+             "loss_pl": "loss_path_length_regularization"}
+    for step, iteration in enumerate((1, 16)):
+        real, draws = load_train_draws(z, step, m.model_wrapper)
+        trainer.iteration = iteration - 1
+        trainer.train_iteration(real.to(DEV), draws.to(DEV))
+        log = trainer.pop_logs()
+        pre = f"train.it{step}."
+        for key in z.keys(pre + "log."):
+            want, got = float(z[key]), log[names[key[len(pre + "log."):]]][0]
+            assert abs(got - want) <= TOL * max(1.0, abs(want)), (key, got, want)
+        gp, dp = dict(g.named_parameters()), dict(d.named_parameters())
+        ep = dict(trainer.generator_ema.named_parameters())
+        for key in z.keys(pre + "G."):
+            assert rel_err(gp[key[len(pre + "G."):]], z[key]) < TOL, key
+        for key in z.keys(pre + "Gema."):
+            assert rel_err(ep[key[len(pre + "Gema."):]], z[key]) < TOL, key
+        for key in z.keys(pre + "D."):
+            assert rel_err(dp[key[len(pre + "D."):]], z[key]) < TOL, key
+    assert rel_err(trainer.path_length_regularization.mean_path_length, z["train.it1.mean_path_length"]) < TOL
+    assert torch.equal(g.main_convolutions_2[3].modulated_convolution.weight.cpu(), dead0.cpu())
+
+
+def test_config1_64px_matches_oracle():
+    """BASELINE config 1 (64x64, 5 stages x 512 channels, B=4): product on the GPU vs the CPU oracle with the
+    same weights, z and noise."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    from oracle import models as om
+    torch.manual_seed(3)
+    cfg = generator_config_for_resolution(64)
+    go = om.Generator(cfg)
+    gd = m.MultiStyleGANGenerator(cfg)
+    gd.load_state_dict(go.state_dict())
+    gd.to(DEV)
+    z = [torch.randn(4, 512), torch.randn(4, 512)]
+    noise = [torch.randn(4, 1, 4, 4)] + [torch.randn(4, 1, 2 ** (i // 2 + 3), 2 ** (i // 2 + 3)) for i in range(8)]
+    with torch.no_grad():
+        want = go(z, noise=noise, inject_index=4)
+        got = gd([t.to(DEV) for t in z], noise=[t.to(DEV) for t in noise], inject_index=4)
+    assert rel_err(got, want) < TOL
+    do = om.Discriminator(no_rfp=True)
+    dd = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    dd.load_state_dict(do.state_dict())
+    dd.to(DEV)
+    x = torch.rand(4, 2, 3, 64, 64)
+    with torch.no_grad():
+        ws, wp = do(x)
+        gs, gp = dd(x.to(DEV))
+    assert rel_err(gs, ws) < TOL and rel_err(gp, wp) < TOL

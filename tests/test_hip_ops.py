@@ -1,0 +1,177 @@
+"""Parity of the gfx950 kernels (called through the C ABI via multi_stylegan_amd.op_static) against the golden
+vectors and the CPU oracle.  fp32 tolerance: 1e-3 relative (BASELINE.json north_star); in practice ~1e-6.
+bf16 storage: 2e-2 relative to max|ref| (8-bit mantissa on inputs and outputs, fp32 arithmetic inside)."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-3
+TOL16 = 2e-2
+DEV = "cuda:0"
+
+UPFIRDN_CASES = ["g_blur_pad21_gain4", "g_skip_up2_pad21", "d_blur_pad22_odd", "bwd_of_up2_down2",
+                 "asym_blur_pad21", "asym_up2_pad21", "asym_down2_pad12", "blur_pad11"]
+
+
+def _ops():
+    from multi_stylegan_amd import op_static
+    return op_static
+
+
+@pytest.mark.parametrize("case", UPFIRDN_CASES)
+def test_upfirdn2d_golden_nchw(golden, case):
+    z, ops = golden("upfirdn2d"), _ops()
+    up, down, p0, p1 = [int(v) for v in z[case + ".cfg"]]
+    x = z[case + ".x"].to(DEV).requires_grad_(True)
+    gy = z[case + ".gy"].to(DEV).requires_grad_(True)
+    fir = z[case + ".fir"].to(DEV)
+    y = ops.upfirdn2d(x, fir, up=up, down=down, pad=(p0, p1))
+    gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+    ggy, = torch.autograd.grad(gx, gy, z[case + ".ggx"].to(DEV))
+    assert rel_err(y, z[case + ".y"]) < TOL32
+    assert rel_err(gx, z[case + ".gx"]) < TOL32
+    assert rel_err(ggy, z[case + ".ggy"]) < TOL32
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOL16)])
+@pytest.mark.parametrize("cfg", [  # (up, down, pad, channels, h, w)
+    (1, 1, (2, 1), 16, 12, 10), (1, 1, (2, 2), 8, 15, 15), (2, 1, (2, 1), 24, 7, 9), (1, 2, (1, 1), 16, 14, 18),
+    (2, 1, (1, 2), 8, 5, 6), (1, 2, (2, 1), 40, 9, 11), (1, 1, (1, 1), 12, 5, 5), (3, 2, (2, 3), 8, 6, 7),
+    (1, 1, (-1, 0), 8, 9, 9)])
+def test_upfirdn2d_channels_last_vs_oracle(cfg, dtype, tol):
+    """The vectorised channels-last fast paths (and the generic one for odd configs) against the CPU oracle,
+    forward + adjoint + second order, asymmetric random FIR so any flip/transposition shows."""
+    from oracle import ops as oo
+    ops = _ops()
+    up, down, pad, c, h, w = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    fir = torch.randn(4, 4, generator=g) if up != 3 else torch.randn(5, 3, generator=g)
+    x = torch.randn(2, c, h, w, generator=g).to(dtype).float()
+    xr = x.clone().requires_grad_(True)
+    yr = oo.upfirdn2d(xr, fir, up=up, down=down, pad=pad)
+    gy = torch.randn(yr.shape, generator=g).to(dtype).float()
+    gyr = gy.clone().requires_grad_(True)
+    gxr, = torch.autograd.grad(yr, xr, gyr, create_graph=True)
+    ggx = torch.randn(x.shape, generator=g).to(dtype).float()
+    ggyr, = torch.autograd.grad(gxr, gyr, ggx)
+    xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gyd = gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.upfirdn2d(xd, fir.to(DEV), up=up, down=down, pad=pad)
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.dtype == dtype
+    gx, = torch.autograd.grad(y, xd, gyd, create_graph=True)
+    ggy, = torch.autograd.grad(gx, gyd, ggx.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    assert rel_err(y.float(), yr) < tol
+    assert rel_err(gx.float(), gxr) < tol
+    assert rel_err(ggy.float(), ggyr) < tol
+
+
+def test_upfirdn2d_edge_cases():
+    ops = _ops()
+    from multi_stylegan_amd._lib import MsgHipError
+    fir = torch.ones(4, 4, device=DEV) / 16
+    with pytest.raises(MsgHipError):                       # CPU tensors: no silent fallback
+        ops.upfirdn2d(torch.zeros(1, 1, 4, 4), fir.cpu())
+    with pytest.raises(MsgHipError):                       # empty output
+        ops.upfirdn2d(torch.zeros(1, 1, 2, 2, device=DEV), fir, pad=(0, 0))
+    with pytest.raises(MsgHipError):                       # unsupported storage type
+        ops.upfirdn2d(torch.zeros(1, 1, 8, 8, device=DEV, dtype=torch.float64), fir, pad=(2, 1))
+    y = ops.upfirdn2d(torch.zeros(0, 8, 8, 8, device=DEV), fir, pad=(2, 1))      # empty batch
+    assert y.shape == (0, 8, 8, 8)
+    x = torch.ones(1, 8, 6, 6, device=DEV)
+    up = ops.upfirdn2d(x, fir, up=2, pad=(2, 1))           # sum-1 FIR, no gain: interior == 1/4 (quirk Q3)
+    assert torch.allclose(up[0, 0, 3:9, 3:9], torch.full((6, 6), 0.25, device=DEV))
+
+
+def test_upfirdn2d_full_size_properties():
+    """BASELINE config sizes (B=2 of the 16): linearity, adjointness <F x, g> == <x, F^T g>, and agreement between
+    the NCHW (generic) and channels-last (vector) kernels on the same data."""
+    ops = _ops()
+    torch.manual_seed(0)
+    fir = (torch.outer(torch.tensor([1., 3., 3., 1.]), torch.tensor([1., 3., 3., 1.])) / 64 * 4).to(DEV)
+    x = torch.randn(2, 512, 256, 256, device=DEV).contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn_like(x)
+    y = ops.upfirdn2d(x, fir, pad=(2, 1))
+    y2 = ops.upfirdn2d(x2, fir, pad=(2, 1))
+    ysum = ops.upfirdn2d(x + 2 * x2, fir, pad=(2, 1))
+    assert rel_err(ysum, y + 2 * y2) < 1e-5
+    g = torch.randn_like(y)
+    xg = x.detach().clone().requires_grad_(True)
+    gx, = torch.autograd.grad(ops.upfirdn2d(xg, fir, pad=(2, 1)), xg, g)
+    lhs, rhs = (y.double() * g.double()).sum(), (x.double() * gx.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+    sub = x[:1, :64].contiguous()                                            # NCHW planes -> generic kernel
+    assert rel_err(ops.upfirdn2d(sub, fir, pad=(2, 1)), y[:1, :64]) < 1e-6
+    # D-side up-2 and its adjoint (down-2) at 256 ch @ 128 -> 256
+    fir1 = fir / 4
+    u = torch.randn(2, 256, 128, 128, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    up = ops.upfirdn2d(u, fir1, up=2, pad=(2, 1))
+    assert up.shape == (2, 256, 256, 256)
+    gu = torch.randn_like(up)
+    gin, = torch.autograd.grad(up, u, gu)
+    lhs, rhs = (up.double() * gu.double()).sum(), (u.double() * gin.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["mlp_2d", "conv_4d", "conv_4d_sqrt2"])
+def test_fused_leaky_relu_golden(golden, case):
+    z, ops = golden("fused_act"), _ops()
+    x, b = z[case + ".x"].to(DEV).requires_grad_(True), z[case + ".b"].to(DEV).requires_grad_(True)
+    gy = z[case + ".gy"].to(DEV).requires_grad_(True)
+    y = ops.fused_leaky_relu(x, b, 0.2, float(z[case + ".scale"]))
+    gx, gb = torch.autograd.grad(y, (x, b), gy, create_graph=True)
+    ggy, = torch.autograd.grad((gx, gb), gy, (z[case + ".ggx"].to(DEV), z[case + ".ggb"].to(DEV)))
+    for got, key in ((y, "y"), (gx, "gx"), (gb, "gb"), (ggy, "ggy")):
+        assert rel_err(got, z[f"{case}.{key}"]) < TOL32, key
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOL16)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("shape,noise_batch", [((3, 16, 6, 5), 3), ((2, 24, 4, 4), 1), ((2, 40, 9, 7), 2),
+                                               ((4, 8, 16, 16), 4), ((2, 6, 5, 5), 2)])
+def test_fused_bias_noise_act_vs_oracle(shape, noise_batch, layout, dtype, tol):
+    from oracle import ops as oo
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(dtype).float()
+    bias = torch.randn(shape[1], generator=g)
+    noise = torch.randn(noise_batch, 1, *shape[2:], generator=g)
+    nw = torch.randn(1, generator=g)
+    gy = torch.randn(*shape, generator=g).to(dtype).float()
+    ggx, ggb, ggw = torch.randn(*shape, generator=g).to(dtype).float(), torch.randn(shape[1], generator=g), \
+        torch.randn(1, generator=g)
+    xr, br, wr, gyr = [t.clone().requires_grad_(True) for t in (x, bias, nw, gy)]
+    yr = oo.fused_leaky_relu(oo.noise_injection(xr, wr, noise), br, 0.2, 1.0)
+    gr = torch.autograd.grad(yr, (xr, br, wr), gyr, create_graph=True)
+    ggyr, = torch.autograd.grad(gr, gyr, (ggx, ggb, ggw))
+    fmt = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+    mv = lambda t: t.to(DEV, dtype).contiguous(memory_format=fmt)
+    xd, gyd = mv(x).requires_grad_(True), mv(gy).requires_grad_(True)
+    bd, wd = bias.to(DEV).requires_grad_(True), nw.to(DEV).requires_grad_(True)
+    y = ops.fused_bias_noise_leaky_relu(xd, bd, noise.to(DEV), wd, 0.2, 1.0)
+    gd = torch.autograd.grad(y, (xd, bd, wd), gyd, create_graph=True)
+    ggy, = torch.autograd.grad(gd, gyd, (mv(ggx), ggb.to(DEV), ggw.to(DEV)))
+    assert rel_err(y.float(), yr) < tol
+    assert rel_err(gd[0].float(), gr[0]) < tol
+    assert rel_err(gd[1], gr[1]) < tol * (1 if dtype == torch.float32 else 4)
+    assert rel_err(gd[2], gr[2]) < tol * (1 if dtype == torch.float32 else 4)
+    assert rel_err(ggy.float(), ggyr) < tol
+
+
+def test_fused_act_full_size_properties():
+    """[4,512,256,256] channels-last bf16: mask consistency and grad_bias == column sums of grad_input."""
+    ops = _ops()
+    torch.manual_seed(1)
+    x = torch.randn(4, 512, 256, 256, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(512, device=DEV, requires_grad=True)
+    xg = x.clone().requires_grad_(True)
+    y = ops.fused_leaky_relu(xg, b, 0.2, 1.0)
+    ref = torch.nn.functional.leaky_relu(x.float() + b.detach()[None, :, None, None], 0.2)
+    assert rel_err(y.float(), ref) < TOL16
+    gy = torch.randn_like(y)
+    gx, gb = torch.autograd.grad(y, (xg, b), gy)
+    want_gx = gy.float() * torch.where(y.float() > 0, 1.0, 0.2)
+    assert rel_err(gx.float(), want_gx) < TOL16
+    assert rel_err(gb, gx.float().sum(dim=(0, 2, 3))) < 2e-3

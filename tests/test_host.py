@@ -1,0 +1,153 @@
+"""CPU-side checks of the product's host logic: C-ABI library exports, module/state_dict surface, losses, the
+gradient-bucket reducer and the trainer's data-parallel path under gloo (world size 2)."""
+import ctypes
+import json
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT, rel_err
+
+
+def test_library_exports_every_declared_symbol():
+    from multi_stylegan_amd import _lib
+    from multi_stylegan_amd.build import build
+    build(verbose=False)
+    names = _lib.declared_symbols()
+    assert {"msg_upfirdn2d", "msg_fused_bias_act", "msg_bias_act_backward", "msg_abi_version"} <= set(names)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in names:
+        assert hasattr(handle, name), f"{name} declared in include/msg_hip.h but not exported"
+    assert _lib.lib().msg_build_arch() == b"gfx950" and _lib.lib().msg_abi_version() >= 1
+    assert set(_lib._SIGNATURES) == set(names)            # the ctypes table binds all of them, nothing else
+
+
+def test_product_modules_keep_reference_surface():
+    import multi_stylegan_amd as m
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    g = m.MultiStyleGANGenerator(m.multi_style_gan_generator_config)
+    d = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    assert {k: list(v.shape) for k, v in g.state_dict().items()} == man["generator"]
+    assert {k: list(v.shape) for k, v in d.state_dict().items()} == man["discriminator"]
+    assert [len(list(grp["params"])) for grp in g.get_parameters()] == man["generator_param_groups"]
+    assert sum(p.numel() for p in g.live_parameters()) == 32565276
+    with pytest.raises(Exception, match="no CPU fallback"):
+        g(torch.randn(2, 512))                                           # product path refuses CPU tensors
+
+
+def test_losses_match_oracle(golden):
+    from multi_stylegan_amd import loss
+    from oracle import train as ot
+    torch.manual_seed(0)
+    pr, pf = torch.randn(4, 1), torch.randn(4, 1, 1, 8, 8)
+    assert rel_err(loss.NonSaturatingLogisticGeneratorLoss()(pf), ot.g_logistic_loss(pf)) < 1e-6
+    a, b = loss.NonSaturatingLogisticDiscriminatorLoss()(pr, pr * 2)
+    c, d_ = ot.d_logistic_loss(pr, pr * 2)
+    assert rel_err(a, c) < 1e-6 and rel_err(b, d_) < 1e-6
+    # path length: value, running mean and -- the subtle part -- the gradient through the running mean
+    pl_a, pl_b = loss.PathLengthRegularization(), ot.PathLength()
+    for _ in range(3):
+        g1 = torch.randn(2, 5, 16, requires_grad=True)
+        g2 = g1.detach().clone().requires_grad_(True)
+        la, _ = pl_a(g1)
+        lb, _ = pl_b(g2)
+        la.backward(); lb.backward()
+        assert rel_err(la, lb) < 1e-6 and rel_err(g1.grad, g2.grad) < 1e-6
+    assert rel_err(pl_a.mean_path_length, pl_b.mean_path_length) < 1e-6
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.a = torch.nn.Linear(6, 5)
+        self.b = torch.nn.Linear(5, 3)
+        self.unused = torch.nn.Parameter(torch.ones(4))
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def _reducer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multi_stylegan_amd.dist import GradBucketReducer
+    model = _Toy()
+    params = [p for n, p in model.named_parameters() if n != "unused"]
+    red = GradBucketReducer(params, bucket_bytes=64, overlap=True)       # tiny buckets -> several of them
+    assert len(red.buckets) > 1
+    torch.manual_seed(100 + rank)
+    x = torch.randn(7, 6)
+    for attempt in range(2):                                             # second pass exercises zero_grad reuse
+        local = [t.clone() for t in torch.autograd.grad(model(x).square().sum(), params)]   # before any collective
+        red.zero_grad(); red.arm()
+        model(x).square().sum().backward()                 # buckets are all-reduced from the hooks, overlapped
+        red.finish()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        for i, p in enumerate(params):
+            want = sum(g[i] for g in gathered) / world
+            assert torch.allclose(p.grad, want, atol=1e-6), (rank, attempt, i)
+        total = red.clip_(0.5)
+        norm_after = torch.sqrt(sum(p.grad.square().sum() for p in params))
+        assert norm_after <= 0.5 + 1e-4 and total > 0
+    assert model.unused.grad is None
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_bucket_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 500
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == "ok"
+
+
+def _trainer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from multi_stylegan_amd.model_wrapper import ModelWrapper
+    from oracle import models as om                      # CPU stand-ins for G/D: the trainer logic is device-agnostic
+    from tools.gen_golden import TINY_D, TINY_G
+    torch.manual_seed(10 + rank)                         # different init per rank: broadcast must fix it
+    g, d = om.Generator(TINY_G), om.Discriminator(TINY_D, no_rfp=True)
+    g.live_parameters = lambda: [p for n, p in g.named_parameters() if not n.startswith("main_convolutions_2.")]
+    orig_forward = g.forward
+    g.forward = lambda *a, path_length_noise=None, **k: orig_forward(*a, **k)
+    tr = ModelWrapper(g, d, device="cpu", bucket_bytes=1 << 16)
+    tr.iteration = 15                                    # next iteration is 16: R1 and path length fire
+    torch.manual_seed(1000 + rank)                       # different data per rank
+    tr.train_iteration(torch.rand(2, 2, 3, 32, 32))
+    logs = tr.pop_logs()
+    assert {"loss_discriminator_regularization", "path_length", "loss_generator"} <= set(logs)
+    flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), "replicas diverged"
+    mpl = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(mpl, tr.path_length_regularization.mean_path_length)
+    assert torch.equal(mpl[0], mpl[1])
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_trainer_data_parallel_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == "ok"

@@ -47,13 +47,26 @@ def parse_args():
     return ap.parse_args()
 
 
+def note(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """CPU threads this process may really use (affinity mask, and the GPU box's 16-core share per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("MSG_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(iters: int):
     """The CPU oracle on BASELINE config 1 (64x64, 5 x 512 channels, B=4): `iters` plain iterations after one
     warm-up.  A bounded sample: the 256^2 workload itself takes minutes per iteration on a CPU."""
     from multi_stylegan_amd.config import generator_config_for_resolution
     from oracle import models as om, train as ot
     import copy
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     torch.set_num_threads(threads)
     torch.manual_seed(1234)
     g, d = om.Generator(generator_config_for_resolution(64)), om.Discriminator(no_rfp=True)
@@ -104,8 +117,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    note(f"models built on {dev}; warm-up ({args.warmup} iterations, includes library kernel selection)")
+    for i in range(args.warmup):
         trainer.train_iteration(real)
+        torch.cuda.synchronize(dev)
+        note(f"warm-up iteration {i + 1} done")
     trainer.pop_logs()
     _lib.kernel_clock.reset(enabled=not args.no_kernel_clock)
     barrier()
@@ -118,6 +134,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
+    note(f"timed region done: {elapsed:.2f} s for {args.steps} steps")
     clock = _lib.kernel_clock.summary()
     _lib.kernel_clock.reset(enabled=False)
     logs = trainer.pop_logs()
@@ -150,6 +167,7 @@ def main():
             "loss_d_real_last": round(logs["loss_discriminator_real"][-1], 4) if logs else None,
         }
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
+            note("CPU baseline (oracle, 64x64, B=4) ...")
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -86,6 +86,36 @@ int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
                           float* grad_bias, const float* noise, float* grad_noise_weight,
                           int noise_batch, int pix, float alpha, float scale, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * a3/a4  dense contractions on the matrix cores (channels-last, implicit GEMM).
+ * The reference has no native boundary here: it calls F.conv2d / F.conv_transpose2d with groups = batch
+ * (multi_stylegan/multi_stylegan_generator.py:391-411) and F.conv2d / F.linear for the equalized layers
+ * (multi_stylegan/equalized_layer.py:63-74, 244-254).  These two entries sit behind ModulatedConv2d.forward,
+ * EqualizedConv2d.forward and EqualizedLinear.forward.
+ *
+ * msg_conv2d_fprop:
+ *   y[b,oh,ow,n] = bias[n] + sum_{kh,kw,c} x[b, (oh*stride+kh-pad)/in_up, (ow*stride+kw-pad)/in_up, c] * w[(b)][n][kh][kw][c]
+ *   x  [B, IH, IW, Cx]   Cx = channel stride (multiple of 16 B); channels >= the real count must hold finite values
+ *   w  [(B)][N][kh*kw][Ck]  Ck = input channels zero-padded to a multiple of 128 B; w_batch_stride = 0 -> shared
+ *   y  [B, OH, OW, ldy]  (pixel_shuffle = 1: N = 4*O and y is [B, 2*OH, 2*OW, ldy] with
+ *                         y[b, 2oh+dy, 2ow+dx, o] = result[n = (2dy+dx)*O + o] -- the 2x2 stride-2 transposed conv)
+ *   in_up > 1 (stride must be 1): samples exist only where the numerator is divisible (transposed strided conv).
+ *   Data gradients are the same entry with the caller's re-laid weights.
+ * msg_conv2d_wgrad:
+ *   gw[(b)][o][tap][i] (+)= sum_{pixels} gy[b,oh,ow,o] * x[b, oh*stride+kh-pad, ow*stride+kw-pad, i]
+ *   gw fp32 [(B)][O][kh*kw][ldgw]; per_sample = 1 (k_chunks must be 1): one slice per sample, plain stores;
+ *   otherwise every (sample, pixel-chunk) slice ACCUMULATES with float atomics (zero gw first).
+ *   pixel_shuffle = 1: OH,OW are the LOW-res extent, gy is [B,2*OH,2*OW,ldgy], tap = (dy,dx).
+ * ------------------------------------------------------------------------- */
+int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, int dtype,
+                     int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                     int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                     long long w_batch_stride, void* stream);
+int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
+                     int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
+                     int kh, int kw, int stride, int pad, int pixel_shuffle,
+                     int per_sample, int k_chunks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,251 @@
+// a3/a4: implicit-GEMM convolution on the gfx950 matrix cores, channels-last.
+//
+//   Y[b, oh, ow, n] = bias[n] + sum_{kh,kw,c} X[b, (oh*stride + kh - pad)/in_up, (ow*stride + kw - pad)/in_up, c]
+//                                            * W[(b)][n][kh][kw][c]
+//
+// GEMM view: M = output pixels, N = output channels, K = (tap, channel).  One kernel serves every dense contraction
+// of the path: 3x3/1x1 "same" convs, the strided 3x3 of the discriminator, the 2x2 stride-2 transposed conv of the
+// generator (as a 1x1 conv to 4*O channels written pixel-shuffled), and -- with the weights re-laid by the caller --
+// all of their data gradients (in_up = 2 expresses a transposed strided conv as a gather with parity holes).
+// Weights may be shared by the batch (batch folded into M) or per sample (grid.z = sample): the latter is how the
+// modulated/demodulated convolution runs (multi_stylegan_generator.py:384-411 builds one weight set per sample).
+//
+// Tiling (wave64, MFMA 32x32): workgroup 128(M) x 128(N), 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64
+// accumulator VGPRs).  K advances in 128-byte channel runs (64 bf16 / 32 f32) of one tap, so every staged row is one
+// fully coalesced 128-B segment of an NHWC pixel.  Global -> registers -> LDS staging, double-buffered (load tile t+1
+// while the matrix cores chew tile t, one barrier per tile); halo / parity / tail rows are zero-filled in registers.
+// LDS rows are 128 B; 16-B slot s of row r lives at slot s ^ ((r >> 1) & 7), which makes both the ds_write_b128 of
+// the staging pass and the ds_read_b128 fragment reads conflict-free.  The epilogue goes through LDS so that each
+// lane stores 16 contiguous bytes.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact fp32).
+#include "msg_common.h"
+
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+
+struct ConvParams {
+    int B, IH, IW, Cx, Ck, OH, OW, N, ldy;
+    int kh, kw, stride, pad, in_up, pixel_shuffle, per_sample;
+    long long x_bstride, w_bstride, y_bstride;     // elements
+    int Mtot, n_chunks, n_iters, m_tiles, n_tiles;
+};
+
+constexpr int BM = 128, BN = 128, ROWB = 128;                  // tile rows / cols, bytes per staged row
+constexpr int STAGE_BYTES = (BM + BN) * ROWB;                  // 32 KiB
+__device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                            T* __restrict__ y, const float* __restrict__ bias,
+                                                            ConvParams p) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int BKE = ROWB / sizeof(T);
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (int)(L % p.n_tiles) * BN;
+    const int m0 = (int)(L / p.n_tiles) * BM;
+    const int bz = blockIdx.z;
+
+    // ---- staging assignment: this thread moves 16-B slot `slot` of rows rbase + 32 j (j = 0..3) of A and of B
+    const int slot = tid & 7, rbase = tid >> 3;
+    int a_ih0[4], a_iw0[4];
+    long long a_off[4];
+    bool a_ok[4];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + rbase + 32 * j;
+        a_ok[j] = m < p.Mtot;
+        const int mm = a_ok[j] ? m : 0;
+        const int b = p.per_sample ? bz : mm / ohw;
+        const int pix = p.per_sample ? mm : mm - b * ohw;
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        a_ih0[j] = oh * p.stride - p.pad;
+        a_iw0[j] = ow * p.stride - p.pad;
+        a_off[j] = (long long)b * p.x_bstride;
+    }
+    const T* wb = w + (p.per_sample ? (long long)bz * p.w_bstride : 0);
+    const int taps = p.kh * p.kw;
+
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int it) {
+        const int tap = it / p.n_chunks, chunk = it - tap * p.n_chunks;
+        const int kh_ = tap / p.kw, kw_ = tap - kh_ * p.kw;
+        const int c = chunk * BKE + slot * VEC;
+        const bool c_ok = c + VEC <= p.Cx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ih = a_ih0[j] + kh_, iw = a_iw0[j] + kw_;
+            bool ok = a_ok[j] & c_ok & (ih >= 0) & (iw >= 0);
+            if (p.in_up > 1) {
+                ok = ok & (ih % p.in_up == 0) & (iw % p.in_up == 0);
+                ih /= p.in_up; iw /= p.in_up;
+            }
+            ok = ok & (ih < p.IH) & (iw < p.IW);
+            ra[j] = ok ? *reinterpret_cast<const uint4*>(x + a_off[j] + ((long long)ih * p.IW + iw) * p.Cx + c)
+                       : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + rbase + 32 * j;
+            rb[j] = (n < p.N) ? *reinterpret_cast<const uint4*>(wb + ((long long)n * taps + tap) * p.Ck + c)
+                              : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = rbase + 32 * j;
+            *reinterpret_cast<uint4*>(sa + swz(r, slot)) = ra[j];
+            *reinterpret_cast<uint4*>(sb + swz(r, slot)) = rb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int it = 0; it < p.n_iters; ++it) {
+        const int stage = it & 1;
+        if (it + 1 < p.n_iters) load_tile(it + 1);                   // in flight under the MFMAs below
+        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sb = sa + BM * ROWB;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {                           // 4 k-steps of 16
+                bf16v8 fa[2], fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, 2 * kk + lh));
+                    fb[t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, 2 * kk + lh));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // lane half h owns k = 16h .. 16h+15 of the 32-float run (any k order is fine as long as A and B agree)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 fa[2], fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[t] = *reinterpret_cast<const f32x4*>(sa + swz(wm * 64 + t * 32 + lr, 4 * lh + q));
+                    fb[t] = *reinterpret_cast<const f32x4*>(sb + swz(wn * 64 + t * 32 + lr, 4 * lh + q));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (it + 1 < p.n_iters) store_tile(stage ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (wave-private 64x64 patch) -> 16-B stores
+    constexpr int PITCH = 64 * sizeof(T);     // f32: 4 waves x 64 rows x 256 B = exactly the 64 KiB of staging LDS
+    char* ep = smem + wid * (64 * PITCH);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + lr;
+            const int n = n0 + wn * 64 + col;
+            const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                store_from_f32(reinterpret_cast<T*>(ep + row * PITCH) + col, acc[i][j][e] + bv);
+            }
+        }
+    __syncthreads();
+    constexpr int LPR = 64 / VEC;                                  // lanes per 64-element row
+    constexpr int RPP = 64 / LPR;                                  // rows per pass
+    const int er = lane / LPR, ec = (lane % LPR) * VEC;
+#pragma unroll
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+        const int row = pass * RPP + er;
+        const int m = m0 + wm * 64 + row;
+        const int n = n0 + wn * 64 + ec;
+        if (m >= p.Mtot || n >= p.N) continue;
+        const int b = p.per_sample ? bz : m / ohw;
+        const int pix = p.per_sample ? m : m - b * ohw;
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        T* dst;
+        int nn = n;
+        if (p.pixel_shuffle) {
+            const int oc = p.N >> 2, q = n / oc;
+            nn = n - q * oc;
+            dst = y + (long long)b * p.y_bstride +
+                  ((long long)(2 * oh + (q >> 1)) * (2 * p.OW) + (2 * ow + (q & 1))) * p.ldy + nn;
+        } else {
+            dst = y + (long long)b * p.y_bstride + ((long long)oh * p.OW + ow) * p.ldy + n;
+        }
+        const T* src = reinterpret_cast<const T*>(ep + row * PITCH) + ec;
+        const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;  // valid elements left in this channel run
+        if (lim >= VEC) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+        } else {
+            for (int e = 0; e < lim; ++e) dst[e] = src[e];
+        }
+    }
+}
+
+extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, int dtype,
+                                int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                long long w_batch_stride, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!x || !w || !y || B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || N <= 0 || kh <= 0 || kw <= 0 ||
+        stride <= 0 || in_up <= 0 || Cx <= 0 || Ck <= 0 || ldy <= 0)
+        return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz, bke = 128 / esz;
+    if (Ck % bke || Cx % vec || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
+    if (pixel_shuffle && (N % 4 || (N / 4) % vec || ldy % vec)) return MSG_EUNSUPPORTED;
+    if (!pixel_shuffle && ldy % vec) return MSG_EUNSUPPORTED;
+    if (in_up > 1 && stride != 1) return MSG_EUNSUPPORTED;
+    ConvParams p{};
+    p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.in_up = in_up; p.pixel_shuffle = pixel_shuffle;
+    p.per_sample = w_batch_stride != 0;
+    p.x_bstride = (long long)IH * IW * Cx;
+    p.w_bstride = w_batch_stride;
+    p.y_bstride = pixel_shuffle ? 4ll * OH * OW * ldy : (long long)OH * OW * ldy;
+    const long long mtot = p.per_sample ? (long long)OH * OW : (long long)B * OH * OW;
+    if (mtot >= (1ll << 31)) return MSG_EUNSUPPORTED;
+    p.Mtot = (int)mtot;
+    p.n_chunks = Ck / bke;
+    p.n_iters = kh * kw * p.n_chunks;
+    p.m_tiles = (int)((mtot + BM - 1) / BM);
+    p.n_tiles = (N + BN - 1) / BN;
+    const long long blocks = (long long)p.m_tiles * p.n_tiles;
+    if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
+    dim3 grid((unsigned)blocks, 1, p.per_sample ? B : 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((conv_fprop_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w,
+                           (bf16_t*)y, bias, p);
+    else
+        hipLaunchKernelGGL((conv_fprop_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (const float*)w,
+                           (float*)y, bias, p);
+    return MSG_CHECK_LAUNCH();
+}

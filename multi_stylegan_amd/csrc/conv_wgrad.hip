@@ -1,0 +1,233 @@
+// a3/a4: weight gradient of the channels-last convolutions on the gfx950 matrix cores.
+//
+//   GW[(z)][o][tap][i] (+)= sum_{b in slice z} sum_{oh,ow} GY[b, oh, ow, o] * X[b, ih(oh,kh), iw(ow,kw), i]
+//
+// GEMM view: M = O (output channels of the forward conv), N = I (its input channels), K = pixels; both operands are
+// stored pixel-major (channels contiguous), i.e. the contraction index is the slow one -- a "TN" product.  The LDS
+// tiles therefore keep the global layout ([pixel][channel], one fully coalesced row per pixel) and the transposition
+// happens in the fragment read: bf16 uses ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group reads a
+// 4-pixel x 16-channel block and each lane receives its channel's 4 pixels), f32 needs none because an f32 MFMA
+// operand is one element per lane.  A 64-B rotation of every LDS row by (pixel & 3) keeps the transposed reads of the
+// four pixels of a block on disjoint banks.
+// Tiling: workgroup = 128 (o) x 128 (i) of ONE tap, 4 waves as 2x2 (64x64 each, 64 accumulator VGPRs); K advances
+// 64 pixels (bf16) / 32 pixels (f32) per step, double-buffered through registers like the forward kernel.  grid.y =
+// tap, grid.z = K-slice (sample, or sample x pixel-chunk).  Output is fp32; slices either own their own GW[z] (per-sample
+// gradients of the modulated conv) or accumulate into one GW with float atomics (shared weights, 128-B runs).
+// pixel_shuffle = 1 is the weight gradient of the generator's 2x2 stride-2 transposed conv: tap (dy,dx) pairs
+// X[b,h,w,:] with GY[b, 2h+dy, 2w+dx, :].
+#include "msg_common.h"
+
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+    int B, IH, IW, Cx, I, OH, OW, ldgy, O;
+    int kh, kw, stride, pad, pixel_shuffle;
+    int per_sample, chunks_per_sample, pix_per_chunk, atomic;
+    int o_tiles, i_tiles, ldgw;                       // ldgw = padded I of the gradient buffer
+    long long gw_zstride;
+};
+
+constexpr int WT = 128;                              // tile extent in both channel dimensions
+template <typename T> struct WgCfg { static constexpr int KP = 8192 / (WT * sizeof(T)) * 2; };  // 64 bf16 / 32 f32
+// byte offset of 16-B chunk `ch` of pixel row `r` inside a [KP][128] tile, rows rotated by 64 B * (r & 3)
+template <typename T> __device__ __forceinline__ int wg_off(int r, int ch) {
+    constexpr int ROW = WT * sizeof(T);
+    return r * ROW + (((ch << 4) + ((r & 3) << 6)) & (ROW - 1));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ gy, const T* __restrict__ x,
+                                                            float* __restrict__ gw, WgradParams p) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int KP = WgCfg<T>::KP;
+    constexpr int ROW = WT * sizeof(T);
+    constexpr int CPR = ROW / 16;                    // 16-B chunks per pixel row: 16 (bf16) / 32 (f32)
+    constexpr int TILE = KP * ROW;                   // 16 KiB
+    constexpr int NLD = TILE / 16 / 256;             // 16-B loads per thread per operand: 4
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int o0 = (blockIdx.x / p.i_tiles) * WT, i0 = (blockIdx.x % p.i_tiles) * WT;
+    const int tap = blockIdx.y, kh_ = tap / p.kw, kw_ = tap - kh_ * p.kw;
+    const int z = blockIdx.z;
+    const int b = z / p.chunks_per_sample, chunk = z - b * p.chunks_per_sample;
+    const int npix = p.OH * p.OW;
+    const int pix0 = chunk * p.pix_per_chunk;
+    const int pix1 = min(npix, pix0 + p.pix_per_chunk);
+    const int n_iters = (pix1 - pix0 + KP - 1) / KP;
+
+    uint4 ra[NLD], rb[NLD];
+    auto load_tile = [&](int it) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / CPR, ch = idx - r * CPR;
+            const int pix = pix0 + it * KP + r;
+            const bool pok = pix < pix1;
+            const int pp = pok ? pix : 0;
+            const int oh = pp / p.OW, ow = pp - oh * p.OW;
+            // gradient row (A): channels o0 + ch*VEC ..
+            int gh = oh, gwc = ow, xh, xw;
+            if (p.pixel_shuffle) {                      // (oh,ow) enumerates the LOW-res grid; GY is 2x larger
+                gh = 2 * oh + kh_; gwc = 2 * ow + kw_; xh = oh; xw = ow;
+            } else {
+                xh = oh * p.stride + kh_ - p.pad; xw = ow * p.stride + kw_ - p.pad;
+            }
+            const int oc = o0 + ch * VEC;
+            const int gyw = p.pixel_shuffle ? 2 * p.OW : p.OW;
+            const int gyh = p.pixel_shuffle ? 2 * p.OH : p.OH;
+            ra[j] = (pok && oc + VEC <= p.ldgy)
+                        ? *reinterpret_cast<const uint4*>(gy + (((long long)b * gyh + gh) * gyw + gwc) * p.ldgy + oc)
+                        : make_uint4(0, 0, 0, 0);
+            const int ic = i0 + ch * VEC;
+            const bool xok = pok && xh >= 0 && xw >= 0 && xh < p.IH && xw < p.IW && ic + VEC <= p.Cx;
+            rb[j] = xok ? *reinterpret_cast<const uint4*>(x + (((long long)b * p.IH + xh) * p.IW + xw) * p.Cx + ic)
+                        : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sa = smem + stage * 2 * TILE;
+        char* sb = sa + TILE;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / CPR, ch = idx - r * CPR;
+            *reinterpret_cast<uint4*>(sa + wg_off<T>(r, ch)) = ra[j];
+            *reinterpret_cast<uint4*>(sb + wg_off<T>(r, ch)) = rb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (n_iters > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < n_iters; ++it) {
+        const int stage = it & 1;
+        if (it + 1 < n_iters) load_tile(it + 1);
+        const char* sa = smem + stage * 2 * TILE;
+        const char* sb = sa + TILE;
+        if constexpr (sizeof(T) == 2) {
+            // transposed fragment: lane = 16 g + 4 q + pq supplies the address of pixel row (kb + q), channels
+            // cb + 4 pq ..+3; it receives channel (cb + lane%16) of pixel rows kb .. kb+3.
+            const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+            const int kb = 8 * (g >> 1), cb = 16 * (g & 1);
+#pragma unroll
+            for (int ks = 0; ks < KP / 16; ++ks) {                 // k-steps of 16 pixels
+                bf16v8 fa[2], fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s16x4 lo[2], hi[2];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int r = ks * 16 + kb + 4 * half + q;
+                        const int ca = wm * 64 + t * 32 + cb + 4 * pq;      // element index inside the 128-wide row
+                        const int cbn = wn * 64 + t * 32 + cb + 4 * pq;
+                        const int rot = (r & 3) << 6;
+                        const char* pa = sa + r * ROW + ((ca * 2 + rot) & (ROW - 1));
+                        const char* pb = sb + r * ROW + ((cbn * 2 + rot) & (ROW - 1));
+                        lo[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(pa));
+                        hi[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(pb));
+                    }
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    s16x8 va = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    s16x8 vb = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    fa[t] = __builtin_bit_cast(bf16v8, va);
+                    fb[t] = __builtin_bit_cast(bf16v8, vb);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll 4
+            for (int ks = 0; ks < KP / 2; ++ks) {                  // k-steps of 2 pixels
+                const int r = 2 * ks + lh;
+                const int rot = (r & 3) << 6;
+                float fa[2], fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[t] = *reinterpret_cast<const float*>(sa + r * ROW + (((wm * 64 + t * 32 + lr) * 4 + rot) & (ROW - 1)));
+                    fb[t] = *reinterpret_cast<const float*>(sb + r * ROW + (((wn * 64 + t * 32 + lr) * 4 + rot) & (ROW - 1)));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (it + 1 < n_iters) store_tile(stage ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: fp32, lanes 0..31 = 32 consecutive input channels (128-B runs)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int taps = p.kh * p.kw;
+    float* gz = gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ic = i0 + wn * 64 + j * 32 + lr;
+            if (ic >= p.ldgw) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int o = o0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (o >= p.O) continue;
+                float* dst = gz + ((long long)o * taps + tap) * p.ldgw + ic;
+                if (p.atomic) atomicAdd(dst, acc[i][j][e]);
+                else *dst = acc[i][j][e];
+            }
+        }
+}
+
+extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
+                                int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
+                                int kh, int kw, int stride, int pad, int pixel_shuffle,
+                                int per_sample, int k_chunks, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!gy || !x || !gw || B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || O <= 0 || I <= 0 || kh <= 0 ||
+        kw <= 0 || stride <= 0 || Cx <= 0 || ldgy <= 0 || ldgw < I || k_chunks <= 0)
+        return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz;
+    if (Cx % vec || ldgy % vec || (((uintptr_t)gy | (uintptr_t)x) & 15u)) return MSG_EUNSUPPORTED;
+    WgradParams p{};
+    p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.I = I; p.OH = OH; p.OW = OW; p.ldgy = ldgy; p.O = O;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.pixel_shuffle = pixel_shuffle;
+    p.per_sample = per_sample;
+    p.chunks_per_sample = k_chunks;
+    const int npix = OH * OW;
+    const int kp = dtype == MSG_BF16 ? 64 : 32;
+    p.pix_per_chunk = (((npix + k_chunks - 1) / k_chunks + kp - 1) / kp) * kp;
+    p.atomic = !(per_sample && k_chunks == 1);
+    p.o_tiles = (O + WT - 1) / WT;
+    p.i_tiles = (I + WT - 1) / WT;
+    p.ldgw = ldgw;
+    p.gw_zstride = (long long)O * kh * kw * ldgw;
+    const long long zs = (long long)B * k_chunks;
+    if (zs > 65535 || kh * kw > 65535) return MSG_EUNSUPPORTED;
+    dim3 grid(p.o_tiles * p.i_tiles, kh * kw, (unsigned)zs);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<float>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+    return MSG_CHECK_LAUNCH();
+}

@@ -91,7 +91,7 @@ def _relay_dgrad(w: torch.Tensor, dtype, flip: bool) -> Tuple[torch.Tensor, int]
 
 
 # --------------------------------------------------------------------------------------------------- raw launches
-def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample):
+def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real):
     dev = _lib.require_gpu(x, wk, bias)
     xv, cx = _nhwc_view(x)
     b, _, ih, iw = xv.shape
@@ -101,7 +101,8 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
     else:
         y, ldy = _alloc_out(b, n, oh, ow, x.dtype, dev)
     wstride = wk.stride(0) if per_sample else 0
-    flops = 2.0 * b * oh * ow * n * kh * kw * ck
+    # algorithmic FLOPs: real channels, and only the taps a transposed strided conv can reach (1/in_up^2)
+    flops = 2.0 * b * oh * ow * n * kh * kw * c_real / (in_up * in_up)
     with torch.cuda.device(dev), _lib.kernel_clock.span(f"conv_fprop/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_fprop(
             xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow,
@@ -159,19 +160,19 @@ def _f_raw(x, w, bias, g: Geometry):
     if g.kind == "up2":
         # rows n = (2dy+dx)*O + o  <-  w[o, :, dy, dx]
         wk = wk.transpose(-3, -2).reshape(*wk.shape[:-3], 4 * o, 1, ck).contiguous()
-        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample)
-    return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample)
+        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, w.shape[-3])
+    return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, w.shape[-3])
 
 
 def _d_raw(gy, w, g: Geometry):
     i = w.shape[-3]
     if g.kind == "up2":
         wk, ok = _relay_dgrad(w, gy.dtype, flip=False)
-        return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample)
+        return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample, w.shape[-4])
     wk, ok = _relay_dgrad(w, gy.dtype, flip=True)
     pad = g.kh - 1 - g.pad
     assert g.kh == g.kw
-    return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample)
+    return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample, w.shape[-4])
 
 
 def _g_raw(gy, x, o, i, g: Geometry):

@@ -20,6 +20,10 @@
 #include "msg_common.h"
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+// explicit global-address-space pointers: loads through them are global_load (never flat_load, which would force a
+// vmcnt(0) in front of every LDS access and serialise the pipeline)
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef const __attribute__((address_space(1))) u32x4* gvec_t;
 
 struct ConvParams {
     int B, IH, IW, Cx, Ck, OH, OW, N, ldy;
@@ -30,6 +34,9 @@ struct ConvParams {
 
 constexpr int BM = 128, BN = 128, ROWB = 128;                  // tile rows / cols, bytes per staged row
 constexpr int STAGE_BYTES = (BM + BN) * ROWB;                  // 32 KiB
+// Rows that must contribute zeros (halo, parity holes, tile tails) read from here: no branch, no select.
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[16384];   // 64 KiB
+
 __device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 template <typename T>
@@ -48,10 +55,13 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     const int m0 = (int)(L / p.n_tiles) * BM;
     const int bz = blockIdx.z;
 
-    // ---- staging assignment: this thread moves 16-B slot `slot` of rows rbase + 32 j (j = 0..3) of A and of B
+    // ---- staging assignment: this thread moves 16-B slot `slot` of rows rbase + 32 j (j = 0..3) of A and of B.
+    // All address arithmetic is hoisted: per TAP each row gets one pointer (or the zero page when the tap falls into
+    // the halo / a parity hole / past the image), per K-step the pointers just advance 128 B.  Rows that must read
+    // zeros point into g_zero_page, so the loads need neither a branch nor a select.
     const int slot = tid & 7, rbase = tid >> 3;
     int a_ih0[4], a_iw0[4];
-    long long a_off[4];
+    long long a_boff[4];
     bool a_ok[4];
     const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -64,46 +74,29 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
         a_ih0[j] = oh * p.stride - p.pad;
         a_iw0[j] = ow * p.stride - p.pad;
-        a_off[j] = (long long)b * p.x_bstride;
+        a_boff[j] = ((long long)b * p.x_bstride + slot * VEC) * (long long)sizeof(T);
     }
-    const T* wb = w + (p.per_sample ? (long long)bz * p.w_bstride : 0);
     const int taps = p.kh * p.kw;
-
-    uint4 ra[4], rb[4];
-    auto load_tile = [&](int it) {
-        const int tap = it / p.n_chunks, chunk = it - tap * p.n_chunks;
-        const int kh_ = tap / p.kw, kw_ = tap - kh_ * p.kw;
-        const int c = chunk * BKE + slot * VEC;
-        const bool c_ok = c + VEC <= p.Cx;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int ih = a_ih0[j] + kh_, iw = a_iw0[j] + kw_;
-            bool ok = a_ok[j] & c_ok & (ih >= 0) & (iw >= 0);
-            if (p.in_up > 1) {
-                ok = ok & (ih % p.in_up == 0) & (iw % p.in_up == 0);
-                ih /= p.in_up; iw /= p.in_up;
-            }
-            ok = ok & (ih < p.IH) & (iw < p.IW);
-            ra[j] = ok ? *reinterpret_cast<const uint4*>(x + a_off[j] + ((long long)ih * p.IW + iw) * p.Cx + c)
-                       : make_uint4(0, 0, 0, 0);
-        }
+    const gptr_t xbase = (gptr_t)x;
+    const gptr_t zbase = (gptr_t)g_zero_page;
+    const long long zoff = slot * 16;
+    gptr_t pa[4];
+    gptr_t pb[4];
+    {
+        const gptr_t wb = (gptr_t)w + (p.per_sample ? (long long)bz * p.w_bstride : 0) * (long long)sizeof(T);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + rbase + 32 * j;
-            rb[j] = (n < p.N) ? *reinterpret_cast<const uint4*>(wb + ((long long)n * taps + tap) * p.Ck + c)
-                              : make_uint4(0, 0, 0, 0);
+            const bool ok = n < p.N;
+            pb[j] = (ok ? wb : zbase) + (ok ? ((long long)n * taps * p.Ck + slot * VEC) * (long long)sizeof(T) : zoff);
+            pa[j] = zbase;
         }
-    };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-        char* sb = sa + BM * ROWB;
+    }
+    const bool ragged = (p.Cx % BKE) != 0;          // channel stride not a whole number of 128-B runs
+    int ld_tap = -1, ld_chunk = p.n_chunks - 1;     // cursor of the NEXT K-step to load (advanced before each load)
+    int st_off[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = rbase + 32 * j;
-            *reinterpret_cast<uint4*>(sa + swz(r, slot)) = ra[j];
-            *reinterpret_cast<uint4*>(sb + swz(r, slot)) = rb[j];
-        }
-    };
+    for (int j = 0; j < 4; ++j) st_off[j] = swz(rbase + 32 * j, slot);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -113,50 +106,102 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int it = 0; it < p.n_iters; ++it) {
-        const int stage = it & 1;
-        if (it + 1 < p.n_iters) load_tile(it + 1);                   // in flight under the MFMAs below
-        const char* sa = smem + stage * STAGE_BYTES;
-        const char* sb = sa + BM * ROWB;
-        if constexpr (sizeof(T) == 2) {
+    u32x4 ra[4], rb[4];
+    // Software pipeline, one barrier per K-step: iteration `it` issues the global loads of step it+1, runs the MFMAs
+    // of step it out of LDS stage it&1, then parks the loaded registers in the other stage.  it = -1 is the prologue.
+    for (int it = -1; it < p.n_iters; ++it) {
+        const bool more = it + 1 < p.n_iters;
+        if (more) {
+            if (++ld_chunk == p.n_chunks) {         // next tap: one pointer per row (or the zero page)
+                ld_chunk = 0;
+                ++ld_tap;
+                const int kh_ = ld_tap / p.kw, kw_ = ld_tap - kh_ * p.kw;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {                           // 4 k-steps of 16
-                bf16v8 fa[2], fb[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    fa[t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, 2 * kk + lh));
-                    fb[t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, 2 * kk + lh));
+                for (int j = 0; j < 4; ++j) {
+                    int ih = a_ih0[j] + kh_, iw = a_iw0[j] + kw_;
+                    bool ok = a_ok[j] & (ih >= 0) & (iw >= 0);
+                    if (p.in_up > 1) {
+                        ok = ok & (ih % p.in_up == 0) & (iw % p.in_up == 0);
+                        ih /= p.in_up; iw /= p.in_up;
+                    }
+                    ok = ok & (ih < p.IH) & (iw < p.IW);
+                    const long long off = ok ? a_boff[j] + ((long long)ih * p.IW + iw) * p.Cx * (long long)sizeof(T) : zoff;
+                    pa[j] = (ok ? xbase : zbase) + off;
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
-        } else {
-            // lane half h owns k = 16h .. 16h+15 of the 32-float run (any k order is fine as long as A and B agree)
+            const bool c_bad = ragged && (ld_chunk * BKE + slot * VEC + VEC > p.Cx);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 fa[2], fb[2];
+            for (int j = 0; j < 4; ++j) {
+                gptr_t a_addr = pa[j];
+                if (c_bad) a_addr = zbase + zoff;
+                ra[j] = *(gvec_t)a_addr;
+                rb[j] = *(gvec_t)pb[j];
+                pa[j] += ROWB;
+                pb[j] += ROWB;
+            }
+        }
+        if (it >= 0) {
+            const char* sa = smem + (it & 1) * STAGE_BYTES;
+            const char* sb = sa + BM * ROWB;
+            if constexpr (sizeof(T) == 2) {
+                // 4 k-steps of 16; the fragments of step kk+1 are requested before the MFMAs of step kk are issued,
+                // and the order is pinned (DS x8, then [MFMA x4, DS x4] ...) so LDS latency hides under the matrix pipe
+                bf16v8 fa[2][2], fb[2][2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    fa[t] = *reinterpret_cast<const f32x4*>(sa + swz(wm * 64 + t * 32 + lr, 4 * lh + q));
-                    fb[t] = *reinterpret_cast<const f32x4*>(sb + swz(wn * 64 + t * 32 + lr, 4 * lh + q));
+                    fa[0][t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, lh));
+                    fb[0][t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, lh));
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk + 1 < 4) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            fa[(kk + 1) & 1][t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, 2 * (kk + 1) + lh));
+                            fb[(kk + 1) & 1][t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, 2 * (kk + 1) + lh));
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // DS read x8 (steps 0 and 1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 0)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 2)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 1)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 3)
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // MFMA x8   (steps 2, 3)
+            } else {
+                // lane half h owns k = 16h .. 16h+15 of the 32-float run (any k order is fine as long as A and B agree)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 fa[2], fb[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        fa[t] = *reinterpret_cast<const f32x4*>(sa + swz(wm * 64 + t * 32 + lr, 4 * lh + q));
+                        fb[t] = *reinterpret_cast<const f32x4*>(sb + swz(wn * 64 + t * 32 + lr, 4 * lh + q));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                }
             }
         }
-        if (it + 1 < p.n_iters) store_tile(stage ^ 1);
+        if (more) {
+            char* sa = smem + ((it + 1) & 1) * STAGE_BYTES;
+            char* sb = sa + BM * ROWB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<u32x4*>(sa + st_off[j]) = ra[j];
+                *reinterpret_cast<u32x4*>(sb + st_off[j]) = rb[j];
+            }
+        }
         __syncthreads();
     }
 
@@ -202,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         const T* src = reinterpret_cast<const T*>(ep + row * PITCH) + ec;
         const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;  // valid elements left in this channel run
         if (lim >= VEC) {
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
         } else {
             for (int e = 0; e < lim; ++e) dst[e] = src[e];
         }
@@ -235,6 +280,7 @@ extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias,
     p.Mtot = (int)mtot;
     p.n_chunks = Ck / bke;
     p.n_iters = kh * kw * p.n_chunks;
+    if ((long long)(p.n_iters + 1) * ROWB + 128 > 65536) return MSG_EUNSUPPORTED;   // zero page covers a full K sweep
     p.m_tiles = (int)((mtot + BM - 1) / BM);
     p.n_tiles = (N + BN - 1) / BN;
     const long long blocks = (long long)p.m_tiles * p.n_tiles;

@@ -19,6 +19,9 @@
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) char* gptr_t;       // explicit global pointers: global_load, never flat
+typedef const __attribute__((address_space(1))) u32x4* gvec_t;
+__device__ __attribute__((aligned(256))) unsigned int g_wgrad_zero_page[64];   // rows that must contribute zeros read here
 
 struct WgradParams {
     int B, IH, IW, Cx, I, OH, OW, ldgy, O;
@@ -58,46 +61,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     const int pix1 = min(npix, pix0 + p.pix_per_chunk);
     const int n_iters = (pix1 - pix0 + KP - 1) / KP;
 
-    uint4 ra[NLD], rb[NLD];
-    auto load_tile = [&](int it) {
+    // ---- staging: thread moves 16-B chunk `ch` of pixel rows r0 + RSTEP*j (j = 0..NLD-1) of both operands.  Pixel
+    // coordinates advance incrementally (no division in the loop); rows that must read zeros use the zero page.
+    constexpr int RSTEP = 256 / CPR;
+    const int ch = tid % CPR, r0 = tid / CPR;
+    const gptr_t zsrc = (gptr_t)g_wgrad_zero_page + (tid & 7) * 16;
+    const int step_h = KP / p.OW, step_w = KP % p.OW;
+    const int gyw = p.pixel_shuffle ? 2 * p.OW : p.OW, gyh = p.pixel_shuffle ? 2 * p.OH : p.OH;
+    const int oc = o0 + ch * VEC, ic = i0 + ch * VEC;
+    const bool oc_ok = oc + VEC <= p.ldgy, ic_ok = ic + VEC <= p.Cx;
+    const gptr_t gyb = (gptr_t)gy + ((long long)b * gyh * gyw * p.ldgy + oc) * (long long)sizeof(T);
+    const gptr_t xb = (gptr_t)x + ((long long)b * p.IH * p.IW * p.Cx + ic) * (long long)sizeof(T);
+    int pix[NLD], oh[NLD], ow[NLD];
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int idx = tid + 256 * j;
-            const int r = idx / CPR, ch = idx - r * CPR;
-            const int pix = pix0 + it * KP + r;
-            const bool pok = pix < pix1;
-            const int pp = pok ? pix : 0;
-            const int oh = pp / p.OW, ow = pp - oh * p.OW;
-            // gradient row (A): channels o0 + ch*VEC ..
-            int gh = oh, gwc = ow, xh, xw;
-            if (p.pixel_shuffle) {                      // (oh,ow) enumerates the LOW-res grid; GY is 2x larger
-                gh = 2 * oh + kh_; gwc = 2 * ow + kw_; xh = oh; xw = ow;
-            } else {
-                xh = oh * p.stride + kh_ - p.pad; xw = ow * p.stride + kw_ - p.pad;
-            }
-            const int oc = o0 + ch * VEC;
-            const int gyw = p.pixel_shuffle ? 2 * p.OW : p.OW;
-            const int gyh = p.pixel_shuffle ? 2 * p.OH : p.OH;
-            ra[j] = (pok && oc + VEC <= p.ldgy)
-                        ? *reinterpret_cast<const uint4*>(gy + (((long long)b * gyh + gh) * gyw + gwc) * p.ldgy + oc)
-                        : make_uint4(0, 0, 0, 0);
-            const int ic = i0 + ch * VEC;
-            const bool xok = pok && xh >= 0 && xw >= 0 && xh < p.IH && xw < p.IW && ic + VEC <= p.Cx;
-            rb[j] = xok ? *reinterpret_cast<const uint4*>(x + (((long long)b * p.IH + xh) * p.IW + xw) * p.Cx + ic)
-                        : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * 2 * TILE;
-        char* sb = sa + TILE;
+    for (int j = 0; j < NLD; ++j) {
+        pix[j] = pix0 + r0 + RSTEP * j;
+        oh[j] = pix[j] / p.OW;
+        ow[j] = pix[j] - oh[j] * p.OW;
+    }
+    int st_off[NLD];
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int idx = tid + 256 * j;
-            const int r = idx / CPR, ch = idx - r * CPR;
-            *reinterpret_cast<uint4*>(sa + wg_off<T>(r, ch)) = ra[j];
-            *reinterpret_cast<uint4*>(sb + wg_off<T>(r, ch)) = rb[j];
-        }
-    };
+    for (int j = 0; j < NLD; ++j) st_off[j] = wg_off<T>(r0 + RSTEP * j, ch);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -107,72 +91,109 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (n_iters > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < n_iters; ++it) {
-        const int stage = it & 1;
-        if (it + 1 < n_iters) load_tile(it + 1);
-        const char* sa = smem + stage * 2 * TILE;
-        const char* sb = sa + TILE;
-        if constexpr (sizeof(T) == 2) {
-            // transposed fragment: lane = 16 g + 4 q + pq supplies the address of pixel row (kb + q), channels
-            // cb + 4 pq ..+3; it receives channel (cb + lane%16) of pixel rows kb .. kb+3.
-            const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
-            const int kb = 8 * (g >> 1), cb = 16 * (g & 1);
+    u32x4 ra[NLD], rb[NLD];
+    // one barrier per K-step: iteration `it` loads step it+1, computes step it, parks the registers (it = -1: prologue)
+    for (int it = -1; it < n_iters; ++it) {
+        const bool more = it + 1 < n_iters;
+        if (more) {
 #pragma unroll
-            for (int ks = 0; ks < KP / 16; ++ks) {                 // k-steps of 16 pixels
-                bf16v8 fa[2], fb[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    s16x4 lo[2], hi[2];
+            for (int j = 0; j < NLD; ++j) {
+                const bool pok = pix[j] < pix1;
+                int gh = oh[j], gwc = ow[j], xh, xw;
+                if (p.pixel_shuffle) {                  // (oh,ow) enumerates the LOW-res grid; GY is 2x larger
+                    gh = 2 * oh[j] + kh_; gwc = 2 * ow[j] + kw_; xh = oh[j]; xw = ow[j];
+                } else {
+                    xh = oh[j] * p.stride + kh_ - p.pad; xw = ow[j] * p.stride + kw_ - p.pad;
+                }
+                gptr_t ga = gyb + ((long long)gh * gyw + gwc) * p.ldgy * (long long)sizeof(T);
+                if (!(pok & oc_ok)) ga = zsrc;
+                const bool xok = pok & ic_ok & (xh >= 0) & (xw >= 0) & (xh < p.IH) & (xw < p.IW);
+                gptr_t xa = xb + ((long long)xh * p.IW + xw) * p.Cx * (long long)sizeof(T);
+                if (!xok) xa = zsrc;
+                ra[j] = *(gvec_t)ga;
+                rb[j] = *(gvec_t)xa;
+                pix[j] += KP;
+                oh[j] += step_h;
+                ow[j] += step_w;
+                if (ow[j] >= p.OW) { ow[j] -= p.OW; ++oh[j]; }
+            }
+        }
+        if (it >= 0) {
+            const char* sa = smem + (it & 1) * 2 * TILE;
+            const char* sb = sa + TILE;
+            if constexpr (sizeof(T) == 2) {
+                // transposed fragment: lane = 16 g + 4 q + pq supplies the address of pixel row (kb + q), channels
+                // cb + 4 pq ..+3; it receives channel (cb + lane%16) of pixel rows kb .. kb+3.
+                const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+                const int kb = 8 * (g >> 1), cb = 16 * (g & 1);
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                auto frag = [&](const char* base, int ks, int col0) __attribute__((always_inline)) {
+                    s16x4 part[2];
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         const int r = ks * 16 + kb + 4 * half + q;
-                        const int ca = wm * 64 + t * 32 + cb + 4 * pq;      // element index inside the 128-wide row
-                        const int cbn = wn * 64 + t * 32 + cb + 4 * pq;
-                        const int rot = (r & 3) << 6;
-                        const char* pa = sa + r * ROW + ((ca * 2 + rot) & (ROW - 1));
-                        const char* pb = sb + r * ROW + ((cbn * 2 + rot) & (ROW - 1));
-                        lo[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)(pa));
-                        hi[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)(pb));
+                        const char* pa = base + r * ROW + (((col0 + cb + 4 * pq) * 2 + ((r & 3) << 6)) & (ROW - 1));
+                        part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
                     }
-                    typedef short s16x8 __attribute__((ext_vector_type(8)));
-                    s16x8 va = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    s16x8 vb = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    fa[t] = __builtin_bit_cast(bf16v8, va);
-                    fb[t] = __builtin_bit_cast(bf16v8, vb);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-            const int lr = lane & 31, lh = lane >> 5;
-#pragma unroll 4
-            for (int ks = 0; ks < KP / 2; ++ks) {                  // k-steps of 2 pixels
-                const int r = 2 * ks + lh;
-                const int rot = (r & 3) << 6;
-                float fa[2], fb[2];
+                    return __builtin_bit_cast(bf16v8, (s16x8)__builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                };
+                constexpr int NKS = KP / 16;
+                bf16v8 fa[2][2], fb[2][2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    fa[t] = *reinterpret_cast<const float*>(sa + r * ROW + (((wm * 64 + t * 32 + lr) * 4 + rot) & (ROW - 1)));
-                    fb[t] = *reinterpret_cast<const float*>(sb + r * ROW + (((wn * 64 + t * 32 + lr) * 4 + rot) & (ROW - 1)));
+                    fa[0][t] = frag(sa, 0, wm * 64 + t * 32);
+                    fb[0][t] = frag(sb, 0, wn * 64 + t * 32);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int ks = 0; ks < NKS; ++ks) {                  // k-steps of 16 pixels, fragments one step ahead
+                    if (ks + 1 < NKS) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) {
+                            fa[(ks + 1) & 1][t] = frag(sa, ks + 1, wm * 64 + t * 32);
+                            fb[(ks + 1) & 1][t] = frag(sb, ks + 1, wn * 64 + t * 32);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);    // DS read x16 (steps 0 and 1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // step 2
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // step 3
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else {
+                const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll 4
+                for (int ks = 0; ks < KP / 2; ++ks) {              // k-steps of 2 pixels
+                    const int r = 2 * ks + lh;
+                    const int rot = (r & 3) << 6;
+                    float fa[2], fb[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        fa[t] = *reinterpret_cast<const float*>(sa + r * ROW + (((wm * 64 + t * 32 + lr) * 4 + rot) & (ROW - 1)));
+                        fb[t] = *reinterpret_cast<const float*>(sb + r * ROW + (((wn * 64 + t * 32 + lr) * 4 + rot) & (ROW - 1)));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
-        if (it + 1 < n_iters) store_tile(stage ^ 1);
+        if (more) {
+            char* sa = smem + ((it + 1) & 1) * 2 * TILE;
+            char* sb = sa + TILE;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                *reinterpret_cast<u32x4*>(sa + st_off[j]) = ra[j];
+                *reinterpret_cast<u32x4*>(sb + st_off[j]) = rb[j];
+            }
+        }
         __syncthreads();
     }
 

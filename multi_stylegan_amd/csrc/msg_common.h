@@ -10,6 +10,7 @@ typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef short  bf16x8 __attribute__((ext_vector_type(8)));
 typedef short  bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-B staging register (plain vector: stays in VGPRs)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -6,11 +6,13 @@
 // times instead of 16, keeps the 16 FIR taps in SGPRs, and remaps blocks so that one XCD's L2 sees a
 // contiguous band of tiles.  Arithmetic is fp32 whatever the storage type.
 #include "msg_common.h"
+#include <stdlib.h>
 
 struct UpfirdnParams {
     int major, in_h, in_w, minor, out_h, out_w;
     int up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw;
     unsigned nvec, tiles_x, tiles_y, total;
+    long long bias;      // elements; makes the per-lane part of every footprint address a non-negative offset
 };
 
 // out[o] = sum_t z[o*down + t - pad0] * fir[k-1-t], z = zero-inserted input (z[i*up] = x[i]).
@@ -47,8 +49,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const T* __restr
 // Fast path: k <= 4x4, (UP,DOWN) in {(1,1),(1,2),(2,1)}, minor a multiple of the 16-byte vector.
 // One lane = one 16-byte channel vector of a TH x TW output tile.  For UP == 2 tiles start on even outputs,
 // so which taps meet which input sample depends only on the parity PY/PX of (-pad0): a template constant.
-template <typename T, int UP, int DOWN, int PY, int PX, int TH, int TW>
-__global__ __launch_bounds__(256) void upfirdn2d_vec_kernel(const T* __restrict__ x, const float* __restrict__ fir,
+template <typename T, int UP, int DOWN, int PY, int PX, int TH, int TW, bool PIPE, bool ADDR32>
+__global__ __launch_bounds__(256, (PIPE ? 3 : 2)) void upfirdn2d_vec_kernel(const T* __restrict__ x, const float* __restrict__ fir,
                                                             T* __restrict__ y, UpfirdnParams p) {
     using V = Vec16<T>;
     constexpr int VEC = V::N;
@@ -79,6 +81,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_vec_kernel(const T* __restrict_
         ix_lo = (ox0 - p.pad_x0 - PX) >> 1;
     }
     const T* xb = x + (size_t)mj * p.in_h * p.in_w * p.minor + (size_t)cv * VEC;
+    // ADDR32: address = (uniform base + uniform (row,col) offset, all SGPR) + ONE 32-bit per-lane byte offset, so the
+    // 25..36 footprint loads share a single address VGPR instead of carrying a 64-bit pointer each.
+    const long long lane_elems = (long long)mj * p.in_h * p.in_w * p.minor + ((long long)iy_lo * p.in_w + ix_lo) * p.minor +
+                                 (long long)cv * VEC + p.bias;
+    const unsigned lane_off = (unsigned)(lane_elems * (long long)sizeof(T));
+    const char* xs = reinterpret_cast<const char*>(x) - p.bias * (long long)sizeof(T);
 
     float acc[TH][TW][VEC];
 #pragma unroll
@@ -88,31 +96,56 @@ __global__ __launch_bounds__(256) void upfirdn2d_vec_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[a][b][e] = 0.f;
 
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int iy = iy_lo + r;
-        const bool row_ok = (iy >= 0) & (iy < p.in_h);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int ix = ix_lo + c;
-            V v;
-            if (row_ok & (ix >= 0) & (ix < p.in_w))
+    auto load_vec = [&](int r, int c) {
+        const int iy = iy_lo + r, ix = ix_lo + c;
+        V v;
+        if ((iy >= 0) & (iy < p.in_h) & (ix >= 0) & (ix < p.in_w)) {
+            if constexpr (ADDR32) {
+                const char* sbase = xs + (size_t)(r * p.in_w + c) * p.minor * sizeof(T);      // wave-uniform
+                v.raw = *reinterpret_cast<const uint4*>(sbase + lane_off);
+            } else {
                 v.raw = *reinterpret_cast<const uint4*>(xb + ((size_t)iy * p.in_w + ix) * p.minor);
-            else
-                v.zero();
-#pragma unroll
-            for (int a = 0; a < TH; ++a) {
-                const int tap_y = (UP == 1) ? r - a * DOWN : 2 * r - a - PY;
-                if (tap_y < 0 || tap_y > 3) continue;
-#pragma unroll
-                for (int b = 0; b < TW; ++b) {
-                    const int tap_x = (UP == 1) ? c - b * DOWN : 2 * c - b - PX;
-                    if (tap_x < 0 || tap_x > 3) continue;
-                    const float wv = w[tap_y][tap_x];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[a][b][e] = fmaf(v.get(e), wv, acc[a][b][e]);
-                }
             }
+        } else {
+            v.zero();
+        }
+        return v;
+    };
+    auto accumulate = [&](const V& v, int r, int c) {
+#pragma unroll
+        for (int a = 0; a < TH; ++a) {
+            const int tap_y = (UP == 1) ? r - a * DOWN : 2 * r - a - PY;
+            if (tap_y < 0 || tap_y > 3) continue;
+#pragma unroll
+            for (int b = 0; b < TW; ++b) {
+                const int tap_x = (UP == 1) ? c - b * DOWN : 2 * c - b - PX;
+                if (tap_x < 0 || tap_x > 3) continue;
+                const float wv = w[tap_y][tap_x];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[a][b][e] = fmaf(v.get(e), wv, acc[a][b][e]);
+            }
+        }
+    };
+    if constexpr (!PIPE) {
+        // every footprint vector in flight at once (most registers, fewest waves)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) accumulate(load_vec(r, c), r, c);
+    } else {
+        // one input row ahead: row r+1 is in flight while row r is consumed (fewer registers, more waves per SIMD)
+        V row[2][NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) row[0][c] = load_vec(0, c);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r + 1 < NR) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) row[(r + 1) & 1][c] = load_vec(r + 1, c);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) accumulate(row[r & 1][c], r, c);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -138,16 +171,43 @@ __global__ __launch_bounds__(256) void upfirdn2d_vec_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int UP, int DOWN, int PY, int PX>
-static void launch_vec(const void* x, const float* fir, void* y, UpfirdnParams& p, hipStream_t s) {
-    constexpr int TH = 2, TW = 2;
+static int fir_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MSG_FIR_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <typename T, int UP, int DOWN, int PY, int PX, int TH, int TW, bool PIPE>
+static void launch_tile(const void* x, const float* fir, void* y, UpfirdnParams& p, hipStream_t s) {
     p.nvec = p.minor / Vec16<T>::N;
     p.tiles_x = (p.out_w + TW - 1) / TW;
     p.tiles_y = (p.out_h + TH - 1) / TH;
     p.total = (unsigned)p.major * p.tiles_y * p.tiles_x * p.nvec;
     const unsigned blocks = (p.total + 255u) / 256u;
-    hipLaunchKernelGGL((upfirdn2d_vec_kernel<T, UP, DOWN, PY, PX, TH, TW>), dim3(blocks), dim3(256), 0, s,
-                       (const T*)x, fir, (T*)y, p);
+    const int ay = p.pad_y0 < 0 ? -p.pad_y0 : p.pad_y0, ax = p.pad_x0 < 0 ? -p.pad_x0 : p.pad_x0;
+    p.bias = ((long long)(ay + 2) * p.in_w + (ax + 2)) * p.minor;
+    const long long span = ((long long)p.major * p.in_h * p.in_w * p.minor + 2 * p.bias) * (long long)sizeof(T);
+    if (span < (1ll << 32) && fir_variant() != 9)
+        hipLaunchKernelGGL((upfirdn2d_vec_kernel<T, UP, DOWN, PY, PX, TH, TW, PIPE, true>), dim3(blocks), dim3(256), 0, s,
+                           (const T*)x, fir, (T*)y, p);
+    else
+        hipLaunchKernelGGL((upfirdn2d_vec_kernel<T, UP, DOWN, PY, PX, TH, TW, PIPE, false>), dim3(blocks), dim3(256), 0, s,
+                           (const T*)x, fir, (T*)y, p);
+}
+
+template <typename T, int UP, int DOWN, int PY, int PX>
+static void launch_vec(const void* x, const float* fir, void* y, UpfirdnParams& p, hipStream_t s) {
+    if constexpr (UP == 1 && DOWN == 1) {
+        switch (fir_variant()) {                       // tuning variants of the blur (the HBM-roofline kernel)
+            case 1: return launch_tile<T, UP, DOWN, PY, PX, 2, 2, true>(x, fir, y, p, s);
+            case 2: return launch_tile<T, UP, DOWN, PY, PX, 2, 4, false>(x, fir, y, p, s);
+            case 3: return launch_tile<T, UP, DOWN, PY, PX, 4, 2, true>(x, fir, y, p, s);
+            case 4: return launch_tile<T, UP, DOWN, PY, PX, 2, 4, true>(x, fir, y, p, s);
+            case 5: return launch_tile<T, UP, DOWN, PY, PX, 4, 4, true>(x, fir, y, p, s);
+            default: break;
+        }
+    }
+    launch_tile<T, UP, DOWN, PY, PX, 2, 2, false>(x, fir, y, p, s);
 }
 
 template <typename T>

@@ -116,6 +116,27 @@ int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
                      int kh, int kw, int stride, int pad, int pixel_shuffle,
                      int per_sample, int k_chunks, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * a3  weight modulation / demodulation of the dual-styled conv (multi_stylegan/multi_stylegan_generator.py:379-388).
+ * The reference does this with elementwise torch ops on a [B,O,I,kh,kw] tensor; these entries write the per-sample
+ * weights directly in the contraction kernels' layouts and turn per-sample weight gradients back into parameter and
+ * style gradients (including the derivative of the demodulation norm).
+ *   msg_demod_coeff:       d[b,o] = rsqrt(scale^2 * sum_{i,t} (W[o,i,t]*s[b,i])^2 + eps);  W [O][I][taps], s [B][I]
+ *   msg_scale_rows_cols:   out[b][r][t][c] = gain * base[r][t][c] * rowscale[b][r] * colscale[b][c], c >= C -> 0;
+ *                          base fp32 [R][T][C]; rowscale/colscale fp32 or NULL (= 1); out [B][R][T][Ck] f32/bf16
+ *   msg_modulate_backward: gwk fp32 [B][O][taps][ldg] (per-sample dL/dw, w = d*scale*W*s) ->
+ *                          gW fp32 [O][I][taps] (overwritten) and gs_part fp32 [ceil(O/o_group)][B][I] (overwritten;
+ *                          the caller sums over the first axis); d = NULL means "no demodulation".
+ *                          Limits: I <= 512, taps <= 9, B <= 16 (else MSG_EUNSUPPORTED).
+ * ------------------------------------------------------------------------- */
+int msg_demod_coeff(const float* W, const float* s, float* d, int B, int O, int I, int taps,
+                    float scale, float eps, void* stream);
+int msg_scale_rows_cols(const float* base, const float* rowscale, const float* colscale, void* out,
+                        int dtype, int B, int R, int T, int C, int Ck, float gain, void* stream);
+int msg_modulate_backward(const float* gwk, const float* W, const float* s, const float* d, float* gW,
+                          float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
+                          float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,8 @@ def _alloc_out(b: int, n: int, h: int, w: int, dtype, device) -> Tuple[torch.Ten
 
 def _relay_fwd(w: torch.Tensor, dtype) -> Tuple[torch.Tensor, int]:
     """[..., O, I, kh, kw] -> [..., O, kh*kw, Ck] (K-contiguous, input channels zero-padded to a 128-byte run)."""
+    if w.ndim == 2:
+        w = w[:, :, None, None]
     *lead, o, i, kh, kw = w.shape
     ck = _round_up(i, 128 // (2 if dtype == torch.bfloat16 else 4))
     out = torch.zeros((*lead, o, kh * kw, ck), dtype=dtype, device=w.device)
@@ -80,6 +82,8 @@ def _relay_fwd(w: torch.Tensor, dtype) -> Tuple[torch.Tensor, int]:
 
 def _relay_dgrad(w: torch.Tensor, dtype, flip: bool) -> Tuple[torch.Tensor, int]:
     """[..., O, I, kh, kw] -> [..., I, kh*kw (flipped if asked), Ok]: the weights of the data-gradient contraction."""
+    if w.ndim == 2:
+        w = w[:, :, None, None]
     *lead, o, i, kh, kw = w.shape
     ok = _round_up(o, 128 // (2 if dtype == torch.bfloat16 else 4))
     src = w.reshape(*lead, o, i, kh * kw)
@@ -88,6 +92,41 @@ def _relay_dgrad(w: torch.Tensor, dtype, flip: bool) -> Tuple[torch.Tensor, int]
     out = torch.zeros((*lead, i, kh * kw, ok), dtype=dtype, device=w.device)
     out[..., :o] = src.permute(*range(len(lead)), len(lead) + 1, len(lead) + 2, len(lead))
     return out, ok
+
+
+# Re-laid copies of PARAMETERS are cached between weight updates: D runs three times and G two to three times per
+# iteration on unchanged weights.  The cache lives ON the nn.Parameter object (it dies with it and can never alias a
+# recycled address) and is validated against (a) the tensor's in-place version counter and (b) a global weight
+# generation that every torch optimizer step bumps (fused/foreach optimizers and `.data` writes do not touch the
+# version counter).  Code that writes parameters behind both mechanisms must call invalidate_weight_cache().
+_WEIGHT_GENERATION = [0]
+
+
+def invalidate_weight_cache(*_args, **_kwargs) -> None:
+    _WEIGHT_GENERATION[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(invalidate_weight_cache)
+
+
+def _cached(w, tag, dtype, wscale, build):
+    if not isinstance(w, torch.nn.Parameter):
+        out = build()
+        return (out[0] * wscale, out[1]) if wscale != 1.0 else out
+    store = w.__dict__.setdefault("_msg_relay", {})
+    key = (tag, dtype, wscale)
+    stamp = (w._version, _WEIGHT_GENERATION[0], w.data_ptr())
+    hit = store.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    with torch.no_grad():
+        out = build()
+        if wscale != 1.0:
+            out = (out[0] * wscale, out[1])
+    store[key] = (stamp, out)
+    return out
 
 
 # --------------------------------------------------------------------------------------------------- raw launches
@@ -111,7 +150,7 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
     return y
 
 
-def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw):
+def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw, raw=False):
     dev = _lib.require_gpu(gy, x)
     gv, ldgy = _nhwc_view(gy)
     xv, cx = _nhwc_view(x)
@@ -135,6 +174,8 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
             gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw,
             kh, kw, stride, pad, int(pixel_shuffle), int(per_sample), k_chunks, _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_wgrad")
+    if raw:
+        return gw, ldgw                                   # kernel layout [(B)][O][taps][ldgw]
     gw = gw[..., :i]
     # [.., O, taps, I] -> [.., O, I, kh, kw]
     return gw.transpose(-1, -2).reshape(*gw.shape[:-2], i, kh, kw)
@@ -143,42 +184,54 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
 # ------------------------------------------------------------------------------------- the three primitives, raw
 class Geometry:
     """kind 'conv': y = conv(x, w, stride, pad);  kind 'up2': y = conv_transpose(x, w^T, kernel 2, stride 2)."""
-    __slots__ = ("kind", "kh", "kw", "stride", "pad", "x_hw", "y_hw", "per_sample")
+    __slots__ = ("kind", "kh", "kw", "stride", "pad", "x_hw", "y_hw", "per_sample", "wscale")
 
-    def __init__(self, kind, kh, kw, stride, pad, x_hw, per_sample):
+    def __init__(self, kind, kh, kw, stride, pad, x_hw, per_sample, wscale=1.0):
         self.kind, self.kh, self.kw, self.stride, self.pad = kind, kh, kw, stride, pad
-        self.x_hw, self.per_sample = tuple(x_hw), per_sample
+        self.x_hw, self.per_sample, self.wscale = tuple(x_hw), per_sample, float(wscale)
         if kind == "up2":
             self.y_hw = (2 * x_hw[0], 2 * x_hw[1])
         else:
             self.y_hw = ((x_hw[0] + 2 * pad - kh) // stride + 1, (x_hw[1] + 2 * pad - kw) // stride + 1)
 
 
-def _f_raw(x, w, bias, g: Geometry):
-    wk, ck = _relay_fwd(w, x.dtype)
-    o = w.shape[-4]
-    if g.kind == "up2":
-        # rows n = (2dy+dx)*O + o  <-  w[o, :, dy, dx]
+def _oi(w):
+    """(out channels, in channels) of a weight in [O,I], [O,I,kh,kw] or [B,O,I,kh,kw] form."""
+    return (w.shape[0], w.shape[1]) if w.ndim == 2 else (w.shape[-4], w.shape[-3])
+
+
+def _relay_fwd_kind(w, dtype, kind):
+    wk, ck = _relay_fwd(w, dtype)
+    if kind == "up2":                                      # rows n = (2dy+dx)*O + o  <-  w[o, :, dy, dx]
+        o = _oi(w)[0]
         wk = wk.transpose(-3, -2).reshape(*wk.shape[:-3], 4 * o, 1, ck).contiguous()
-        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, w.shape[-3])
-    return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, w.shape[-3])
+    return wk, ck
+
+
+def _f_raw(x, w, bias, g: Geometry):
+    wk, ck = _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
+    o, _ = _oi(w)
+    if g.kind == "up2":
+        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, _oi(w)[1])
+    return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, _oi(w)[1])
 
 
 def _d_raw(gy, w, g: Geometry):
-    i = w.shape[-3]
+    i = _oi(w)[1]
+    wk, ok = _cached(w, "d" + g.kind, gy.dtype, g.wscale, lambda: _relay_dgrad(w, gy.dtype, flip=g.kind != "up2"))
     if g.kind == "up2":
-        wk, ok = _relay_dgrad(w, gy.dtype, flip=False)
-        return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample, w.shape[-4])
-    wk, ok = _relay_dgrad(w, gy.dtype, flip=True)
+        return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample, _oi(w)[0])
     pad = g.kh - 1 - g.pad
     assert g.kh == g.kw
-    return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample, w.shape[-4])
+    return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample, _oi(w)[0])
 
 
 def _g_raw(gy, x, o, i, g: Geometry):
     if g.kind == "up2":
-        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw)
-    return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None)
+        gw = _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw)
+    else:
+        gw = _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None)
+    return gw * g.wscale if g.wscale != 1.0 else gw
 
 
 # ------------------------------------------------------------------------------------- autograd closure of F/D/G
@@ -195,7 +248,7 @@ class _ConvF(Function):
         x, w = ctx.saved_tensors
         g = ctx.g
         gx = _ConvD.apply(gy, w, g) if ctx.needs_input_grad[0] else None
-        gw = _ConvG.apply(gy, x, w.shape[-4], w.shape[-3], g) if ctx.needs_input_grad[1] else None
+        gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
         gb = gy.float().sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb, None
 
@@ -212,16 +265,17 @@ class _ConvD(Function):
         gy, w = ctx.saved_tensors
         g = ctx.g
         ggy = _ConvF.apply(v, w, None, g) if ctx.needs_input_grad[0] else None
-        gw = _ConvG.apply(gy, v, w.shape[-4], w.shape[-3], g) if ctx.needs_input_grad[1] else None
+        gw = _ConvG.apply(gy, v, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
         return ggy, gw, None
 
 
 class _ConvG(Function):
     @staticmethod
-    def forward(ctx, gy, x, o, i, g):
+    def forward(ctx, gy, x, oi, w_ndim, g):
         ctx.g = g
         ctx.save_for_backward(gy, x)
-        return _g_raw(gy, x, o, i, g)
+        gw = _g_raw(gy, x, oi[0], oi[1], g)
+        return gw.reshape(oi) if w_ndim == 2 else gw
 
     @staticmethod
     def backward(ctx, u):
@@ -233,19 +287,21 @@ class _ConvG(Function):
 
 
 # ------------------------------------------------------------------------------------------------- public entry
-def conv2d(x, weight, bias=None, stride=1, padding=0):
-    """Shared-weight conv; weight [O,I,kh,kw] fp32 (already equalized-lr scaled), x [B,I,H,W]; y in x's dtype."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):
+    """Shared-weight conv: y = conv(x, wscale * weight) + bias; weight [O,I,kh,kw] fp32, x [B,I,H,W]; y in x's dtype.
+    Passing the raw parameter plus its equalized-lr scale lets the re-laid weights be cached between optimizer steps."""
     s = stride if isinstance(stride, int) else stride[0]
     p = padding if isinstance(padding, int) else padding[0]
-    g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False)
+    g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
     return _ConvF.apply(x, weight, None if bias is None else bias.float(), g)
 
 
-def linear(x, weight, bias=None):
-    """x [B,I] @ weight[O,I]^T (+ bias): the same contraction with the batch rows as 'pixels' of one sample."""
+def linear(x, weight, bias=None, wscale=1.0):
+    """x [B,I] @ (wscale * weight[O,I])^T (+ bias): the same contraction with the batch rows as 'pixels' of one sample."""
     b, i = x.shape
     o = weight.shape[0]
-    y = conv2d(x.reshape(1, b, 1, i).permute(0, 3, 1, 2), weight.reshape(o, i, 1, 1), bias)
+    g = Geometry("conv", 1, 1, 1, 0, (b, 1), False, wscale)
+    y = _ConvF.apply(x.reshape(1, b, 1, i).permute(0, 3, 1, 2), weight, None if bias is None else bias.float(), g)
     return y.permute(0, 2, 3, 1).reshape(b, o)
 
 
@@ -255,14 +311,8 @@ def demod_coefficients(weight, style, scale):
     return torch.rsqrt((scale * scale) * (style.square() @ wsq.t()) + 1e-8)
 
 
-def modulated_conv2d(x, weight, style, demodulate, upsample):
-    """x [B,I,H,W]; weight [1,O,I,kh,kw] fp32; style [B,I] fp32 -> conv result (before any blur).
-
-    One weight set per sample, w_b = d[b,o] * scale * W[o,i,k] * s[b,i] (multi_stylegan_generator.py:384-388), and
-    one batched contraction (grid.z = sample) instead of the reference's groups=batch library conv.  The demodulation
-    norm is evaluated from sum_k W^2 (an [O,I] table) so no [B,O,I,k,k] reduction pass is needed.
-    """
-    _lib.require_gpu(x, weight, style)
+def _modulated_composite(x, weight, style, demodulate, upsample):
+    """Differentiable-to-any-order formulation: torch ops build w_b = d * scale * W * s, then one batched contraction."""
     _, out_c, in_c, kh, kw = weight.shape
     scale = math.sqrt(2.0) / math.sqrt(in_c * kh * kw)
     wmod = (weight * scale) * style[:, None, :, None, None]
@@ -270,3 +320,117 @@ def modulated_conv2d(x, weight, style, demodulate, upsample):
         wmod = wmod * demod_coefficients(weight, style, scale)[:, :, None, None, None]
     g = Geometry("up2" if upsample else "conv", kh, kw, 1, kh // 2, x.shape[2:], True)
     return _ConvF.apply(x, wmod, None, g)
+
+
+def _scale_rows_cols(base, rowscale, colscale, out, gain):
+    b, r, t, ck = out.shape
+    c = base.shape[-1]
+    dev = base.device
+    with torch.cuda.device(dev):
+        code = _lib.lib().msg_scale_rows_cols(base.data_ptr(), _lib.ptr(rowscale), _lib.ptr(colscale), out.data_ptr(),
+                                              _lib.dtype_code(out), b, r, t, c, ck, float(gain), _lib.stream_of(dev))
+    _lib.check(code, "msg_scale_rows_cols")
+    return out
+
+
+class _ModulatedConv(Function):
+    """The dual-styled modulated / demodulated convolution with fused weight handling (csrc/modulate.hip):
+    forward  = demod coefficients (wave-shuffle reduction) -> per-sample weights written straight in the kernel
+               layout -> batched MFMA contraction;
+    backward = data gradient with re-laid per-sample weights, per-sample weight gradient (TN kernel), then ONE kernel
+               that folds it into dL/dW and dL/ds including the derivative of the demodulation norm.
+    When a higher-order graph is requested (path-length regularisation) the backward re-derives itself from the
+    composite formulation, which is differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, x, weight, style, demodulate, upsample):
+        dev = _lib.require_gpu(x, weight, style)
+        _, o, i, kh, kw = weight.shape
+        b, t = x.shape[0], kh * kw
+        scale = math.sqrt(2.0) / math.sqrt(i * t)
+        w3 = weight.detach().reshape(o, i, t)
+        s = style.detach().float().contiguous()
+        d = None
+        if demodulate:
+            d = torch.empty((b, o), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                code = _lib.lib().msg_demod_coeff(w3.data_ptr(), s.data_ptr(), d.data_ptr(), b, o, i, t, scale, 1e-8,
+                                                  _lib.stream_of(dev))
+            _lib.check(code, "msg_demod_coeff")
+        esz = 2 if x.dtype == torch.bfloat16 else 4
+        ck = _round_up(i, 128 // esz)
+        kind = "up2" if upsample else "conv"
+        # base [R][T][C]: conv -> [O][taps][I];  up2 -> rows n = q*O + o, one tap
+        base, _ = _cached(weight, "mb" + kind, torch.float32, 1.0, lambda: (
+            (w3.permute(2, 0, 1).reshape(t * o, 1, i) if upsample else w3.transpose(1, 2)).contiguous(), 0))
+        rows = t * o if upsample else o
+        wk = torch.empty((b, rows, 1 if upsample else t, ck), dtype=x.dtype, device=dev)
+        rowscale = d if not (upsample and d is not None) else d.repeat(1, t)
+        _scale_rows_cols(base, rowscale, s, wk, scale)
+        g = Geometry(kind, kh, kw, 1, kh // 2, x.shape[2:], True)
+        if upsample:
+            y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
+        else:
+            y = _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i)
+        ctx.save_for_backward(x, weight, style, d if d is not None else torch.empty(0, device=dev))
+        ctx.cfg = (demodulate, upsample, g, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, style, d = ctx.saved_tensors
+        demodulate, upsample, g, scale = ctx.cfg
+        _, o, i, kh, kw = weight.shape
+        b, t = x.shape[0], kh * kw
+        need = ctx.needs_input_grad
+        fused_ok = i <= 512 and t <= 9 and b <= 16
+        if torch.is_grad_enabled() or not fused_ok:
+            # higher-order request (create_graph=True): differentiate the composite formulation instead
+            with torch.enable_grad():
+                ins = [v for v, n in zip((x, weight, style), need[:3]) if n]
+                y2 = _modulated_composite(x, weight, style, demodulate, upsample)
+                grads = list(torch.autograd.grad(y2, ins, gy, create_graph=torch.is_grad_enabled(), allow_unused=True))
+            out = [grads.pop(0) if n else None for n in need[:3]]
+            return out[0], out[1], out[2], None, None
+        dev = x.device
+        w3 = weight.detach().reshape(o, i, t)
+        s = style.detach().float().contiguous()
+        dd = d if demodulate else None
+        esz = 2 if gy.dtype == torch.bfloat16 else 4
+        gx = None
+        if need[0]:
+            okp = _round_up(o, 128 // esz)
+            base, _ = _cached(weight, "md" + g.kind, torch.float32, 1.0, lambda: (
+                (w3 if upsample else w3.flip(-1)).permute(1, 2, 0).contiguous(), 0))       # [I][taps'][O]
+            wd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
+            _scale_rows_cols(base, s, dd, wd, scale)
+            if upsample:
+                gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o)
+            else:
+                gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o)
+        gw = gs = None
+        if need[1] or need[2]:
+            if upsample:
+                gwk, ldg = _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True)
+            else:
+                gwk, ldg = _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
+            og = 8
+            groups = (o + og - 1) // og
+            gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
+            gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                code = _lib.lib().msg_modulate_backward(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
+                                                        gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t, ldg, og,
+                                                        scale, _lib.stream_of(dev))
+            _lib.check(code, "msg_modulate_backward")
+            gw = gw3.reshape(1, o, i, kh, kw)
+            gs = gs_part.sum(dim=0).to(style.dtype)
+        return gx, gw, gs, None, None
+
+
+def modulated_conv2d(x, weight, style, demodulate, upsample):
+    """x [B,I,H,W]; weight [1,O,I,kh,kw] fp32; style [B,I] fp32 -> conv result (before any blur).
+
+    One weight set per sample, w_b = d[b,o] * scale * W[o,i,k] * s[b,i] (multi_stylegan_generator.py:384-388), and
+    one batched contraction (grid.z = sample) instead of the reference's groups=batch library conv."""
+    return _ModulatedConv.apply(x, weight, style, bool(demodulate), bool(upsample))

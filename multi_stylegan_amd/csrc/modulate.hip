@@ -1,0 +1,221 @@
+// a3: weight modulation / demodulation of the dual-styled convolution (multi_stylegan_generator.py:379-388) as
+// three small gfx950 kernels, so that no [B,O,I,kh,kw] fp32 tensor is ever materialised by elementwise library ops:
+//
+//   msg_demod_coeff        d[b,o] = rsqrt(scale^2 * sum_{i,t} (W[o,i,t] * s[b,i])^2 + eps)
+//                          one workgroup per output channel, wave-shuffle + LDS reduction per sample
+//   msg_scale_rows_cols    out[b][r][t][c] = base[r][t][c] * rowscale[b][r] * colscale[b][c]   (c >= C: 0)
+//                          writes the per-sample weights straight in the contraction kernels' K-contiguous layouts
+//                          (forward: r = o, c = i;  data gradient: r = i, c = o), in bf16 or f32
+//   msg_modulate_backward  from the per-sample weight gradients GWK[b][o][t][i] (what conv_wgrad produces) to
+//                          gW[o][i][t] (summed over the batch) and the style gradient gs[b][i], including the
+//                          derivative of the demodulation norm:  with u = scale*W*s, w = d*u,
+//                          g_u = d*g_w - d^3 * u * <g_w, u>_{i,t}
+#include "msg_common.h"
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// W [O][I][T] fp32, s [B][I] fp32 -> d [B][O] fp32
+__global__ __launch_bounds__(256) void demod_coeff_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                          float* __restrict__ d, int B, int O, int I, int T,
+                                                          float scale, float eps) {
+    __shared__ float red[4];
+    const int o = blockIdx.x;
+    const float* wo = W + (size_t)o * I * T;
+    for (int b = 0; b < B; ++b) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < I; i += 256) {
+            const float sv = s[(size_t)b * I + i];
+            float w2 = 0.f;
+            for (int t = 0; t < T; ++t) { const float wv = wo[i * T + t]; w2 = fmaf(wv, wv, w2); }
+            acc = fmaf(w2, sv * sv, acc);
+        }
+        const float tot = block_sum_256(acc, red);
+        if (threadIdx.x == 0) d[(size_t)b * O + o] = rsqrtf(scale * scale * tot + eps);
+    }
+}
+
+extern "C" int msg_demod_coeff(const float* W, const float* s, float* d, int B, int O, int I, int taps,
+                               float scale, float eps, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!W || !s || !d || B < 0 || O <= 0 || I <= 0 || taps <= 0) return MSG_EINVAL;
+    hipLaunchKernelGGL(demod_coeff_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, W, s, d, B, O, I, taps, scale, eps);
+    return MSG_CHECK_LAUNCH();
+}
+
+// base [R][T][C] fp32; rowscale [B][R] (or NULL = 1); colscale [B][C] (or NULL = 1); out [B][R][T][Ck] of type TO
+template <typename TO>
+__global__ __launch_bounds__(256) void scale_rows_cols_kernel(const float* __restrict__ base,
+                                                              const float* __restrict__ rowscale,
+                                                              const float* __restrict__ colscale, TO* __restrict__ out,
+                                                              int B, int R, int T, int C, int Ck, float gain,
+                                                              long long nvec) {
+    using V = Vec16<TO>;
+    constexpr int VEC = V::N;
+    const int cvecs = Ck / VEC;
+    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * 256) {
+        const int cv = (int)(vi % cvecs);
+        long long rest = vi / cvecs;
+        const int t = (int)(rest % T); rest /= T;
+        const int r = (int)(rest % R);
+        const int b = (int)(rest / R);
+        const int c0 = cv * VEC;
+        const float rs = gain * (rowscale ? rowscale[(size_t)b * R + r] : 1.f);
+        const float* src = base + ((size_t)r * T + t) * C + c0;
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = c0 + e;
+            f[e] = (c < C) ? src[e] * rs * (colscale ? colscale[(size_t)b * C + c] : 1.f) : 0.f;
+        }
+        V o;
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)vi * VEC) = o.raw;
+    }
+}
+
+extern "C" int msg_scale_rows_cols(const float* base, const float* rowscale, const float* colscale, void* out,
+                                   int dtype, int B, int R, int T, int C, int Ck, float gain, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!base || !out || B < 0 || R <= 0 || T <= 0 || C <= 0 || Ck < C) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (Ck % vec || ((uintptr_t)out & 15u)) return MSG_EUNSUPPORTED;
+    const long long nvec = (long long)B * R * T * (Ck / vec);
+    const unsigned blocks = (unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((scale_rows_cols_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, base, rowscale, colscale,
+                           (bf16_t*)out, B, R, T, C, Ck, gain, nvec);
+    else
+        hipLaunchKernelGGL((scale_rows_cols_kernel<float>), dim3(blocks), dim3(256), 0, s, base, rowscale, colscale,
+                           (float*)out, B, R, T, C, Ck, gain, nvec);
+    return MSG_CHECK_LAUNCH();
+}
+
+// One workgroup per group of OG output channels.  Thread = input channel(s) i = tid + 256*slot (all taps of it):
+// the style gradient of its channels never leaves the thread; <g_w,u> needs one block reduction per (o, all b at once).
+constexpr int MB_SLOTS = 2;      // I <= 512
+constexpr int MB_TAPS = 9;
+constexpr int MB_BMAX = 32;
+template <bool DEMOD>
+__global__ __launch_bounds__(256) void modulate_backward_kernel(const float* __restrict__ gwk, const float* __restrict__ W,
+                                                                const float* __restrict__ s, const float* __restrict__ d,
+                                                                float* __restrict__ gW, float* __restrict__ gs_part,
+                                                                int B, int O, int I, int T, int ldg, int OG, float scale) {
+    __shared__ float red[4 * MB_BMAX];
+    __shared__ float Tsh[MB_BMAX];
+    const int og = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float gs_acc[MB_BMAX / 2][MB_SLOTS];             // filled for b < B (B <= 16 fits the unrolled part; see host check)
+#pragma unroll
+    for (int b = 0; b < MB_BMAX / 2; ++b)
+#pragma unroll
+        for (int k = 0; k < MB_SLOTS; ++k) gs_acc[b][k] = 0.f;
+
+    for (int oo = 0; oo < OG; ++oo) {
+        const int o = og * OG + oo;
+        if (o >= O) break;
+        float wv[MB_SLOTS][MB_TAPS], gacc[MB_SLOTS][MB_TAPS];
+#pragma unroll
+        for (int k = 0; k < MB_SLOTS; ++k) {
+            const int i = tid + 256 * k;
+#pragma unroll
+            for (int t = 0; t < MB_TAPS; ++t) {
+                wv[k][t] = (i < I && t < T) ? W[((size_t)o * I + i) * T + t] : 0.f;
+                gacc[k][t] = 0.f;
+            }
+        }
+        if (DEMOD) {
+            // T[b] = <g_w[b,o], u[b,o]> for every sample, one reduction round for all of them
+            for (int b = 0; b < B; ++b) {
+                float part = 0.f;
+#pragma unroll
+                for (int k = 0; k < MB_SLOTS; ++k) {
+                    const int i = tid + 256 * k;
+                    if (i >= I) continue;
+                    const float sv = s[(size_t)b * I + i];
+                    const float* g = gwk + (((size_t)b * O + o) * T) * ldg + i;
+#pragma unroll
+                    for (int t = 0; t < MB_TAPS; ++t)
+                        if (t < T) part = fmaf(g[(size_t)t * ldg], wv[k][t] * sv, part);
+                }
+                part = wave_sum(part);
+                if (lane == 0) red[wid * MB_BMAX + b] = part;
+            }
+            __syncthreads();
+            if (tid < B) Tsh[tid] = scale * (red[tid] + red[MB_BMAX + tid] + red[2 * MB_BMAX + tid] + red[3 * MB_BMAX + tid]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int b = 0; b < MB_BMAX / 2; ++b) {
+            if (b >= B) break;
+            const float dv = DEMOD ? d[(size_t)b * O + o] : 1.f;
+            const float corr = DEMOD ? dv * dv * dv * Tsh[b] : 0.f;
+#pragma unroll
+            for (int k = 0; k < MB_SLOTS; ++k) {
+                const int i = tid + 256 * k;
+                if (i >= I) continue;
+                const float sv = s[(size_t)b * I + i];
+                const float* g = gwk + (((size_t)b * O + o) * T) * ldg + i;
+                float sgrad = 0.f;
+#pragma unroll
+                for (int t = 0; t < MB_TAPS; ++t) {
+                    if (t >= T) continue;
+                    // g_u = d * g_w - d^3 * u * <g_w,u>,  u = scale * W * s
+                    const float gu = dv * g[(size_t)t * ldg] - corr * (scale * wv[k][t] * sv);
+                    gacc[k][t] = fmaf(gu, sv, gacc[k][t]);
+                    sgrad = fmaf(gu, wv[k][t], sgrad);
+                }
+                gs_acc[b][k] += sgrad;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MB_SLOTS; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= I) continue;
+#pragma unroll
+            for (int t = 0; t < MB_TAPS; ++t)
+                if (t < T) gW[((size_t)o * I + i) * T + t] = scale * gacc[k][t];
+        }
+        if (DEMOD) __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < MB_BMAX / 2; ++b) {
+        if (b >= B) break;
+#pragma unroll
+        for (int k = 0; k < MB_SLOTS; ++k) {
+            const int i = tid + 256 * k;
+            if (i < I) gs_part[((size_t)og * B + b) * I + i] = scale * gs_acc[b][k];
+        }
+    }
+}
+
+extern "C" int msg_modulate_backward(const float* gwk, const float* W, const float* s, const float* d, float* gW,
+                                     float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
+                                     float scale, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!gwk || !W || !s || !gW || !gs_part || B < 0 || O <= 0 || I <= 0 || taps <= 0 || ldg < I || o_group <= 0)
+        return MSG_EINVAL;
+    if (I > 256 * MB_SLOTS || taps > MB_TAPS || B > MB_BMAX / 2) return MSG_EUNSUPPORTED;
+    const int groups = (O + o_group - 1) / o_group;
+    hipStream_t st = (hipStream_t)stream;
+    if (d)
+        hipLaunchKernelGGL((modulate_backward_kernel<true>), dim3(groups), dim3(256), 0, st, gwk, W, s, d, gW, gs_part,
+                           B, O, I, taps, ldg, o_group, scale);
+    else
+        hipLaunchKernelGGL((modulate_backward_kernel<false>), dim3(groups), dim3(256), 0, st, gwk, W, s, d, gW, gs_part,
+                           B, O, I, taps, ldg, o_group, scale);
+    return MSG_CHECK_LAUNCH();
+}

@@ -32,7 +32,7 @@ class EqualizedConv2d(nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         b = None if self.bias is None else self.bias * self.scale_bias
-        return conv_ops.conv2d(input, self.weight * self.scale, b, stride=self.stride, padding=self.padding)
+        return conv_ops.conv2d(input, self.weight, b, stride=self.stride, padding=self.padding, wscale=self.scale)
 
 
 class EqualizedLinear(nn.Module):
@@ -48,7 +48,7 @@ class EqualizedLinear(nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         b = None if self.bias is None else self.bias * self.scale_bias
-        return conv_ops.linear(input, self.weight * self.scale, b)
+        return conv_ops.linear(input, self.weight, b, wscale=self.scale)
 
 
 class PixelwiseNormalization(nn.Module):

@@ -24,3 +24,5 @@ def exponential_moving_average(model_ema, model_train, decay: float = 0.999) -> 
         src.append(train[name].data)
     torch._foreach_mul_(ema_params, decay)
     torch._foreach_add_(ema_params, src, alpha=1 - decay)
+    from . import conv_ops
+    conv_ops.invalidate_weight_cache()          # `.data` writes do not bump the tensors' version counters

@@ -414,7 +414,7 @@ class _ModulatedConv(Function):
                 gwk, ldg = _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True)
             else:
                 gwk, ldg = _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
-            og = 8
+            og = 1 if o >= 256 else 2                      # >= 256 workgroups for the 512-channel layers
             groups = (o + og - 1) // og
             gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
             gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)

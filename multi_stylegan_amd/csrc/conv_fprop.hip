@@ -107,40 +107,55 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     u32x4 ra[4], rb[4];
-    // Software pipeline, one barrier per K-step: iteration `it` issues the global loads of step it+1, runs the MFMAs
-    // of step it out of LDS stage it&1, then parks the loaded registers in the other stage.  it = -1 is the prologue.
-    for (int it = -1; it < p.n_iters; ++it) {
-        const bool more = it + 1 < p.n_iters;
-        if (more) {
-            if (++ld_chunk == p.n_chunks) {         // next tap: one pointer per row (or the zero page)
-                ld_chunk = 0;
-                ++ld_tap;
-                const int kh_ = ld_tap / p.kw, kw_ = ld_tap - kh_ * p.kw;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int ih = a_ih0[j] + kh_, iw = a_iw0[j] + kw_;
-                    bool ok = a_ok[j] & (ih >= 0) & (iw >= 0);
-                    if (p.in_up > 1) {
-                        ok = ok & (ih % p.in_up == 0) & (iw % p.in_up == 0);
-                        ih /= p.in_up; iw /= p.in_up;
-                    }
-                    ok = ok & (ih < p.IH) & (iw < p.IW);
-                    const long long off = ok ? a_boff[j] + ((long long)ih * p.IW + iw) * p.Cx * (long long)sizeof(T) : zoff;
-                    pa[j] = (ok ? xbase : zbase) + off;
-                }
-            }
-            const bool c_bad = ragged && (ld_chunk * BKE + slot * VEC + VEC > p.Cx);
+    auto load_next = [&]() __attribute__((always_inline)) {     // global -> registers for the next K-step, cursor advances
+        if (++ld_chunk == p.n_chunks) {         // next tap: one pointer per row (or the zero page)
+            ld_chunk = 0;
+            ++ld_tap;
+            const int kh_ = ld_tap / p.kw, kw_ = ld_tap - kh_ * p.kw;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                gptr_t a_addr = pa[j];
-                if (c_bad) a_addr = zbase + zoff;
-                ra[j] = *(gvec_t)a_addr;
-                rb[j] = *(gvec_t)pb[j];
-                pa[j] += ROWB;
-                pb[j] += ROWB;
+                int ih = a_ih0[j] + kh_, iw = a_iw0[j] + kw_;
+                bool ok = a_ok[j] & (ih >= 0) & (iw >= 0);
+                if (p.in_up > 1) {
+                    ok = ok & (ih % p.in_up == 0) & (iw % p.in_up == 0);
+                    ih /= p.in_up; iw /= p.in_up;
+                }
+                ok = ok & (ih < p.IH) & (iw < p.IW);
+                const long long off = ok ? a_boff[j] + ((long long)ih * p.IW + iw) * p.Cx * (long long)sizeof(T) : zoff;
+                pa[j] = (ok ? xbase : zbase) + off;
             }
         }
-        if (it >= 0) {
+        const bool c_bad = ragged && (ld_chunk * BKE + slot * VEC + VEC > p.Cx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gptr_t a_addr = pa[j];
+            if (c_bad) a_addr = zbase + zoff;
+            ra[j] = *(gvec_t)a_addr;
+            rb[j] = *(gvec_t)pb[j];
+            pa[j] += ROWB;
+            pb[j] += ROWB;
+        }
+    };
+    auto park = [&](int stage) __attribute__((always_inline)) {  // registers -> LDS stage
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<u32x4*>(sa + st_off[j]) = ra[j];
+            *reinterpret_cast<u32x4*>(sb + st_off[j]) = rb[j];
+        }
+    };
+    // Software pipeline, ONE barrier per K-step, writes placed AFTER it: at step `it` the registers hold step it+1
+    // (loaded during step it-1); they are parked in the other LDS stage right after the barrier, the loads of step
+    // it+2 are issued, and only then the MFMAs of step `it` run -- LDS writes and global loads both fly under them.
+    load_next();
+    park(0);
+    if (p.n_iters > 1) load_next();
+    for (int it = 0; it < p.n_iters; ++it) {
+        __syncthreads();
+        if (it + 1 < p.n_iters) park((it + 1) & 1);
+        if (it + 2 < p.n_iters) load_next();
+        {
             const char* sa = smem + (it & 1) * STAGE_BYTES;
             const char* sb = sa + BM * ROWB;
             if constexpr (sizeof(T) == 2) {
@@ -193,17 +208,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 }
             }
         }
-        if (more) {
-            char* sa = smem + ((it + 1) & 1) * STAGE_BYTES;
-            char* sb = sa + BM * ROWB;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<u32x4*>(sa + st_off[j]) = ra[j];
-                *reinterpret_cast<u32x4*>(sb + st_off[j]) = rb[j];
-            }
-        }
-        __syncthreads();
     }
+    __syncthreads();                                 // everyone done with the staging buffers: the epilogue reuses them
 
     // ---- epilogue: accumulators -> LDS (wave-private 64x64 patch) -> 16-B stores
     constexpr int PITCH = 64 * sizeof(T);     // f32: 4 waves x 64 rows x 256 B = exactly the 64 KiB of staging LDS

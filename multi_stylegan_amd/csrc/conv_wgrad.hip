@@ -92,33 +92,49 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     u32x4 ra[NLD], rb[NLD];
-    // one barrier per K-step: iteration `it` loads step it+1, computes step it, parks the registers (it = -1: prologue)
-    for (int it = -1; it < n_iters; ++it) {
-        const bool more = it + 1 < n_iters;
-        if (more) {
+    auto load_next = [&]() __attribute__((always_inline)) {     // global -> registers for the next K-step
 #pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                const bool pok = pix[j] < pix1;
-                int gh = oh[j], gwc = ow[j], xh, xw;
-                if (p.pixel_shuffle) {                  // (oh,ow) enumerates the LOW-res grid; GY is 2x larger
-                    gh = 2 * oh[j] + kh_; gwc = 2 * ow[j] + kw_; xh = oh[j]; xw = ow[j];
-                } else {
-                    xh = oh[j] * p.stride + kh_ - p.pad; xw = ow[j] * p.stride + kw_ - p.pad;
-                }
-                gptr_t ga = gyb + ((long long)gh * gyw + gwc) * p.ldgy * (long long)sizeof(T);
-                if (!(pok & oc_ok)) ga = zsrc;
-                const bool xok = pok & ic_ok & (xh >= 0) & (xw >= 0) & (xh < p.IH) & (xw < p.IW);
-                gptr_t xa = xb + ((long long)xh * p.IW + xw) * p.Cx * (long long)sizeof(T);
-                if (!xok) xa = zsrc;
-                ra[j] = *(gvec_t)ga;
-                rb[j] = *(gvec_t)xa;
-                pix[j] += KP;
-                oh[j] += step_h;
-                ow[j] += step_w;
-                if (ow[j] >= p.OW) { ow[j] -= p.OW; ++oh[j]; }
+        for (int j = 0; j < NLD; ++j) {
+            const bool pok = pix[j] < pix1;
+            int gh = oh[j], gwc = ow[j], xh, xw;
+            if (p.pixel_shuffle) {                  // (oh,ow) enumerates the LOW-res grid; GY is 2x larger
+                gh = 2 * oh[j] + kh_; gwc = 2 * ow[j] + kw_; xh = oh[j]; xw = ow[j];
+            } else {
+                xh = oh[j] * p.stride + kh_ - p.pad; xw = ow[j] * p.stride + kw_ - p.pad;
             }
+            gptr_t ga = gyb + ((long long)gh * gyw + gwc) * p.ldgy * (long long)sizeof(T);
+            if (!(pok & oc_ok)) ga = zsrc;
+            const bool xok = pok & ic_ok & (xh >= 0) & (xw >= 0) & (xh < p.IH) & (xw < p.IW);
+            gptr_t xa = xb + ((long long)xh * p.IW + xw) * p.Cx * (long long)sizeof(T);
+            if (!xok) xa = zsrc;
+            ra[j] = *(gvec_t)ga;
+            rb[j] = *(gvec_t)xa;
+            pix[j] += KP;
+            oh[j] += step_h;
+            ow[j] += step_w;
+            if (ow[j] >= p.OW) { ow[j] -= p.OW; ++oh[j]; }
         }
-        if (it >= 0) {
+    };
+    auto park = [&](int stage) __attribute__((always_inline)) {
+        char* sa = smem + stage * 2 * TILE;
+        char* sb = sa + TILE;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            *reinterpret_cast<u32x4*>(sa + st_off[j]) = ra[j];
+            *reinterpret_cast<u32x4*>(sb + st_off[j]) = rb[j];
+        }
+    };
+    // one barrier per K-step with the LDS writes placed after it (same pipeline as conv_fprop)
+    if (n_iters > 0) {
+        load_next();
+        park(0);
+        if (n_iters > 1) load_next();
+    }
+    for (int it = 0; it < n_iters; ++it) {
+        __syncthreads();
+        if (it + 1 < n_iters) park((it + 1) & 1);
+        if (it + 2 < n_iters) load_next();
+        {
             const char* sa = smem + (it & 1) * 2 * TILE;
             const char* sb = sa + TILE;
             if constexpr (sizeof(T) == 2) {
@@ -185,16 +201,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
                 }
             }
         }
-        if (more) {
-            char* sa = smem + ((it + 1) & 1) * 2 * TILE;
-            char* sb = sa + TILE;
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                *reinterpret_cast<u32x4*>(sa + st_off[j]) = ra[j];
-                *reinterpret_cast<u32x4*>(sb + st_off[j]) = rb[j];
-            }
-        }
-        __syncthreads();
     }
 
     // ---- epilogue: fp32, lanes 0..31 = 32 consecutive input channels (128-B runs)

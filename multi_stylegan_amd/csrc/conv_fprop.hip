@@ -18,12 +18,14 @@
 // the staging pass and the ds_read_b128 fragment reads conflict-free.  The epilogue goes through LDS so that each
 // lane stores 16 contiguous bytes.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact fp32).
 #include "msg_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 // explicit global-address-space pointers: loads through them are global_load (never flat_load, which would force a
 // vmcnt(0) in front of every LDS access and serialise the pipeline)
 typedef const __attribute__((address_space(1))) char* gptr_t;
 typedef const __attribute__((address_space(1))) u32x4* gvec_t;
+typedef __attribute__((address_space(3))) char* lds_t;
 
 struct ConvParams {
     int B, IH, IW, Cx, Ck, OH, OW, N, ldy;
@@ -39,7 +41,7 @@ __device__ __attribute__((aligned(256))) unsigned int g_zero_page[16384];   // 6
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T>
+template <typename T, bool DMA>
 __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                             T* __restrict__ y, const float* __restrict__ bias,
                                                             ConvParams p) {
@@ -59,14 +61,25 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     // All address arithmetic is hoisted: per TAP each row gets one pointer (or the zero page when the tap falls into
     // the halo / a parity hole / past the image), per K-step the pointers just advance 128 B.  Rows that must read
     // zeros point into g_zero_page, so the loads need neither a branch nor a select.
-    const int slot = tid & 7, rbase = tid >> 3;
+    // register staging: thread moves slot (tid&7) of rows (tid>>3) + 32 j.
+    // LDS-DMA staging (DMA): one wave-instruction writes 1 KiB = 8 consecutive rows in lane order, so wave w moves rows
+    // 32 w + 8 j + (lane>>3), lane&7 is the PHYSICAL slot and the lane fetches the logical slot that belongs there
+    // (swizzle applied on the source address; the LDS image is the same as with register staging).
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    const int slot_phys = tid & 7;
+    int row_of[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row_of[j] = DMA ? (wid * 32 + 8 * j + (lane >> 3)) : ((tid >> 3) + 32 * j);
+    const int slot = DMA ? 0 : slot_phys;          // (DMA: per-row logical slot, see slot_j below)
     int a_ih0[4], a_iw0[4];
     long long a_boff[4];
+    int a_slot[4];
     bool a_ok[4];
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = m0 + rbase + 32 * j;
+        const int m = m0 + row_of[j];
+        const int slot_j = DMA ? (slot_phys ^ ((row_of[j] >> 1) & 7)) : slot_phys;
         a_ok[j] = m < p.Mtot;
         const int mm = a_ok[j] ? m : 0;
         const int b = p.per_sample ? bz : mm / ohw;
@@ -74,21 +87,22 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
         a_ih0[j] = oh * p.stride - p.pad;
         a_iw0[j] = ow * p.stride - p.pad;
-        a_boff[j] = ((long long)b * p.x_bstride + slot * VEC) * (long long)sizeof(T);
+        a_boff[j] = ((long long)b * p.x_bstride + slot_j * VEC) * (long long)sizeof(T);
+        a_slot[j] = slot_j;
     }
     const int taps = p.kh * p.kw;
     const gptr_t xbase = (gptr_t)x;
     const gptr_t zbase = (gptr_t)g_zero_page;
-    const long long zoff = slot * 16;
+    const long long zoff = slot_phys * 16;
     gptr_t pa[4];
     gptr_t pb[4];
     {
         const gptr_t wb = (gptr_t)w + (p.per_sample ? (long long)bz * p.w_bstride : 0) * (long long)sizeof(T);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + rbase + 32 * j;
+            const int n = n0 + row_of[j];
             const bool ok = n < p.N;
-            pb[j] = (ok ? wb : zbase) + (ok ? ((long long)n * taps * p.Ck + slot * VEC) * (long long)sizeof(T) : zoff);
+            pb[j] = (ok ? wb : zbase) + (ok ? ((long long)n * taps * p.Ck + a_slot[j] * VEC) * (long long)sizeof(T) : zoff);
             pa[j] = zbase;
         }
     }
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     int ld_tap = -1, ld_chunk = p.n_chunks - 1;     // cursor of the NEXT K-step to load (advanced before each load)
     int st_off[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st_off[j] = swz(rbase + 32 * j, slot);
+    for (int j = 0; j < 4; ++j) st_off[j] = swz(row_of[j], a_slot[j]);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -107,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     u32x4 ra[4], rb[4];
+    int dma_stage = 0;                              // LDS stage the next load_next() fills (DMA path)
     auto load_next = [&]() __attribute__((always_inline)) {     // global -> registers for the next K-step, cursor advances
         if (++ld_chunk == p.n_chunks) {         // next tap: one pointer per row (or the zero page)
             ld_chunk = 0;
@@ -125,13 +140,20 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 pa[j] = (ok ? xbase : zbase) + off;
             }
         }
-        const bool c_bad = ragged && (ld_chunk * BKE + slot * VEC + VEC > p.Cx);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const bool c_bad = ragged && (ld_chunk * BKE + a_slot[j] * VEC + VEC > p.Cx);
             gptr_t a_addr = pa[j];
             if (c_bad) a_addr = zbase + zoff;
-            ra[j] = *(gvec_t)a_addr;
-            rb[j] = *(gvec_t)pb[j];
+            if constexpr (DMA) {
+                // wave-uniform LDS destination: rows 32 w + 8 j .. +7 of the stage being filled, lanes in order
+                lds_t la = (lds_t)(smem + dma_stage * STAGE_BYTES + (wid_u * 32 + 8 * j) * ROWB);
+                __builtin_amdgcn_global_load_lds(a_addr, la, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pb[j], la + BM * ROWB, 16, 0, 0);
+            } else {
+                ra[j] = *(gvec_t)a_addr;
+                rb[j] = *(gvec_t)pb[j];
+            }
             pa[j] += ROWB;
             pb[j] += ROWB;
         }
@@ -148,13 +170,22 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     // Software pipeline, ONE barrier per K-step, writes placed AFTER it: at step `it` the registers hold step it+1
     // (loaded during step it-1); they are parked in the other LDS stage right after the barrier, the loads of step
     // it+2 are issued, and only then the MFMAs of step `it` run -- LDS writes and global loads both fly under them.
-    load_next();
-    park(0);
-    if (p.n_iters > 1) load_next();
+    if constexpr (DMA) {
+        dma_stage = 0;
+        load_next();                                // step 0 -> stage 0, asynchronously
+    } else {
+        load_next();
+        park(0);
+        if (p.n_iters > 1) load_next();
+    }
     for (int it = 0; it < p.n_iters; ++it) {
-        __syncthreads();
-        if (it + 1 < p.n_iters) park((it + 1) & 1);
-        if (it + 2 < p.n_iters) load_next();
+        __syncthreads();                            // (DMA: the barrier's vmcnt(0) is what retires step `it`'s DMA)
+        if constexpr (DMA) {
+            if (it + 1 < p.n_iters) { dma_stage = (it + 1) & 1; load_next(); }   // lands while the MFMAs below run
+        } else {
+            if (it + 1 < p.n_iters) park((it + 1) & 1);
+            if (it + 2 < p.n_iters) load_next();
+        }
         {
             const char* sa = smem + (it & 1) * STAGE_BYTES;
             const char* sb = sa + BM * ROWB;
@@ -293,11 +324,17 @@ extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias,
     if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
     dim3 grid((unsigned)blocks, 1, p.per_sample ? B : 1);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MSG_BF16)
-        hipLaunchKernelGGL((conv_fprop_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w,
-                           (bf16_t*)y, bias, p);
-    else
-        hipLaunchKernelGGL((conv_fprop_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (const float*)w,
-                           (float*)y, bias, p);
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("MSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+    // staging: LDS-DMA (global_load_lds) for long K sweeps, register staging (two steps in flight) for short ones;
+    // MSG_CONV_VARIANT=1 / 2 forces DMA / registers (A/B measurements)
+    const bool dma = variant == 1 || (variant == 0 && p.n_iters >= 12);
+    if (dtype == MSG_BF16) {
+        if (dma) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
+        else hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
+    } else {
+        if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
+        else hipLaunchKernelGGL((conv_fprop_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
+    }
     return MSG_CHECK_LAUNCH();
 }

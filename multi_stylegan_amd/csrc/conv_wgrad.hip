@@ -16,11 +16,13 @@
 // pixel_shuffle = 1 is the weight gradient of the generator's 2x2 stride-2 transposed conv: tap (dy,dx) pairs
 // X[b,h,w,:] with GY[b, 2h+dy, 2w+dx, :].
 #include "msg_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) char* gptr_t;       // explicit global pointers: global_load, never flat
 typedef const __attribute__((address_space(1))) u32x4* gvec_t;
+typedef __attribute__((address_space(3))) char* lds_t;
 __device__ __attribute__((aligned(256))) unsigned int g_wgrad_zero_page[64];   // rows that must contribute zeros read here
 
 struct WgradParams {
@@ -39,7 +41,7 @@ template <typename T> __device__ __forceinline__ int wg_off(int r, int ch) {
     return r * ROW + (((ch << 4) + ((r & 3) << 6)) & (ROW - 1));
 }
 
-template <typename T>
+template <typename T, bool DMA>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                             float* __restrict__ gw, WgradParams p) {
     constexpr int VEC = 16 / sizeof(T);
@@ -64,7 +66,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     // ---- staging: thread moves 16-B chunk `ch` of pixel rows r0 + RSTEP*j (j = 0..NLD-1) of both operands.  Pixel
     // coordinates advance incrementally (no division in the loop); rows that must read zeros use the zero page.
     constexpr int RSTEP = 256 / CPR;
-    const int ch = tid % CPR, r0 = tid / CPR;
+    // LDS-DMA (DMA): a wave-instruction fills 1 KiB = RPW whole pixel rows in lane order; wave w takes rows
+    // w*RPW + 4*RPW*j + lane/CPR, (lane % CPR) is the PHYSICAL 16-B chunk and the lane fetches the logical chunk that the
+    // 64-B row rotation puts there.  Register staging keeps the original assignment.
+    constexpr int RPW = 1024 / ROW;                   // rows per wave-instruction: 4 (bf16) / 2 (f32)
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    const int r0 = DMA ? (wid * RPW + lane / CPR) : tid / CPR;
+    const int ch_phys = DMA ? (lane % CPR) : (tid % CPR);
+    const int ch = DMA ? ((ch_phys - 4 * (r0 & 3)) & (CPR - 1)) : ch_phys;   // (row & 3) is the same for all j: steps of 4*RPW rows
     const gptr_t zsrc = (gptr_t)g_wgrad_zero_page + (tid & 7) * 16;
     const int step_h = KP / p.OW, step_w = KP % p.OW;
     const int gyw = p.pixel_shuffle ? 2 * p.OW : p.OW, gyh = p.pixel_shuffle ? 2 * p.OH : p.OH;
@@ -75,13 +84,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     int pix[NLD], oh[NLD], ow[NLD];
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-        pix[j] = pix0 + r0 + RSTEP * j;
+        pix[j] = pix0 + r0 + (DMA ? 4 * RPW : RSTEP) * j;
         oh[j] = pix[j] / p.OW;
         ow[j] = pix[j] - oh[j] * p.OW;
     }
     int st_off[NLD];
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) st_off[j] = wg_off<T>(r0 + RSTEP * j, ch);
+    for (int j = 0; j < NLD; ++j) st_off[j] = wg_off<T>(r0 + (DMA ? 4 * RPW : RSTEP) * j, ch);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     u32x4 ra[NLD], rb[NLD];
+    int dma_stage = 0;
     auto load_next = [&]() __attribute__((always_inline)) {     // global -> registers for the next K-step
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -107,8 +117,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             const bool xok = pok & ic_ok & (xh >= 0) & (xw >= 0) & (xh < p.IH) & (xw < p.IW);
             gptr_t xa = xb + ((long long)xh * p.IW + xw) * p.Cx * (long long)sizeof(T);
             if (!xok) xa = zsrc;
-            ra[j] = *(gvec_t)ga;
-            rb[j] = *(gvec_t)xa;
+            if constexpr (DMA) {
+                lds_t la = (lds_t)(smem + dma_stage * 2 * TILE + (wid_u * RPW + 4 * RPW * j) * ROW);
+                __builtin_amdgcn_global_load_lds(ga, la, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(xa, la + TILE, 16, 0, 0);
+            } else {
+                ra[j] = *(gvec_t)ga;
+                rb[j] = *(gvec_t)xa;
+            }
             pix[j] += KP;
             oh[j] += step_h;
             ow[j] += step_w;
@@ -126,14 +142,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     };
     // one barrier per K-step with the LDS writes placed after it (same pipeline as conv_fprop)
     if (n_iters > 0) {
-        load_next();
-        park(0);
-        if (n_iters > 1) load_next();
+        if constexpr (DMA) {
+            dma_stage = 0;
+            load_next();
+        } else {
+            load_next();
+            park(0);
+            if (n_iters > 1) load_next();
+        }
     }
     for (int it = 0; it < n_iters; ++it) {
-        __syncthreads();
-        if (it + 1 < n_iters) park((it + 1) & 1);
-        if (it + 2 < n_iters) load_next();
+        __syncthreads();                            // (DMA: its vmcnt(0) retires the DMA of step `it`)
+        if constexpr (DMA) {
+            if (it + 1 < n_iters) { dma_stage = (it + 1) & 1; load_next(); }
+        } else {
+            if (it + 1 < n_iters) park((it + 1) & 1);
+            if (it + 2 < n_iters) load_next();
+        }
         {
             const char* sa = smem + (it & 1) * 2 * TILE;
             const char* sb = sa + TILE;
@@ -252,9 +277,17 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     if (zs > 65535 || kh * kw > 65535) return MSG_EUNSUPPORTED;
     dim3 grid(p.o_tiles * p.i_tiles, kh * kw, (unsigned)zs);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MSG_BF16)
-        hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
-    else
-        hipLaunchKernelGGL((conv_wgrad_kernel<float>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("MSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+    // Register staging keeps two K-steps of loads in flight; measured faster here than LDS-DMA with one step in
+    // flight (685 vs 608 TFLOP/s at 3x3 512->512 @256^2): both operands of this kernel stream from beyond L2.
+    const bool dma = variant == 1;                   // MSG_CONV_VARIANT=1 forces LDS-DMA staging (A/B measurements)
+    if (dtype == MSG_BF16) {
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+    } else {
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+    }
     return MSG_CHECK_LAUNCH();
 }

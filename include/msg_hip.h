@@ -137,6 +137,10 @@ int msg_modulate_backward(const float* gwk, const float* W, const float* s, cons
                           float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
                           float scale, void* stream);
 
+/* y = (a + beta*b) * gain over n elements (n multiple of the 16-byte vector, all pointers 16-B aligned): the
+ * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
+int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

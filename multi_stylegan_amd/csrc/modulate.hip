@@ -48,40 +48,42 @@ extern "C" int msg_demod_coeff(const float* W, const float* s, float* d, int B, 
     return MSG_CHECK_LAUNCH();
 }
 
-// base [R][T][C] fp32; rowscale [B][R] (or NULL = 1); colscale [B][C] (or NULL = 1); out [B][R][T][Ck] of type TO
+// base [R][T][C] fp32; rowscale [B][R] (or NULL = 1); colscale [B][C] (or NULL = 1); out [B][R][T][Ck] of type TO.
+// grid = (row r, sample b): the row scale is one scalar per workgroup, the column scales one vector per lane, and
+// no index is ever divided.
 template <typename TO>
 __global__ __launch_bounds__(256) void scale_rows_cols_kernel(const float* __restrict__ base,
                                                               const float* __restrict__ rowscale,
                                                               const float* __restrict__ colscale, TO* __restrict__ out,
-                                                              int B, int R, int T, int C, int Ck, float gain,
-                                                              long long nvec) {
+                                                              int R, int T, int C, int Ck, float gain) {
     using V = Vec16<TO>;
     constexpr int VEC = V::N;
+    const int r = blockIdx.x, b = blockIdx.y;
     const int cvecs = Ck / VEC;
-    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * 256) {
-        const int cv = (int)(vi % cvecs);
-        long long rest = vi / cvecs;
-        const int t = (int)(rest % T); rest /= T;
-        const int r = (int)(rest % R);
-        const int b = (int)(rest / R);
+    const float rs = gain * (rowscale ? rowscale[(size_t)b * R + r] : 1.f);
+    const float* src_row = base + (size_t)r * T * C;
+    TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
+    const float* cs = colscale ? colscale + (size_t)b * C : nullptr;
+    for (int cv = threadIdx.x % cvecs; cv < cvecs; cv += 256) {       // (cvecs <= 256 in practice: one pass)
         const int c0 = cv * VEC;
-        const float rs = gain * (rowscale ? rowscale[(size_t)b * R + r] : 1.f);
-        const float* src = base + ((size_t)r * T + t) * C + c0;
-        float f[VEC];
+        float sc[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const int c = c0 + e;
-            f[e] = (c < C) ? src[e] * rs * (colscale ? colscale[(size_t)b * C + c] : 1.f) : 0.f;
+        for (int e = 0; e < VEC; ++e) sc[e] = (c0 + e < C) ? rs * (cs ? cs[c0 + e] : 1.f) : 0.f;
+        for (int t = threadIdx.x / cvecs; t < T; t += (256 / cvecs > 0 ? 256 / cvecs : 1)) {
+            const float* src = src_row + (size_t)t * C + c0;
+            float f[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = (c0 + e < C) ? src[e] * sc[e] : 0.f;
+            V o;
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+            }
+            *reinterpret_cast<uint4*>(dst_row + (size_t)t * Ck + c0) = o.raw;
         }
-        V o;
-        if constexpr (VEC == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o.set(e, f[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
-        }
-        *reinterpret_cast<uint4*>(out + (size_t)vi * VEC) = o.raw;
     }
 }
 
@@ -91,16 +93,15 @@ extern "C" int msg_scale_rows_cols(const float* base, const float* rowscale, con
     if (!base || !out || B < 0 || R <= 0 || T <= 0 || C <= 0 || Ck < C) return MSG_EINVAL;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int vec = dtype == MSG_BF16 ? 8 : 4;
-    if (Ck % vec || ((uintptr_t)out & 15u)) return MSG_EUNSUPPORTED;
-    const long long nvec = (long long)B * R * T * (Ck / vec);
-    const unsigned blocks = (unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    if (Ck % vec || ((uintptr_t)out & 15u) || B > 65535) return MSG_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    dim3 grid(R, B);
     if (dtype == MSG_BF16)
-        hipLaunchKernelGGL((scale_rows_cols_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, base, rowscale, colscale,
-                           (bf16_t*)out, B, R, T, C, Ck, gain, nvec);
+        hipLaunchKernelGGL((scale_rows_cols_kernel<bf16_t>), grid, dim3(256), 0, s, base, rowscale, colscale,
+                           (bf16_t*)out, R, T, C, Ck, gain);
     else
-        hipLaunchKernelGGL((scale_rows_cols_kernel<float>), dim3(blocks), dim3(256), 0, s, base, rowscale, colscale,
-                           (float*)out, B, R, T, C, Ck, gain, nvec);
+        hipLaunchKernelGGL((scale_rows_cols_kernel<float>), grid, dim3(256), 0, s, base, rowscale, colscale,
+                           (float*)out, R, T, C, Ck, gain);
     return MSG_CHECK_LAUNCH();
 }
 

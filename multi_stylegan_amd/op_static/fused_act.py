@@ -131,3 +131,32 @@ class FusedLeakyReLU(nn.Module):
 
     def forward(self, input):
         return fused_leaky_relu(input, self.bias, self.negative_slope, self.scale)
+
+
+class _ScaledAdd(Function):
+    """y = (a + b) * gain in one pass (csrc/bias_act.hip: msg_scaled_add); the backward is plain torch (gy * gain for
+    both inputs) so that it stays differentiable for R1."""
+
+    @staticmethod
+    def forward(ctx, a, b, gain):
+        ctx.gain = gain
+        dev = _lib.require_gpu(a, b)
+        y = torch.empty_like(a)
+        with torch.cuda.device(dev):
+            code = _lib.lib().msg_scaled_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), _lib.dtype_code(a), a.numel(), 1.0,
+                                             float(gain), _lib.stream_of(dev))
+        _lib.check(code, "msg_scaled_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = gy * ctx.gain
+        return g, g, None
+
+
+def scaled_add(a, b, gain):
+    """(a + b) * gain for two tensors of identical shape, dtype and memory layout (falls back to torch otherwise)."""
+    same = a.shape == b.shape and a.dtype == b.dtype and a.stride() == b.stride() and a.is_cuda and \
+        a.numel() % 8 == 0 and a.dtype in (torch.float32, torch.bfloat16) and \
+        (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last))
+    return _ScaledAdd.apply(a, b, gain) if same else (a + b) * gain

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv_ops, equalized_layer
-from .op_static import FusedLeakyReLU, upfirdn2d
+from .op_static import FusedLeakyReLU, scaled_add, upfirdn2d
 
 
 def _fir2d(taps, gain=1.0):
@@ -76,7 +76,7 @@ class ResNetBlock(nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         output = self.main_mapping(self.mini_batch_std_dev(input))
-        return (output + self.residual_mapping(input)) * (1.0 / math.sqrt(2))
+        return scaled_add(output, self.residual_mapping(input), 1.0 / math.sqrt(2))
 
 
 class NonLocalBlock(nn.Module):
@@ -98,7 +98,7 @@ class NonLocalBlock(nn.Module):
         beta = torch.softmax(torch.bmm(theta.transpose(1, 2), phi).float(), dim=-1).to(input.dtype)
         attended = torch.bmm(g, beta.transpose(1, 2)).view(bsz, -1, height, width)
         output = self.o(conv_ops.to_compute_layout(attended))
-        return (self.gamma.to(input.dtype) * output + self.residual_mapping(input)) * (1.0 / math.sqrt(2))
+        return scaled_add(self.gamma.to(input.dtype) * output, self.residual_mapping(input), 1.0 / math.sqrt(2))
 
 
 class Discriminator(nn.Module):

@@ -43,7 +43,7 @@ def parse_args():
                          "the G step); identical training trajectory, not used for the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-clock", action="store_true")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=2)
+    ap.add_argument("--cpu-baseline-iters", type=int, default=4)
     return ap.parse_args()
 
 
@@ -144,13 +144,22 @@ def main():
         value = world * args.batch * args.steps / elapsed
         # dominant kernel (rocprofv3: ~44 % of GPU time): the bf16 implicit-GEMM conv on the matrix cores.
         # achieved = algorithmic FLOPs of its launches inside the timed region / their HIP-event durations.
+        try:        # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this workload (profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        except (OSError, KeyError, ValueError):
+            pmc = {}
+
         def leg(key, bound, peak, unit, name):
             if key not in clock:
                 return None
             c = clock[key]
             rate = c["work"] / (c["total_ms"] * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
             return {"kernel": name, "bound": bound, "achieved": round(rate, 1), "peak": peak, "unit": unit,
-                    "frac": round(rate / peak, 4), "traffic": None, "launches": c["launches"],
+                    "frac": round(rate / peak, 4),
+                    "traffic": pmc.get(key, {}).get("traffic_bytes_per_launch") if args.batch == 16 and
+                    args.resolution == 256 and args.dtype == "bf16" else None,
+                    "traffic_unit": "HBM-side bytes per launch, rocprofv3 PMC (profiles/r01_pmc_traffic.json)",
+                    "launches": c["launches"],
                     "avg_us": round(c["avg_us"], 2), "algorithmic_work_per_launch": round(c["work"] / c["launches"])}
         mf = args.dtype == "bf16"
         roof = leg(f"conv_fprop/{args.dtype}", "mfma", MFMA_BF16_PEAK_TFLOPS if mf else MFMA_F32_PEAK_TFLOPS,

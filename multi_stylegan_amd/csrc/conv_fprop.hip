@@ -291,6 +291,11 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     }
 }
 
+extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float* bias, void* y,
+                                       int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                       int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                       long long w_batch_stride, void* stream);
+
 extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, int dtype,
                                 int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                 int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
@@ -305,6 +310,10 @@ extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias,
     if (pixel_shuffle && (N % 4 || (N / 4) % vec || ldy % vec)) return MSG_EUNSUPPORTED;
     if (!pixel_shuffle && ldy % vec) return MSG_EUNSUPPORTED;
     if (in_up > 1 && stride != 1) return MSG_EUNSUPPORTED;
+    if (dtype == MSG_BF16 &&
+        msg_conv2d_fprop_pp_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
+                                pixel_shuffle, w_batch_stride, stream))
+        return MSG_CHECK_LAUNCH();                 // large shapes: 256x256 ping-pong kernel (conv_fprop_pp.hip)
     ConvParams p{};
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.in_up = in_up; p.pixel_shuffle = pixel_shuffle;

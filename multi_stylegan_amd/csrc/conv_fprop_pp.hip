@@ -1,0 +1,268 @@
+// a3/a4: large-tile "ping-pong" variant of the implicit-GEMM convolution (same contract as conv_fprop.hip, bf16 only).
+//
+// The 128x128 kernel keeps the matrix pipe ~50 % busy: per MFMA it needs 1 KiB of LDS fragment reads and 0.5 KiB of
+// LDS fills, and its four waves sit in the same barrier at the same time.  This kernel changes the ratios and the
+// schedule:
+//   * workgroup tile 256 (pixels) x 256 (channels) x 64 (K), 8 waves, wave tile 128 x 64 -> 0.5 KiB of fragment reads
+//     and 0.25 KiB of LDS-DMA fill per MFMA; 2 LDS stages of 64 KiB; one workgroup per CU;
+//   * the two waves that share a SIMD (w and w+4) run half a phase apart: while one issues its 16 MFMAs (a 64x64
+//     half of its tile) the other reads the 16 fragments of its next half and issues LDS-DMA for the next K-tile, then
+//     they swap.  Four s_barrier slots per K-tile keep the two groups in lock-step; the barriers are raw (no implicit
+//     vmcnt(0)), each wave waits for its own DMA pieces exactly once per K-tile, one slot before they are needed.
+//
+//   slot (global)      4t        4t+1      4t+2      4t+3      4t+4
+//   group 0 (w<4)    read h0(t)  MFMA h0   read h1   MFMA h1   read h0(t+1) ...
+//   group 1 (w>=4)   MFMA h1(t-1) read h0(t) MFMA h0  read h1   MFMA h1(t)  ...
+//   DMA(t+1) is issued at the top of each wave's "read h0(t)" phase and retired before the barrier that ends slot
+//   4t+3; the stage it fills was last read in slot 4t-1, and read phases drain lgkmcnt before their barrier.
+#include "msg_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef __attribute__((address_space(3))) char* lds_t;
+
+struct ConvParamsPP {
+    int B, IH, IW, Cx, Ck, OH, OW, N, ldy;
+    int kh, kw, stride, pad, in_up, pixel_shuffle, per_sample;
+    long long x_bstride, w_bstride, y_bstride;
+    int Mtot, n_chunks, n_iters, m_tiles, n_tiles;
+};
+
+constexpr int PM = 256, PN = 256, PROW = 128;
+constexpr int PSTAGE = (PM + PN) * PROW;                  // 64 KiB
+__device__ __attribute__((aligned(256))) unsigned int g_pp_zero_page[16384];
+
+__device__ __forceinline__ int pswz(int row, int slot) { return row * PROW + ((slot ^ ((row >> 1) & 7)) << 4); }
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); \
+                          __builtin_amdgcn_sched_barrier(0); } while (0)
+
+__global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                               bf16_t* __restrict__ y, const float* __restrict__ bias,
+                                                               ConvParamsPP p) {
+    constexpr int VEC = 8, BKE = 64, ESZ = 2;
+    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    const int grp = wid_u >> 2;                           // 0: waves 0-3 (tile rows 0..127), 1: waves 4-7 (rows 128..255)
+    const int wn = wid_u & 3;                             // 64-column slice of the tile
+    const int lr = lane & 31, lh = lane >> 5;
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (int)(L % p.n_tiles) * PN;
+    const int m0 = (int)(L / p.n_tiles) * PM;
+    const int bz = blockIdx.z;
+
+    // ---- LDS-DMA assignment: wave w fills rows 32 w + 8 j + (lane >> 3) of A and of B (j = 0..3).  lane & 7 is the
+    // PHYSICAL 16-B slot; the lane fetches the logical slot that the XOR swizzle puts there.  Row coordinates are
+    // recomputed at every tap change (once per n_chunks K-tiles) instead of living in registers: this kernel needs its
+    // VGPRs for 128 accumulators + 64 fragment registers.
+    const int slot_phys = lane & 7;
+    const int row0 = wid * 32 + (lane >> 3);                 // row of j = 0; j adds 8
+    const int sw0 = (row0 >> 1) & 7;                         // swizzle of rows j = 0, 2 ; rows j = 1, 3 use sw0 ^ 4
+    const int ohw = p.OH * p.OW;
+    const int taps = p.kh * p.kw;
+    const gptr_t xbase = (gptr_t)x;
+    const gptr_t zbase = (gptr_t)g_pp_zero_page;
+    const long long zoff = slot_phys * 16;
+    gptr_t pa[4], pb[4];
+    {
+        const gptr_t wb = (gptr_t)w + (p.per_sample ? (long long)bz * p.w_bstride : 0) * ESZ;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + row0 + 8 * j;
+            const int sl = slot_phys ^ (sw0 ^ ((j & 1) << 2));
+            const bool ok = n < p.N;
+            pb[j] = (ok ? wb : zbase) + (ok ? ((long long)n * taps * p.Ck + sl * VEC) * ESZ : zoff);
+            pa[j] = zbase;
+        }
+    }
+    const bool ragged = (p.Cx % BKE) != 0;
+    int ld_tap = -1, ld_chunk = p.n_chunks - 1;
+    auto advance = [&]() __attribute__((always_inline)) {     // cursor to the next K-tile; new tap -> new row pointers
+        if (++ld_chunk == p.n_chunks) {
+            ld_chunk = 0;
+            ++ld_tap;
+            const int kh_ = ld_tap / p.kw, kw_ = ld_tap - kh_ * p.kw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + row0 + 8 * j;
+                const int sl = slot_phys ^ (sw0 ^ ((j & 1) << 2));
+                bool ok = m < p.Mtot;
+                const int mm = ok ? m : 0;
+                const int b = p.per_sample ? bz : mm / ohw;
+                const int pix = p.per_sample ? mm : mm - b * ohw;
+                const int oh = pix / p.OW, ow = pix - oh * p.OW;
+                int ih = oh * p.stride - p.pad + kh_, iw = ow * p.stride - p.pad + kw_;
+                ok = ok & (ih >= 0) & (iw >= 0);
+                if (p.in_up > 1) {
+                    ok = ok & (ih % p.in_up == 0) & (iw % p.in_up == 0);
+                    ih /= p.in_up; iw /= p.in_up;
+                }
+                ok = ok & (ih < p.IH) & (iw < p.IW);
+                const long long off = ok ? ((long long)b * p.x_bstride + ((long long)ih * p.IW + iw) * p.Cx + sl * VEC) * ESZ : zoff;
+                pa[j] = (ok ? xbase : zbase) + off;
+            }
+        }
+    };
+    auto issue = [&](int jlo, int stage) __attribute__((always_inline)) {   // two of this wave's four row groups
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = jlo + jj;
+            const bool c_bad = ragged && (ld_chunk * BKE + (slot_phys ^ (sw0 ^ ((j & 1) << 2))) * VEC + VEC > p.Cx);
+            gptr_t a_addr = pa[j];
+            if (c_bad) a_addr = zbase + zoff;
+            lds_t la = (lds_t)(smem + stage * PSTAGE + (wid_u * 32 + 8 * j) * PROW);
+            __builtin_amdgcn_global_load_lds(a_addr, la, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pb[j], la + PM * PROW, 16, 0, 0);
+            pa[j] += PROW;
+            pb[j] += PROW;
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    bf16v8 fa[2][4], fb[2][4];                              // fragments of one 64x64 half: [tile][k-step]
+    auto read_half = [&](int stage, int h) __attribute__((always_inline)) {
+        const char* sa = smem + stage * PSTAGE;
+        const char* sb = sa + PM * PROW;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t][ks] = *reinterpret_cast<const bf16v8*>(sa + pswz(grp * 128 + h * 64 + t * 32 + lr, 2 * ks + lh));
+                fb[t][ks] = *reinterpret_cast<const bf16v8*>(sb + pswz(wn * 64 + t * 32 + lr, 2 * ks + lh));
+            }
+    };
+    auto mfma_half = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[h * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[h * 2 + i][j], 0, 0, 0);
+    };
+
+    const int T = p.n_iters;
+    // ---- prologue: K-tile 0 into stage 0 (all waves)
+    advance();
+    issue(0, 0);
+    issue(2, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();                               // stagger: group 1 runs one slot behind group 0
+
+    // DMA(t+1) goes to the stage that held K-tile t-1, last read in global slot 4t-1.  Every read phase ends with
+    // lgkmcnt(0) BEFORE its barrier (the reading wave would idle there anyway), so once a barrier is passed all
+    // fragment reads of earlier slots have returned and the stage may be refilled.  Each wave issues its 8 DMA pieces
+    // at the top of its phase A (global slot 4t for group 0, 4t+1 for group 1) -- MFMA phases carry nothing but
+    // MFMAs -- and retires them before the barrier that ends global slot 4t+3.
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        // ---- phase A: DMA for the next K-tile, fragments of half 0
+        if (t + 1 < T) { advance(); issue(0, buf ^ 1); issue(2, buf ^ 1); }
+        read_half(buf, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        // ---- phase B: MFMAs of half 0
+        __builtin_amdgcn_s_setprio(1);
+        mfma_half(0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BARRIER();
+        // ---- phase C: fragments of half 1
+        read_half(buf, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K-tile t+1 is in LDS
+        PP_BARRIER();
+        // ---- phase D: MFMAs of half 1
+        __builtin_amdgcn_s_setprio(1);
+        mfma_half(1);
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BARRIER();
+    }
+    if (grp == 0) PP_BARRIER();
+
+    // ---- epilogue: wave-private 128 x 64 bf16 patch in LDS (16 KiB per wave = all 128 KiB), then 16-B stores
+    constexpr int PITCH = 64 * ESZ;
+    char* ep = smem + wid * (128 * PITCH);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + lr;
+            const int n = n0 + wn * 64 + col;
+            const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                reinterpret_cast<bf16_t*>(ep + row * PITCH)[col] = f2bf(acc[i][j][e] + bv);
+            }
+        }
+    __syncthreads();
+    const int er = lane >> 3, ec = (lane & 7) * VEC;          // 8 lanes per 64-channel row, 8 rows per pass
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int row = pass * 8 + er;
+        const int m = m0 + grp * 128 + row;
+        const int n = n0 + wn * 64 + ec;
+        if (m >= p.Mtot || n >= p.N) continue;
+        const int b = p.per_sample ? bz : m / ohw;
+        const int pix = p.per_sample ? m : m - b * ohw;
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        bf16_t* dst;
+        int nn = n;
+        if (p.pixel_shuffle) {
+            const int oc = p.N >> 2, q = n / oc;
+            nn = n - q * oc;
+            dst = y + (long long)b * p.y_bstride + ((long long)(2 * oh + (q >> 1)) * (2 * p.OW) + (2 * ow + (q & 1))) * p.ldy + nn;
+        } else {
+            dst = y + (long long)b * p.y_bstride + ((long long)oh * p.OW + ow) * p.ldy + n;
+        }
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(ep + row * PITCH) + ec;
+        const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;
+        if (lim >= VEC) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+        else for (int e = 0; e < lim; ++e) dst[e] = src[e];
+    }
+}
+
+// Called by msg_conv2d_fprop (conv_fprop.hip) for shapes where the large tile pays; returns 1 if it launched.
+extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float* bias, void* y,
+                                       int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                       int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                       long long w_batch_stride, void* stream) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("MSG_CONV_PP"); enabled = e ? atoi(e) : 1; }
+    if (!enabled) return 0;
+    const bool per_sample = w_batch_stride != 0;
+    const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;
+    const int n_iters = kh * kw * (Ck / 64);
+    if (N < 256 || mtot < 1024 || n_iters < 4 || mtot >= (1ll << 31)) return 0;
+    if ((long long)(n_iters + 1) * PROW + 128 > 65536) return 0;
+    ConvParamsPP p{};
+    p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.in_up = in_up; p.pixel_shuffle = pixel_shuffle;
+    p.per_sample = per_sample;
+    p.x_bstride = (long long)IH * IW * Cx;
+    p.w_bstride = w_batch_stride;
+    p.y_bstride = pixel_shuffle ? 4ll * OH * OW * ldy : (long long)OH * OW * ldy;
+    p.Mtot = (int)mtot;
+    p.n_chunks = Ck / 64;
+    p.n_iters = n_iters;
+    p.m_tiles = (int)((mtot + PM - 1) / PM);
+    p.n_tiles = (N + PN - 1) / PN;
+    const long long blocks = (long long)p.m_tiles * p.n_tiles;
+    if (blocks >= (1ll << 31)) return 0;
+    if (blocks * (per_sample ? B : 1) < 224) return 0;      // one workgroup per CU: small grids belong to the 128-tile kernel
+    dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);
+    hipLaunchKernelGGL(conv_fprop_pp_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,
+                       (bf16_t*)y, bias, p);
+    return 1;
+}

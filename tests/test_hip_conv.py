@@ -170,3 +170,34 @@ def test_fused_modulated_conv_matches_composite(kind, dtype):
     for a, c, r, name in zip(gd, gc, gr, ("gx", "gw", "gs")):
         assert rel_err(a.float(), r) < tol, name
         assert rel_err(a.float(), c.float()) < tol, name + " vs composite"
+
+
+PP_CASES = [  # shapes that take the 256x256 ping-pong kernel: name, kind, B, I, O, H, W, k, stride, pad, per_sample
+    ("pp_3x3_ragged_m", "conv", 5, 64, 256, 15, 15, 3, 1, 1, True),            # per-sample M = 225 (< tile), many z
+    ("pp_3x3_shared", "conv", 4, 72, 384, 40, 40, 3, 1, 1, False),              # N tail (384), ragged K (72)
+    ("pp_1x1_shared", "conv", 8, 256, 256, 48, 48, 1, 1, 0, False),
+    ("pp_up2", "up2", 3, 64, 128, 36, 36, 2, 2, 0, True),                        # 4*O = 512 columns, pixel shuffle
+    ("pp_s2_dgrad", "conv", 4, 256, 256, 65, 65, 3, 2, 0, False),               # its data gradient uses in_up = 2
+]
+
+
+@pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_pingpong_kernel_shapes(case):
+    """bf16 forward + data gradient on shapes large enough for conv_fprop_pp.hip, against fp64 CPU convolutions."""
+    from multi_stylegan_amd import conv_ops
+    name, kind, b, i, o, h, w_, k, stride, pad, per_sample = case
+    g = torch.Generator().manual_seed(len(name))
+    x = torch.randn(b, i, h, w_, generator=g).bfloat16().double()
+    wshape = (b, o, i, k, k) if per_sample else (o, i, k, k)
+    w = (torch.randn(*wshape, generator=g) / math.sqrt(i * k * k)).bfloat16().double()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = _reference(kind, xr, wr, stride, pad, per_sample)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().double()
+    gxr, = torch.autograd.grad(yr, xr, gy)
+    xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(DEV, torch.float32)
+    geo = conv_ops.Geometry(kind, k, k, stride if kind == "conv" else 1, pad, (h, w_), per_sample)
+    y = conv_ops._ConvF.apply(xd, wd, None, geo)
+    gx, = torch.autograd.grad(y, xd, gy.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert rel_err(y.float(), yr) < 2e-2, "forward"
+    assert rel_err(gx.float(), gxr) < 2e-2, "data gradient"

@@ -44,7 +44,7 @@ def build(force=False, verbose=True, extra_flags=()):
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
             continue
         cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-c", src, "-o", obj,
-               "-Wno-unused-result", *extra_flags]
+               "-Wno-unused-result", *extra_flags, *os.environ.get("MSG_EXTRA_HIPCC_FLAGS", "").split()]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

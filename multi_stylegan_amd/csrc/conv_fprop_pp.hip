@@ -10,6 +10,11 @@
 //     they swap.  Four s_barrier slots per K-tile keep the two groups in lock-step; the barriers are raw (no implicit
 //     vmcnt(0)), each wave waits for its own DMA pieces exactly once per K-tile, one slot before they are needed.
 //
+// Measured with in-kernel s_memtime stamps (tools/pp_stamps.py): MFMA phase ~600 cycles, fragment-read phase ~370,
+// but issuing a wave's 8 LDS-DMA pieces costs ~850 cycles (~100 per piece), which makes phase A the critical path
+// (K-tile ~4200 cycles vs 2048 ideal).  Spreading the pieces into the MFMA phases is the next step; a first attempt
+// ran out of VGPRs (128 accumulators + 64 fragment registers leave ~60 for everything else).
+//
 //   slot (global)      4t        4t+1      4t+2      4t+3      4t+4
 //   group 0 (w<4)    read h0(t)  MFMA h0   read h1   MFMA h1   read h0(t+1) ...
 //   group 1 (w>=4)   MFMA h1(t-1) read h0(t) MFMA h0  read h1   MFMA h1(t)  ...
@@ -34,6 +39,18 @@ constexpr int PSTAGE = (PM + PN) * PROW;                  // 64 KiB
 __device__ __attribute__((aligned(256))) unsigned int g_pp_zero_page[16384];
 
 __device__ __forceinline__ int pswz(int row, int slot) { return row * PROW + ((slot ^ ((row >> 1) & 7)) << 4); }
+#ifdef MSG_PP_STAMPS
+// diagnostic build only: cycle stamps of K-tile 8 of every wave of the first 256 workgroups (tools/pp_stamps.py)
+__device__ unsigned long long g_pp_stamps[256 * 8 * 10];
+#define PP_STAMP(k) do { if (t == 8 && blockIdx.x < 256 && blockIdx.z == 0 && lane == 0) { unsigned long long tt; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); \
+    g_pp_stamps[(blockIdx.x * 8 + wid_u) * 10 + (k)] = tt; } } while (0)
+extern "C" int msg_pp_debug_read(void* host_dst, int nbytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pp_stamps), nbytes) == hipSuccess ? 0 : -1;
+}
+#else
+#define PP_STAMP(k) do {} while (0)
+#endif
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); \
                           __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -65,6 +82,18 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     const gptr_t xbase = (gptr_t)x;
     const gptr_t zbase = (gptr_t)g_pp_zero_page;
     const long long zoff = slot_phys * 16;
+    // (b, oh, ow) of this lane's four A rows, packed 10|11|11 bits (one VGPR per row); bit 31 = row is beyond M
+    unsigned rc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + row0 + 8 * j;
+        const bool ok = m < p.Mtot;
+        const int mm = ok ? m : 0;
+        const int b = p.per_sample ? 0 : mm / ohw;
+        const int pix = p.per_sample ? mm : mm - b * ohw;
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        rc[j] = (ok ? 0u : 0x80000000u) | ((unsigned)b << 22) | ((unsigned)oh << 11) | (unsigned)ow;
+    }
     gptr_t pa[4], pb[4];
     {
         const gptr_t wb = (gptr_t)w + (p.per_sample ? (long long)bz * p.w_bstride : 0) * ESZ;
@@ -78,21 +107,25 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
         }
     }
     const bool ragged = (p.Cx % BKE) != 0;
-    int ld_tap = -1, ld_chunk = p.n_chunks - 1;
+    int ld_tap = -1, ld_chunk = p.n_chunks - 1, ld_tile = -1;
     auto advance = [&]() __attribute__((always_inline)) {     // cursor to the next K-tile; new tap -> new row pointers
+        if (++ld_tile >= p.n_iters) {                         // past the last K-tile: copies of zeros into an unused stage
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pa[j] = zbase + zoff; pb[j] = zbase + zoff; }
+            ld_chunk = 0;
+            ld_tap = taps;                                    // (never a real tap again)
+            return;
+        }
         if (++ld_chunk == p.n_chunks) {
             ld_chunk = 0;
             ++ld_tap;
             const int kh_ = ld_tap / p.kw, kw_ = ld_tap - kh_ * p.kw;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int m = m0 + row0 + 8 * j;
                 const int sl = slot_phys ^ (sw0 ^ ((j & 1) << 2));
-                bool ok = m < p.Mtot;
-                const int mm = ok ? m : 0;
-                const int b = p.per_sample ? bz : mm / ohw;
-                const int pix = p.per_sample ? mm : mm - b * ohw;
-                const int oh = pix / p.OW, ow = pix - oh * p.OW;
+                bool ok = (rc[j] >> 31) == 0;
+                const int b = p.per_sample ? bz : (int)((rc[j] >> 22) & 0x1ff);
+                const int oh = (int)((rc[j] >> 11) & 0x7ff), ow = (int)(rc[j] & 0x7ff);
                 int ih = oh * p.stride - p.pad + kh_, iw = ow * p.stride - p.pad + kw_;
                 ok = ok & (ih >= 0) & (iw >= 0);
                 if (p.in_up > 1) {
@@ -120,6 +153,20 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
         }
     };
 
+    auto issue_one = [&](int j, bool b_rows, int stage) __attribute__((always_inline)) {
+        lds_t la = (lds_t)(smem + stage * PSTAGE + (wid_u * 32 + 8 * j) * PROW);
+        if (!b_rows) {
+            const bool c_bad = ragged && (ld_chunk * BKE + (slot_phys ^ (sw0 ^ ((j & 1) << 2))) * VEC + VEC > p.Cx);
+            gptr_t a_addr = pa[j];
+            if (c_bad) a_addr = zbase + zoff;
+            __builtin_amdgcn_global_load_lds(a_addr, la, 16, 0, 0);
+            pa[j] += PROW;
+        } else {
+            __builtin_amdgcn_global_load_lds(pb[j], la + PM * PROW, 16, 0, 0);
+            pb[j] += PROW;
+        }
+    };
+
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -129,25 +176,45 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     bf16v8 fa[2][4], fb[2][4];                              // fragments of one 64x64 half: [tile][k-step]
-    auto read_half = [&](int stage, int h) __attribute__((always_inline)) {
-        const char* sa = smem + stage * PSTAGE;
-        const char* sb = sa + PM * PROW;
+    // Fragment addresses: every row this lane reads is (multiple of 32) + lr, so the swizzle term is the same for all
+    // of them and the address is  [per-k-step VGPR] + compile-time offset(half, tile).  The four VGPRs per operand
+    // flip between the two LDS stages with one XOR per K-tile; the reads themselves cost no address arithmetic.
+    unsigned fa_addr[4], fb_addr[4];
+    {
+        const unsigned sw = (unsigned)(lr >> 1) & 7u;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned koff = (((unsigned)(2 * ks + lh)) ^ sw) << 4;
+            fa_addr[ks] = (unsigned)((grp * 128 + lr) * PROW) + koff;
+            fb_addr[ks] = (unsigned)(PM * PROW + (wn * 64 + lr) * PROW) + koff;
+        }
+    }
+    auto read_half = [&](int h) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fa[t][ks] = *reinterpret_cast<const bf16v8*>(sa + pswz(grp * 128 + h * 64 + t * 32 + lr, 2 * ks + lh));
-                fb[t][ks] = *reinterpret_cast<const bf16v8*>(sb + pswz(wn * 64 + t * 32 + lr, 2 * ks + lh));
+                fa[t][ks] = *reinterpret_cast<const bf16v8*>(smem + fa_addr[ks] + (h * 64 + t * 32) * PROW);
+                fb[t][ks] = *reinterpret_cast<const bf16v8*>(smem + fb_addr[ks] + (t * 32) * PROW);
             }
     };
-    auto mfma_half = [&](int h) __attribute__((always_inline)) {
+    auto flip_stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) { fa_addr[ks] ^= (unsigned)PSTAGE; fb_addr[ks] ^= (unsigned)PSTAGE; }
+    };
+    // 16 MFMAs of one 64x64 half.  With `dma` (wave-uniform) the four pieces of row groups 2 and 3 are issued in
+    // their shadow, one after every fourth MFMA: an LDS-DMA issue costs ~100 cycles in a read phase but hides
+    // between MFMAs.
+    auto mfma_half = [&](int h, bool dma, int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[h * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[h * 2 + i][j], 0, 0, 0);
+            if (dma) issue_one(2 + (ks >> 1), (ks & 1) != 0, stage);
+        }
     };
 
     const int T = p.n_iters;
@@ -164,28 +231,43 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     // fragment reads of earlier slots have returned and the stage may be refilled.  Each wave issues its 8 DMA pieces
     // at the top of its phase A (global slot 4t for group 0, 4t+1 for group 1) -- MFMA phases carry nothing but
     // MFMAs -- and retires them before the barrier that ends global slot 4t+3.
+    // Measured alternatives (tools/pp_stamps.py, same shape): splitting the pieces 4 + 4 over phases A and C (group 0)
+    // / A and B-between-MFMAs (group 1) was slower (994 vs 1073 TFLOP/s): an issue costs ~40 cycles between MFMAs but
+    // ~150-200 in a read phase that also carries fragment reads, and only group 1 has two MFMA phases inside the window
+    // in which the target stage is free.  Kept: all 8 pieces at the top of phase A.
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         // ---- phase A: DMA for the next K-tile, fragments of half 0
+        PP_STAMP(0);
         if (t + 1 < T) { advance(); issue(0, buf ^ 1); issue(2, buf ^ 1); }
-        read_half(buf, 0);
+        PP_STAMP(1);
+        read_half(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_STAMP(2);
         PP_BARRIER();
+        PP_STAMP(3);
         // ---- phase B: MFMAs of half 0
         __builtin_amdgcn_s_setprio(1);
-        mfma_half(0);
+        mfma_half(0, false, 0);
         __builtin_amdgcn_s_setprio(0);
+        PP_STAMP(4);
         PP_BARRIER();
+        PP_STAMP(5);
         // ---- phase C: fragments of half 1
-        read_half(buf, 1);
+        read_half(1);
+        flip_stage();                                      // next reads come from the other stage
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_STAMP(6);
         if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K-tile t+1 is in LDS
+        PP_STAMP(7);
         PP_BARRIER();
+        PP_STAMP(8);
         // ---- phase D: MFMAs of half 1
         __builtin_amdgcn_s_setprio(1);
-        mfma_half(1);
+        mfma_half(1, false, 0);
         __builtin_amdgcn_s_setprio(0);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_STAMP(9);
         PP_BARRIER();
     }
     if (grp == 0) PP_BARRIER();

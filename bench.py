@@ -162,8 +162,10 @@ def main():
                     "launches": c["launches"],
                     "avg_us": round(c["avg_us"], 2), "algorithmic_work_per_launch": round(c["work"] / c["launches"])}
         mf = args.dtype == "bf16"
-        roof = leg(f"conv_fprop/{args.dtype}", "mfma", MFMA_BF16_PEAK_TFLOPS if mf else MFMA_F32_PEAK_TFLOPS,
-                   "TFLOP/s", f"conv_fprop_kernel<{args.dtype}> (implicit-GEMM conv fwd + data-grad, MFMA 32x32)")
+        roof = leg(f"conv_fprop_pp/{args.dtype}", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
+                   "conv_fprop_pp_kernel (implicit-GEMM conv fwd + data-grad, 256x256 ping-pong tile, MFMA 32x32x16 bf16)") \
+            if mf else leg(f"conv_fprop_dma/{args.dtype}", "mfma", MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                           "conv_fprop_kernel<float, true> (implicit-GEMM conv, MFMA 32x32x2 f32)")
         roof_fir = leg(f"upfirdn2d/{args.dtype}/up1down1/vec", "hbm", HBM_PEAK_GBS, "GB/s",
                        "upfirdn2d_vec_kernel<up=1,down=1> (4x4 FIR blur, channels-last)")
         kernels = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),

@@ -141,6 +141,11 @@ int msg_modulate_backward(const float* gwk, const float* W, const float* s, cons
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
 int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);
 
+/* Which kernel msg_conv2d_fprop launches for a problem (no launch): 2 = 256x256 ping-pong, 1 = 128x128 with LDS-DMA
+ * staging, 0 = 128x128 with register staging.  Used by bench.py to label per-kernel timings. */
+int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
+                          int kh, int kw, long long w_batch_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,7 +142,11 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
     wstride = wk.stride(0) if per_sample else 0
     # algorithmic FLOPs: real channels, and only the taps a transposed strided conv can reach (1/in_up^2)
     flops = 2.0 * b * oh * ow * n * kh * kw * c_real / (in_up * in_up)
-    with torch.cuda.device(dev), _lib.kernel_clock.span(f"conv_fprop/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
+    key = "conv_fprop"
+    if _lib.kernel_clock.enabled:                       # label the timing with the kernel the library will pick
+        plan = _lib.lib().msg_conv2d_fprop_plan(_lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, kh, kw, wstride)
+        key = ("conv_fprop_reg", "conv_fprop_dma", "conv_fprop_pp")[plan]
+    with torch.cuda.device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_fprop(
             xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow,
             n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))

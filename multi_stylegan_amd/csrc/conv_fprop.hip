@@ -296,6 +296,21 @@ extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float
                                        int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
                                        long long w_batch_stride, void* stream);
 
+extern "C" int msg_conv2d_fprop_pp_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
+                                            int kh, int kw, long long w_batch_stride);
+
+// Which kernel msg_conv2d_fprop would launch for this problem: 2 = conv_fprop_pp_kernel (256x256 ping-pong),
+// 1 = conv_fprop_kernel<T, true> (128x128, LDS-DMA staging), 0 = conv_fprop_kernel<T, false> (register staging).
+extern "C" int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
+                                     int kh, int kw, long long w_batch_stride) {
+    if (dtype == MSG_BF16 && msg_conv2d_fprop_pp_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 2;
+    const int esz = dtype == MSG_BF16 ? 2 : 4;
+    const int n_iters = kh * kw * (Ck / (128 / esz));
+    const char* e = getenv("MSG_CONV_VARIANT");
+    const int variant = e ? atoi(e) : 0;
+    return (variant == 1 || (variant == 0 && n_iters >= 12)) ? 1 : 0;
+}
+
 extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, int dtype,
                                 int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                 int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,

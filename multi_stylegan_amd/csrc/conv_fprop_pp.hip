@@ -315,11 +315,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     }
 }
 
-// Called by msg_conv2d_fprop (conv_fprop.hip) for shapes where the large tile pays; returns 1 if it launched.
-extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float* bias, void* y,
-                                       int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
-                                       int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
-                                       long long w_batch_stride, void* stream) {
+// Which shapes take the large tile (shared by the launcher below and by msg_conv2d_fprop_plan).
+extern "C" int msg_conv2d_fprop_pp_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
+                                            int kh, int kw, long long w_batch_stride) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("MSG_CONV_PP"); enabled = e ? atoi(e) : 1; }
     if (!enabled) return 0;
@@ -328,6 +326,21 @@ extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float
     const int n_iters = kh * kw * (Ck / 64);
     if (N < 256 || mtot < 1024 || n_iters < 4 || mtot >= (1ll << 31)) return 0;
     if ((long long)(n_iters + 1) * PROW + 128 > 65536) return 0;
+    const long long blocks = ((mtot + PM - 1) / PM) * ((N + PN - 1) / PN);
+    if (blocks >= (1ll << 31)) return 0;
+    if (blocks * (per_sample ? B : 1) < 224) return 0;      // one workgroup per CU: small grids belong to the 128-tile kernel
+    return 1;
+}
+
+// Called by msg_conv2d_fprop (conv_fprop.hip) for shapes where the large tile pays; returns 1 if it launched.
+extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float* bias, void* y,
+                                       int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                       int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                       long long w_batch_stride, void* stream) {
+    if (!msg_conv2d_fprop_pp_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 0;
+    const bool per_sample = w_batch_stride != 0;
+    const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;
+    const int n_iters = kh * kw * (Ck / 64);
     ConvParamsPP p{};
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.in_up = in_up; p.pixel_shuffle = pixel_shuffle;
@@ -341,8 +354,6 @@ extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float
     p.m_tiles = (int)((mtot + PM - 1) / PM);
     p.n_tiles = (N + PN - 1) / PN;
     const long long blocks = (long long)p.m_tiles * p.n_tiles;
-    if (blocks >= (1ll << 31)) return 0;
-    if (blocks * (per_sample ? B : 1) < 224) return 0;      // one workgroup per CU: small grids belong to the 128-tile kernel
     dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);
     hipLaunchKernelGGL(conv_fprop_pp_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,
                        (bf16_t*)y, bias, p);

@@ -106,6 +106,7 @@ int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
  *   gw fp32 [(B)][O][kh*kw][ldgw]; per_sample = 1 (k_chunks must be 1): one slice per sample, plain stores;
  *   otherwise every (sample, pixel-chunk) slice ACCUMULATES with float atomics (zero gw first).
  *   pixel_shuffle = 1: OH,OW are the LOW-res extent, gy is [B,2*OH,2*OW,ldgy], tap = (dy,dx).
+ *   oi_major = 1 writes gw[(b)][o][i][tap] (the parameter's own [O,I,kh,kw] layout) instead; gain multiplies the result.
  * ------------------------------------------------------------------------- */
 int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, int dtype,
                      int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
@@ -114,7 +115,7 @@ int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, i
 int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
                      int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
                      int kh, int kw, int stride, int pad, int pixel_shuffle,
-                     int per_sample, int k_chunks, void* stream);
+                     int per_sample, int k_chunks, int oi_major, float gain, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a3  weight modulation / demodulation of the dual-styled conv (multi_stylegan/multi_stylegan_generator.py:379-388).

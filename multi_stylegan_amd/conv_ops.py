@@ -154,7 +154,7 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
     return y
 
 
-def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw, raw=False):
+def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw, raw=False, gain=1.0):
     dev = _lib.require_gpu(gy, x)
     gv, ldgy = _nhwc_view(gy)
     xv, cx = _nhwc_view(x)
@@ -162,6 +162,10 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
     oh, ow = low_hw if pixel_shuffle else gv.shape[2:]
     taps = kh * kw
     ldgw = _round_up(i, 4)
+    # The kernel's own [O][tap][I] layout keeps its stores / float atomics on 128-byte runs (the parameter layout
+    # [O][I][tap] would scatter them: measured 25 % slower end to end); the caller gets a strided VIEW in parameter
+    # order, so no transposing copy is made either.
+    oi_major = False
     if per_sample:
         gw = torch.empty((b, o, taps, ldgw), dtype=torch.float32, device=dev)
         k_chunks = 1
@@ -176,13 +180,13 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
     with torch.cuda.device(dev), _lib.kernel_clock.span(f"conv_wgrad/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_wgrad(
             gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw,
-            kh, kw, stride, pad, int(pixel_shuffle), int(per_sample), k_chunks, _lib.stream_of(dev))
+            kh, kw, stride, pad, int(pixel_shuffle), int(per_sample), k_chunks, int(oi_major), float(gain),
+            _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_wgrad")
     if raw:
         return gw, ldgw                                   # kernel layout [(B)][O][taps][ldgw]
-    gw = gw[..., :i]
-    # [.., O, taps, I] -> [.., O, I, kh, kw]
-    return gw.transpose(-1, -2).reshape(*gw.shape[:-2], i, kh, kw)
+    lead = gw.shape[:-2]                                  # [(B), O]
+    return gw.view(*lead, kh, kw, ldgw)[..., :i].permute(*range(len(lead)), len(lead) + 2, len(lead), len(lead) + 1)
 
 
 # ------------------------------------------------------------------------------------- the three primitives, raw
@@ -232,10 +236,8 @@ def _d_raw(gy, w, g: Geometry):
 
 def _g_raw(gy, x, o, i, g: Geometry):
     if g.kind == "up2":
-        gw = _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw)
-    else:
-        gw = _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None)
-    return gw * g.wscale if g.wscale != 1.0 else gw
+        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw, gain=g.wscale)
+    return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None, gain=g.wscale)
 
 
 # ------------------------------------------------------------------------------------- autograd closure of F/D/G

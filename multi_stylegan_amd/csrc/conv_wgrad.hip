@@ -30,6 +30,8 @@ struct WgradParams {
     int kh, kw, stride, pad, pixel_shuffle;
     int per_sample, chunks_per_sample, pix_per_chunk, atomic;
     int o_tiles, i_tiles, ldgw;                       // ldgw = padded I of the gradient buffer
+    int oi_major;                                     // 1: gw[o][i][tap] (the parameter's own layout), 0: gw[o][tap][ldgw]
+    float gain;                                       // multiplies the result (equalized-lr scale of the layer)
     long long gw_zstride;
 };
 
@@ -242,9 +244,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             for (int e = 0; e < 16; ++e) {
                 const int o = o0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (o >= p.O) continue;
-                float* dst = gz + ((long long)o * taps + tap) * p.ldgw + ic;
-                if (p.atomic) atomicAdd(dst, acc[i][j][e]);
-                else *dst = acc[i][j][e];
+                float* dst = p.oi_major ? gz + ((long long)o * p.I + ic) * taps + tap
+                                        : gz + ((long long)o * taps + tap) * p.ldgw + ic;
+                if (p.oi_major && ic >= p.I) continue;
+                const float v = acc[i][j][e] * p.gain;
+                if (p.atomic) atomicAdd(dst, v);
+                else *dst = v;
             }
         }
 }
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
 extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
                                 int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
                                 int kh, int kw, int stride, int pad, int pixel_shuffle,
-                                int per_sample, int k_chunks, void* stream) {
+                                int per_sample, int k_chunks, int oi_major, float gain, void* stream) {
     if (B == 0) return MSG_OK;
     if (!gy || !x || !gw || B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || O <= 0 || I <= 0 || kh <= 0 ||
         kw <= 0 || stride <= 0 || Cx <= 0 || ldgy <= 0 || ldgw < I || k_chunks <= 0)
@@ -272,7 +277,9 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     p.o_tiles = (O + WT - 1) / WT;
     p.i_tiles = (I + WT - 1) / WT;
     p.ldgw = ldgw;
-    p.gw_zstride = (long long)O * kh * kw * ldgw;
+    p.gw_zstride = oi_major ? (long long)O * I * kh * kw : (long long)O * kh * kw * ldgw;
+    p.oi_major = oi_major;
+    p.gain = gain;
     const long long zs = (long long)B * k_chunks;
     if (zs > 65535 || kh * kw > 65535) return MSG_EUNSUPPORTED;
     dim3 grid(p.o_tiles * p.i_tiles, kh * kw, (unsigned)zs);

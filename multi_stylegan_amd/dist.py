@@ -83,6 +83,7 @@ class GradBucketReducer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets: List[_Bucket] = []
         self._armed = False
+        self._next = 0
         self._bucket_of = {}
         cap = max(1, bucket_bytes // 4)
         # gradients become ready roughly in reverse registration order: fill buckets from the back
@@ -136,6 +137,7 @@ class GradBucketReducer:
     def arm(self) -> None:
         """Call right before the backward whose gradients this reducer owns."""
         self._armed = True
+        self._next = 0                                   # collectives are issued strictly in bucket order on every rank
         for b in self.buckets:
             b.pending, b.work, b.ready = len(b.params), None, False
 
@@ -150,7 +152,7 @@ class GradBucketReducer:
             self._reattach(b)                      # autograd swapped the tensor (out-of-place accumulation)
         b.pending -= 1
         if b.pending == 0 and self.overlap and self.world > 1:
-            self._launch(b)
+            self._launch_ready()
 
     def _view_ptr(self, b, p):
         off = 0
@@ -159,6 +161,14 @@ class GradBucketReducer:
                 return b.flat.data_ptr() + off * 4
             off += q.numel()
         raise KeyError
+
+    def _launch_ready(self) -> None:
+        """Launch every bucket that is complete AND whose predecessors have been launched.  The order in which
+        gradients become ready can differ between ranks (style mixing changes the generator's graph per rank), but
+        collectives must be issued in one order everywhere."""
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b: _Bucket) -> None:
         b.ready = True
@@ -174,9 +184,9 @@ class GradBucketReducer:
         self._armed = False
         if self.world == 1:
             return
-        for b in self.buckets:
-            if not b.ready:
-                self._launch(b)
+        while self._next < len(self.buckets):             # whatever is left (incl. buckets with unused parameters)
+            self._launch(self.buckets[self._next])
+            self._next += 1
         for b in self.buckets:
             b.work.wait()
         if self.comm_stream is not None:

@@ -95,6 +95,18 @@ def _reducer_worker(rank, world, port, out):
         total = red.clip_(0.5)
         norm_after = torch.sqrt(sum(p.grad.square().sum() for p in params))
         assert norm_after <= 0.5 + 1e-4 and total > 0
+    # gradients arriving in a different order on each rank must not reorder the collectives
+    local = [t.clone() for t in torch.autograd.grad(model(x).square().sum(), params)]
+    red.zero_grad(); red.arm()
+    order = list(range(len(params))) if rank == 0 else list(reversed(range(len(params))))
+    for i in order:
+        params[i].grad.copy_(local[i])
+        red._on_grad(params[i])
+    red.finish()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    for i, p in enumerate(params):
+        assert torch.allclose(p.grad, sum(g[i] for g in gathered) / world, atol=1e-6), (rank, "order", i)
     assert model.unused.grad is None
     if rank == 0:
         out.put("ok")

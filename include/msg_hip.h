@@ -142,6 +142,20 @@ int msg_modulate_backward(const float* gwk, const float* W, const float* s, cons
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
 int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);
 
+/* -------------------------------------------------------------------------
+ * Equalized-lr fully connected layers with few rows (mapping network, style affines, classification head), fp32,
+ * dense row-major operands.  Replaces F.linear(input, weight * scale, bias * scale_bias) of
+ * multi_stylegan/equalized_layer.py (EqualizedLinear.forward) and its autograd derivatives; one launch per call.
+ *   msg_linear_fprop   y[M][N]  = gain * x[M][K] . w[N][K]^T + bias_gain * bias[N]   (bias may be NULL)
+ *   msg_linear_dgrad   gx[M][K] = gain * gy[M][N] . w[N][K]
+ *   msg_linear_wgrad   gw[N][K] = gain * gy[M][N]^T . x[M][K];  gb[N] = bias_gain * sum_m gy[m][n]  (gb may be NULL)
+ * ------------------------------------------------------------------------- */
+int msg_linear_fprop(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                     float gain, float bias_gain, void* stream);
+int msg_linear_dgrad(const float* gy, const float* w, float* gx, int M, int N, int K, float gain, void* stream);
+int msg_linear_wgrad(const float* gy, const float* x, float* gw, float* gb, int M, int N, int K,
+                     float gain, float bias_gain, void* stream);
+
 /* Which kernel msg_conv2d_fprop launches for a problem (no launch): 2 = 256x256 ping-pong, 1 = 128x128 with LDS-DMA
  * staging, 0 = 128x128 with register staging.  Used by bench.py to label per-kernel timings. */
 int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,

@@ -33,6 +33,9 @@ _SIGNATURES = {
     "msg_modulate_backward": (_I, [_P] * 6 + [_I] * 6 + [_F, _P]),
     "msg_scaled_add": (_I, [_P, _P, _P, _I, _L, _F, _F, _P]),
     "msg_conv2d_fprop_plan": (_I, [_I] * 11 + [_L]),
+    "msg_linear_fprop": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
+    "msg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "msg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
 }
 
 

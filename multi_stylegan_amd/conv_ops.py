@@ -16,6 +16,7 @@ into the kernels' K-contiguous form; activations are channels-last with a 16-byt
 There is no CPU or library fallback.
 """
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -130,6 +131,7 @@ def _cached(w, tag, dtype, wscale, build):
 
 
 # --------------------------------------------------------------------------------------------------- raw launches
+_CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
 def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real):
     dev = _lib.require_gpu(x, wk, bias)
     xv, cx = _nhwc_view(x)
@@ -146,6 +148,9 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
     if _lib.kernel_clock.enabled:                       # label the timing with the kernel the library will pick
         plan = _lib.lib().msg_conv2d_fprop_plan(_lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, kh, kw, wstride)
         key = ("conv_fprop_reg", "conv_fprop_dma", "conv_fprop_pp")[plan]
+        if _CLOCK_SHAPES:
+            key += f"|B{b} {ih}x{iw}->{oh}x{ow} {c_real}->{n} {kh}x{kw} s{stride} up{in_up}" \
+                   f"{' ps' if pixel_shuffle else ''}{' per-sample' if per_sample else ''}|"
     with torch.cuda.device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_fprop(
             xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow,
@@ -177,7 +182,11 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
         while b * k_chunks > 65535:
             k_chunks -= 1
     flops = 2.0 * b * oh * ow * o * i * taps
-    with torch.cuda.device(dev), _lib.kernel_clock.span(f"conv_wgrad/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
+    key = "conv_wgrad"
+    if _CLOCK_SHAPES and _lib.kernel_clock.enabled:
+        key += f"|B{b} {ih}x{iw}->{oh}x{ow} {i}->{o} {kh}x{kw} s{stride}{' ps' if pixel_shuffle else ''}" \
+               f"{' per-sample' if per_sample else f' chunks{k_chunks}'}|"
+    with torch.cuda.device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_wgrad(
             gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw,
             kh, kw, stride, pad, int(pixel_shuffle), int(per_sample), k_chunks, int(oi_major), float(gain),
@@ -302,10 +311,110 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):
     return _ConvF.apply(x, weight, None if bias is None else bias.float(), g)
 
 
+_LINEAR_MAX_ROWS = 256        # above this the batch rows are worth an MFMA tile: the conv path takes over
+
+
+def _lin_call(name, flops, *args):
+    dev = args[0].device
+    with torch.cuda.device(dev), _lib.kernel_clock.span(f"{name}/f32", flops):
+        code = getattr(_lib.lib(), f"msg_{name}")(*[a.data_ptr() if isinstance(a, torch.Tensor) else
+                                                   (0 if a is None else a) for a in args], _lib.stream_of(dev))
+    _lib.check(code, f"msg_{name}")
+
+
+def _dense32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.MsgHipError("the few-row linear kernels are fp32 (mapping network / style affines / heads)")
+    return [None if t is None else t.contiguous() for t in ts]
+
+
+class _LinF(Function):
+    """y = gain * x @ w^T (+ bias).  csrc/linear.hip; derivatives are _LinD / _LinG (closed family, any order)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gain):
+        _lib.require_gpu(x, w, bias)
+        x, w, bias = _dense32(x, w, bias)
+        (m, k), n = x.shape, w.shape[0]
+        y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        _lin_call("linear_fprop", 2.0 * m * n * k, x, w, bias, y, m, n, k, float(gain), 1.0)
+        ctx.save_for_backward(x, w)
+        ctx.gain, ctx.has_bias = float(gain), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        gx = _LinD.apply(gy, w, ctx.gain) if need_x else None
+        gw = gb = None
+        if need_w and need_b and ctx.has_bias and not torch.is_grad_enabled():
+            (gy_,) = _dense32(gy)                     # first-order step: weight and bias gradient in one launch
+            (m, n), k = gy_.shape, x.shape[1]
+            gw = torch.empty((n, k), dtype=torch.float32, device=x.device)
+            gb = torch.empty((n,), dtype=torch.float32, device=x.device)
+            _lin_call("linear_wgrad", 2.0 * m * n * k, gy_, x, gw, gb, m, n, k, ctx.gain, 1.0)
+        else:
+            if need_w:
+                gw = _LinG.apply(gy, x, ctx.gain)
+            if need_b and ctx.has_bias:
+                gb = gy.sum(dim=0)
+        return gx, gw, gb, None
+
+
+class _LinD(Function):
+    """gx = gain * gy @ w."""
+
+    @staticmethod
+    def forward(ctx, gy, w, gain):
+        _lib.require_gpu(gy, w)
+        gy, w = _dense32(gy, w)
+        (m, n), k = gy.shape, w.shape[1]
+        gx = torch.empty((m, k), dtype=torch.float32, device=gy.device)
+        _lin_call("linear_dgrad", 2.0 * m * n * k, gy, w, gx, m, n, k, float(gain))
+        ctx.save_for_backward(gy, w)
+        ctx.gain = float(gain)
+        return gx
+
+    @staticmethod
+    def backward(ctx, g):
+        gy, w = ctx.saved_tensors
+        d_gy = _LinF.apply(g, w, None, ctx.gain) if ctx.needs_input_grad[0] else None
+        d_w = _LinG.apply(gy, g, ctx.gain) if ctx.needs_input_grad[1] else None
+        return d_gy, d_w, None
+
+
+class _LinG(Function):
+    """gw = gain * gy^T @ x."""
+
+    @staticmethod
+    def forward(ctx, gy, x, gain):
+        _lib.require_gpu(gy, x)
+        gy, x = _dense32(gy, x)
+        (m, n), k = gy.shape, x.shape[1]
+        gw = torch.empty((n, k), dtype=torch.float32, device=gy.device)
+        _lin_call("linear_wgrad", 2.0 * m * n * k, gy, x, gw, None, m, n, k, float(gain), 1.0)
+        ctx.save_for_backward(gy, x)
+        ctx.gain = float(gain)
+        return gw
+
+    @staticmethod
+    def backward(ctx, g):
+        gy, x = ctx.saved_tensors
+        d_gy = _LinF.apply(x, g, None, ctx.gain) if ctx.needs_input_grad[0] else None
+        d_x = _LinD.apply(gy, g, ctx.gain) if ctx.needs_input_grad[1] else None
+        return d_gy, d_x, None
+
+
 def linear(x, weight, bias=None, wscale=1.0):
-    """x [B,I] @ (wscale * weight[O,I])^T (+ bias): the same contraction with the batch rows as 'pixels' of one sample."""
+    """x [B,I] @ (wscale * weight[O,I])^T (+ bias).  Few fp32 rows (the mapping network, the style affines, the
+    classification head) go to the one-launch kernels of csrc/linear.hip; anything else is the same contraction as a
+    1x1 convolution with the batch rows as 'pixels' of one sample."""
     b, i = x.shape
     o = weight.shape[0]
+    if x.dtype == torch.float32 and weight.dtype == torch.float32 and b <= _LINEAR_MAX_ROWS:
+        return _LinF.apply(x, weight, None if bias is None else bias.float(), float(wscale))
     g = Geometry("conv", 1, 1, 1, 0, (b, 1), False, wscale)
     y = _ConvF.apply(x.reshape(1, b, 1, i).permute(0, 3, 1, 2), weight, None if bias is None else bias.float(), g)
     return y.permute(0, 2, 3, 1).reshape(b, o)

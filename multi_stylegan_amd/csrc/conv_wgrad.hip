@@ -29,6 +29,7 @@ struct WgradParams {
     int B, IH, IW, Cx, I, OH, OW, ldgy, O;
     int kh, kw, stride, pad, pixel_shuffle;
     int per_sample, chunks_per_sample, pix_per_chunk, atomic;
+    int fold;                                         // 1: shared weights, K runs over the concatenated pixels of ALL samples
     int o_tiles, i_tiles, ldgw;                       // ldgw = padded I of the gradient buffer
     int oi_major;                                     // 1: gw[o][i][tap] (the parameter's own layout), 0: gw[o][tap][ldgw]
     float gain;                                       // multiplies the result (equalized-lr scale of the layer)
@@ -43,7 +44,15 @@ template <typename T> __device__ __forceinline__ int wg_off(int r, int ch) {
     return r * ROW + (((ch << 4) + ((r & 3) << 6)) & (ROW - 1));
 }
 
-template <typename T, bool DMA>
+// UNI ("uniform rows"): when a K-step of KP pixels never straddles output rows unevenly (OW divides KP or KP divides
+// OW -- every power-of-two map), each thread's pixel sits at a FIXED (row, column) displacement from the K-step's first
+// pixel.  Addresses then split into a per-thread constant byte offset and a wave-uniform part that lives in SGPRs, and
+// the loads become buffer loads (descriptor = sample base, voffset = constant, soffset = scalar): out-of-image rows
+// get an out-of-range voffset, for which the hardware returns zeros.  This removes ~170 of the ~200 VALU instructions
+// per K-step that the generic incremental addressing costs (the kernel was VALU-bound: 12 VALU per MFMA).
+constexpr int BUF_OOB = (int)0x80000000;             // voffset >= num_records: the buffer load returns 0
+
+template <typename T, bool DMA, bool UNI>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                             float* __restrict__ gw, WgradParams p) {
     constexpr int VEC = 16 / sizeof(T);
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     const int b = z / p.chunks_per_sample, chunk = z - b * p.chunks_per_sample;
     const int npix = p.OH * p.OW;
     const int pix0 = chunk * p.pix_per_chunk;
-    const int pix1 = min(npix, pix0 + p.pix_per_chunk);
+    const int pix1 = min(p.fold ? p.B * npix : npix, pix0 + p.pix_per_chunk);
     const int n_iters = (pix1 - pix0 + KP - 1) / KP;
 
     // ---- staging: thread moves 16-B chunk `ch` of pixel rows r0 + RSTEP*j (j = 0..NLD-1) of both operands.  Pixel
@@ -77,7 +86,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     const int ch_phys = DMA ? (lane % CPR) : (tid % CPR);
     const int ch = DMA ? ((ch_phys - 4 * (r0 & 3)) & (CPR - 1)) : ch_phys;   // (row & 3) is the same for all j: steps of 4*RPW rows
     const gptr_t zsrc = (gptr_t)g_wgrad_zero_page + (tid & 7) * 16;
-    const int step_h = KP / p.OW, step_w = KP % p.OW;
+    // K-step stride in (sample, row, column) units; without folding a step never leaves its sample
+    const int step_b = p.fold ? KP / npix : 0;
+    const int step_rem = KP - step_b * npix;
+    const int step_h = step_rem / p.OW, step_w = step_rem % p.OW;
     const int gyw = p.pixel_shuffle ? 2 * p.OW : p.OW, gyh = p.pixel_shuffle ? 2 * p.OH : p.OH;
     const int oc = o0 + ch * VEC, ic = i0 + ch * VEC;
     const bool oc_ok = oc + VEC <= p.ldgy, ic_ok = ic + VEC <= p.Cx;
@@ -94,6 +106,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < NLD; ++j) st_off[j] = wg_off<T>(r0 + (DMA ? 4 * RPW : RSTEP) * j, ch);
 
+    // ---- UNI staging state: thread constants (VGPR) + wave-uniform cursor (SGPR)
+    const int u_gs = p.pixel_shuffle ? 2 : 1, u_gkh = p.pixel_shuffle ? kh_ : 0, u_gkw = p.pixel_shuffle ? kw_ : 0;
+    const int u_xs = p.pixel_shuffle ? 1 : p.stride;
+    const int u_xkh = p.pixel_shuffle ? 0 : kh_ - p.pad, u_xkw = p.pixel_shuffle ? 0 : kw_ - p.pad;
+    const int u_L = p.ldgy * (int)sizeof(T), u_C = p.Cx * (int)sizeof(T);
+    __amdgpu_buffer_rsrc_t rs_gy, rs_x;
+    int voff_gy[NLD], voff_x[NLD], xh_c[NLD], xw_c[NLD];
+    int row_s = 0, col_s = 0, b_s = 0, pix_s = pix0;
+    const int gy_sample = gyh * gyw * u_L, x_sample = p.IH * p.IW * u_C;      // bytes (host guarantees < 2^31)
+    if constexpr (UNI) {
+        const char* gbase = (const char*)gy + (long long)b * gyh * gyw * u_L;
+        const char* xbase = (const char*)x + (long long)b * p.IH * p.IW * u_C + ((long long)u_xkh * p.IW + u_xkw) * u_C;
+        rs_gy = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, BUF_OOB, 0x00020000);
+        rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, BUF_OOB, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int r = r0 + RSTEP * j;
+            const int db = p.fold ? r / npix : 0;       // (only maps smaller than a K-step put several samples in one)
+            const int rr = r - db * npix;
+            const int dh = rr / p.OW, dw = rr - dh * p.OW;
+            voff_gy[j] = oc_ok ? db * gy_sample + (dh * u_gs * gyw + dw * u_gs) * u_L + oc * (int)sizeof(T) : BUF_OOB;
+            voff_x[j] = ic_ok ? db * x_sample + (dh * u_xs * p.IW + dw * u_xs) * u_C + ic * (int)sizeof(T) : BUF_OOB;
+            xh_c[j] = dh * u_xs;
+            xw_c[j] = dw * u_xs;
+        }
+        b_s = p.fold ? pix0 / npix : 0;
+        const int in_sample = pix0 - b_s * npix;
+        row_s = in_sample / p.OW;
+        col_s = in_sample - row_s * p.OW;
+    }
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -105,6 +148,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     u32x4 ra[NLD], rb[NLD];
     int dma_stage = 0;
     auto load_next = [&]() __attribute__((always_inline)) {     // global -> registers for the next K-step
+        if constexpr (UNI && !DMA) {
+            const int rem = pix1 - pix_s;
+            // (soffset is an unsigned 32-bit byte offset: the host checked that the whole tensor fits)
+            const int so_gy = (int)((unsigned)b_s * (unsigned)gy_sample +
+                                    (unsigned)(((row_s * u_gs + u_gkh) * gyw + col_s * u_gs + u_gkw) * u_L));
+            const int so_x = (int)((unsigned)b_s * (unsigned)x_sample + (unsigned)((row_s * u_xs * p.IW + col_s * u_xs) * u_C));
+            const int xh_s = row_s * u_xs + u_xkh, xw_s = col_s * u_xs + u_xkw;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const bool pok = r0 + RSTEP * j < rem;
+                const bool xok = pok & ((unsigned)(xh_s + xh_c[j]) < (unsigned)p.IH) &
+                                 ((unsigned)(xw_s + xw_c[j]) < (unsigned)p.IW);
+                ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gy, pok ? voff_gy[j] : BUF_OOB, so_gy, 0);
+                rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[j] : BUF_OOB, so_x, 0);
+            }
+            pix_s += KP;
+            b_s += step_b;
+            row_s += step_h;
+            col_s += step_w;
+            if (col_s >= p.OW) { col_s -= p.OW; ++row_s; }
+            if (p.fold && row_s >= p.OH) { row_s -= p.OH; ++b_s; }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const bool pok = pix[j] < pix1;
@@ -274,27 +340,51 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     const int kp = dtype == MSG_BF16 ? 64 : 32;
     p.pix_per_chunk = (((npix + k_chunks - 1) / k_chunks + kp - 1) / kp) * kp;
     p.atomic = !(per_sample && k_chunks == 1);
+    long long zs = (long long)B * k_chunks;
+    // uniform-row addressing: K-steps map onto whole rows / whole row fragments and per-sample tensors fit 31-bit offsets
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("MSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+    const long long gy_bytes = (long long)(pixel_shuffle ? 4 : 1) * OH * OW * ldgy * esz;
+    const long long x_bytes = (long long)IH * IW * Cx * esz;
+    const bool uni = variant != 2 && variant != 1 && (kp % OW == 0 || OW % kp == 0) && gy_bytes < (1ll << 31) &&
+                     x_bytes < (1ll << 31);
+    // shared weights: fold the batch into K (one sweep over the concatenated pixels of all samples), so that small maps
+    // still give every workgroup a long K loop and the float atomics shrink from B*chunks to `chunks` per element
+    if (uni && !per_sample && (npix % kp == 0 || kp % npix == 0) && B * gy_bytes < (1ll << 32) && B * x_bytes < (1ll << 32) &&
+        (long long)B * npix < (1ll << 31) && variant != 3) {
+        const long long steps = ((long long)B * npix + kp - 1) / kp;
+        const long long tiles = (long long)((O + WT - 1) / WT) * ((I + WT - 1) / WT) * kh * kw;
+        long long chunks = (1536 + tiles - 1) / tiles;
+        if (chunks > steps / 4) chunks = steps / 4;
+        if (chunks < 1) chunks = 1;
+        if (chunks > 65535) chunks = 65535;
+        p.fold = 1;
+        p.chunks_per_sample = (int)chunks;               // (z = chunk; the sample index derived from it is always 0)
+        p.pix_per_chunk = (int)(((steps + chunks - 1) / chunks) * kp);
+        zs = ((long long)B * npix + p.pix_per_chunk - 1) / p.pix_per_chunk;
+        p.chunks_per_sample = (int)zs;
+        p.atomic = zs > 1;
+    }
     p.o_tiles = (O + WT - 1) / WT;
     p.i_tiles = (I + WT - 1) / WT;
     p.ldgw = ldgw;
     p.gw_zstride = oi_major ? (long long)O * I * kh * kw : (long long)O * kh * kw * ldgw;
     p.oi_major = oi_major;
     p.gain = gain;
-    const long long zs = (long long)B * k_chunks;
     if (zs > 65535 || kh * kw > 65535) return MSG_EUNSUPPORTED;
     dim3 grid(p.o_tiles * p.i_tiles, kh * kw, (unsigned)zs);
     hipStream_t s = (hipStream_t)stream;
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("MSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
     // Register staging keeps two K-steps of loads in flight; measured faster here than LDS-DMA with one step in
     // flight (685 vs 608 TFLOP/s at 3x3 512->512 @256^2): both operands of this kernel stream from beyond L2.
-    const bool dma = variant == 1;                   // MSG_CONV_VARIANT=1 forces LDS-DMA staging (A/B measurements)
+    const bool dma = variant == 1;                   // MSG_CONV_VARIANT=1 forces LDS-DMA staging, 2 the generic addressing (A/B)
     if (dtype == MSG_BF16) {
-        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
     } else {
-        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
     }
     return MSG_CHECK_LAUNCH();
 }

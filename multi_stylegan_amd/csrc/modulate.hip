@@ -49,40 +49,56 @@ extern "C" int msg_demod_coeff(const float* W, const float* s, float* d, int B, 
 }
 
 // base [R][T][C] fp32; rowscale [B][R] (or NULL = 1); colscale [B][C] (or NULL = 1); out [B][R][T][Ck] of type TO.
-// grid = (row r, sample b): the row scale is one scalar per workgroup, the column scales one vector per lane, and
-// no index is ever divided.
+// grid = (row r, group of BG samples): a thread owns up to ITEMS (tap, 16-B column vector) cells of the row, reads
+// their fp32 base values ONCE into registers and then emits the BG per-sample copies (row scale = one scalar per
+// sample, column scales = one vector per lane and sample); no index is ever divided.  The base row is therefore read
+// B/BG times instead of B times and every workgroup streams BG * T * Ck elements.
+constexpr int SRC_ITEMS = 5;
 template <typename TO>
 __global__ __launch_bounds__(256) void scale_rows_cols_kernel(const float* __restrict__ base,
                                                               const float* __restrict__ rowscale,
                                                               const float* __restrict__ colscale, TO* __restrict__ out,
-                                                              int R, int T, int C, int Ck, float gain) {
+                                                              int B, int BG, int R, int T, int C, int Ck, float gain) {
     using V = Vec16<TO>;
     constexpr int VEC = V::N;
-    const int r = blockIdx.x, b = blockIdx.y;
+    const int r = blockIdx.x, b0 = blockIdx.y * BG, b1 = min(B, b0 + BG);
     const int cvecs = Ck / VEC;
-    const float rs = gain * (rowscale ? rowscale[(size_t)b * R + r] : 1.f);
     const float* src_row = base + (size_t)r * T * C;
-    TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
-    const float* cs = colscale ? colscale + (size_t)b * C : nullptr;
+    const int tstep = 256 / cvecs > 0 ? 256 / cvecs : 1;
     for (int cv = threadIdx.x % cvecs; cv < cvecs; cv += 256) {       // (cvecs <= 256 in practice: one pass)
         const int c0 = cv * VEC;
-        float sc[VEC];
+        const int t0 = threadIdx.x / cvecs;
+        for (int tb = t0; tb < T; tb += tstep * SRC_ITEMS) {           // (T <= tstep * SRC_ITEMS in practice: one pass)
+            float f[SRC_ITEMS][VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) sc[e] = (c0 + e < C) ? rs * (cs ? cs[c0 + e] : 1.f) : 0.f;
-        for (int t = threadIdx.x / cvecs; t < T; t += (256 / cvecs > 0 ? 256 / cvecs : 1)) {
-            const float* src = src_row + (size_t)t * C + c0;
-            float f[VEC];
+            for (int k = 0; k < SRC_ITEMS; ++k) {
+                const int t = tb + k * tstep;
+                const float* src = src_row + (size_t)t * C + c0;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] = (c0 + e < C) ? src[e] * sc[e] : 0.f;
-            V o;
-            if constexpr (VEC == 4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o.set(e, f[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+                for (int e = 0; e < VEC; ++e) f[k][e] = (t < T && c0 + e < C) ? src[e] : 0.f;
             }
-            *reinterpret_cast<uint4*>(dst_row + (size_t)t * Ck + c0) = o.raw;
+            for (int b = b0; b < b1; ++b) {
+                const float rs = gain * (rowscale ? rowscale[(size_t)b * R + r] : 1.f);
+                const float* cs = colscale ? colscale + (size_t)b * C : nullptr;
+                float sc[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sc[e] = (c0 + e < C) ? rs * (cs ? cs[c0 + e] : 1.f) : 0.f;
+                TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
+#pragma unroll
+                for (int k = 0; k < SRC_ITEMS; ++k) {
+                    const int t = tb + k * tstep;
+                    if (t >= T) break;
+                    V o;
+                    if constexpr (VEC == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.set(e, f[k][e] * sc[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.set2(e, f[k][2 * e] * sc[2 * e], f[k][2 * e + 1] * sc[2 * e + 1]);
+                    }
+                    *reinterpret_cast<uint4*>(dst_row + (size_t)t * Ck + c0) = o.raw;
+                }
+            }
         }
     }
 }
@@ -95,13 +111,16 @@ extern "C" int msg_scale_rows_cols(const float* base, const float* rowscale, con
     const int vec = dtype == MSG_BF16 ? 8 : 4;
     if (Ck % vec || ((uintptr_t)out & 15u) || B > 65535) return MSG_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(R, B);
+    // samples per workgroup: as many as keep >= ~2048 workgroups in flight (256 CUs x 8), at most 8
+    int bg = 1;
+    while (bg < 8 && bg * 2 <= B && (long long)R * ((B + 2 * bg - 1) / (2 * bg)) >= 2048) bg *= 2;
+    dim3 grid(R, (B + bg - 1) / bg);
     if (dtype == MSG_BF16)
         hipLaunchKernelGGL((scale_rows_cols_kernel<bf16_t>), grid, dim3(256), 0, s, base, rowscale, colscale,
-                           (bf16_t*)out, R, T, C, Ck, gain);
+                           (bf16_t*)out, B, bg, R, T, C, Ck, gain);
     else
         hipLaunchKernelGGL((scale_rows_cols_kernel<float>), grid, dim3(256), 0, s, base, rowscale, colscale,
-                           (float*)out, R, T, C, Ck, gain);
+                           (float*)out, B, bg, R, T, C, Ck, gain);
     return MSG_CHECK_LAUNCH();
 }
 

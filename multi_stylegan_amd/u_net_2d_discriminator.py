@@ -95,7 +95,8 @@ class NonLocalBlock(nn.Module):
         theta = self.theta(input).flatten(start_dim=2)
         phi = F.max_pool2d(self.phi(input), kernel_size=2, stride=2).flatten(start_dim=2)
         g = F.max_pool2d(self.g(input), kernel_size=2, stride=2).flatten(start_dim=2)
-        beta = torch.softmax(torch.bmm(theta.transpose(1, 2), phi).float(), dim=-1).to(input.dtype)
+        # softmax accumulates in fp32 whatever the storage type: no fp32 copy of the [B, HW, HW/4] map is made
+        beta = torch.softmax(torch.bmm(theta.transpose(1, 2), phi), dim=-1)
         attended = torch.bmm(g, beta.transpose(1, 2)).view(bsz, -1, height, width)
         output = self.o(conv_ops.to_compute_layout(attended))
         return scaled_add(self.gamma.to(input.dtype) * output, self.residual_mapping(input), 1.0 / math.sqrt(2))

@@ -23,6 +23,15 @@ CASES = [  # name, kind, B, I, O, H, W, k, stride, pad
     ("3x3_multi_tile", "conv", 1, 72, 136, 20, 20, 3, 1, 1),
     ("up2", "up2", 2, 16, 24, 5, 6, 2, 2, 0),
     ("up2_multi_tile", "up2", 1, 72, 40, 12, 12, 2, 2, 0),
+    # power-of-two maps: the weight-gradient kernel's uniform-row buffer addressing, with the batch folded into K for
+    # shared weights (maps smaller than / equal to / larger than one K-step, several K chunks, strided, up2)
+    ("pow2_4x4_b5", "conv", 5, 16, 8, 4, 4, 3, 1, 1),
+    ("pow2_8x8_b3", "conv", 3, 8, 16, 8, 8, 3, 1, 1),
+    ("pow2_16x16_b3", "conv", 3, 16, 8, 16, 16, 3, 1, 1),
+    ("pow2_64x64_b2", "conv", 2, 8, 8, 64, 64, 3, 1, 1),
+    ("pow2_128w_1x1", "conv", 2, 16, 8, 4, 128, 1, 1, 0),
+    ("pow2_s2_to_16", "conv", 2, 8, 8, 33, 33, 3, 2, 0),
+    ("pow2_up2_8x8", "up2", 3, 8, 16, 8, 8, 2, 2, 0),
 ]
 
 
@@ -131,6 +140,45 @@ def test_conv_full_size_properties():
     # against the library conv on the same bf16 data
     ref = torch.nn.functional.conv2d(x.float(), w.detach(), padding=1)
     assert rel_err(y.float(), ref) < 2e-2
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 512, 512), (5, 7, 70), (33, 20, 1100), (1, 1, 3), (64, 129, 257)])
+def test_few_row_linear_family(m, n, k):
+    """csrc/linear.hip: forward, both gradients, the fused bias gradient and the second-order terms R1 / path length
+    need, against float64 autograd of F.linear(x, w * scale, b)."""
+    from multi_stylegan_amd import conv_ops
+    g = torch.Generator().manual_seed(m * 1000 + n)
+    scale = 0.37
+    x = torch.randn(m, k, generator=g).double().requires_grad_(True)
+    w = torch.randn(n, k, generator=g).double().requires_grad_(True)
+    b = torch.randn(n, generator=g).double().requires_grad_(True)
+    y = F.linear(x, w * scale, b)
+    gy = torch.randn(m, n, generator=g).double()
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), gy, create_graph=True)
+    u, v = torch.randn(m, k, generator=g).double(), torch.randn(n, k, generator=g).double()
+    ggw_r, = torch.autograd.grad(gx, w, u, retain_graph=True)             # d<gx,u>/dw
+    ggx_r, = torch.autograd.grad(gw, x, v, retain_graph=True)             # d<gw,v>/dx
+    xd, wd, bd = [t.detach().to(DEV, torch.float32).requires_grad_(True) for t in (x, w, b)]
+    yd = conv_ops.linear(xd, wd, bd, wscale=scale)
+    assert yd.dtype == torch.float32 and yd.shape == (m, n)
+    gyd = gy.to(DEV, torch.float32)
+    gxd, gwd, gbd = torch.autograd.grad(yd, (xd, wd, bd), gyd, create_graph=True)
+    ggw, = torch.autograd.grad(gxd, wd, u.to(DEV, torch.float32), retain_graph=True)
+    ggx, = torch.autograd.grad(gwd, xd, v.to(DEV, torch.float32), retain_graph=True)
+    tol = 2e-5
+    for name, a, r in [("y", yd, y), ("gx", gxd, gx), ("gw", gwd, gw), ("gb", gbd, gb), ("ggw", ggw, ggw_r),
+                       ("ggx", ggx, ggx_r)]:
+        assert rel_err(a, r) < tol, name
+    # first-order step (no graph): weight and bias gradient come from ONE launch
+    yd2 = conv_ops.linear(xd, wd, bd, wscale=scale)
+    g1 = torch.autograd.grad(yd2, (xd, wd, bd), gyd)
+    for a, r in zip(g1, (gx, gw, gb)):
+        assert rel_err(a, r) < tol
+    # empty batch
+    e = conv_ops.linear(torch.zeros(0, k, device=DEV, requires_grad=True), wd, bd)
+    assert e.shape == (0, n)
+    gwe, = torch.autograd.grad(e.sum(), wd)
+    assert gwe.abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -108,9 +108,42 @@ def bench_conv(args):
             del x, w, wk, y, gy
 
 
+def bench_mod(args):
+    """Per-sample weight materialisation (msg_scale_rows_cols): algorithmic bytes = fp32 base once + B outputs."""
+    from multi_stylegan_amd import conv_ops
+    for (o, i, taps) in [(512, 512, 9), (256, 256, 9), (128, 128, 9), (512, 512, 1), (64, 64, 9)]:
+        name = f"O{o} I{i} T{taps}"
+        if args.only and args.only not in name:
+            continue
+        base = torch.randn(o, taps, i, device=DEV)
+        rs, cs = torch.rand(args.batch, o, device=DEV), torch.rand(args.batch, i, device=DEV)
+        out = torch.empty(args.batch, o, taps, i, device=DEV, dtype=torch.float32 if args.f32 else torch.bfloat16)
+        t = timeit(lambda: conv_ops._scale_rows_cols(base, rs, cs, out, 0.5), args.reps)
+        nbytes = base.numel() * 4 + out.numel() * out.element_size()
+        print(f"modw  {name:24s} {t * 1e6:9.1f} us {nbytes / t / 1e9:8.1f} GB/s", flush=True)
+
+
+def bench_lin(args):
+    """Few-row fp32 linear family (csrc/linear.hip); 50 back-to-back launches per timing so launch gaps do not count."""
+    from multi_stylegan_amd import conv_ops
+    for (m, n, k) in [(16, 512, 512), (32, 512, 512), (16, 128, 768), (16, 1024, 512)]:
+        x, w = torch.randn(m, k, device=DEV), torch.randn(n, k, device=DEV)
+        gy, b = torch.randn(m, n, device=DEV), torch.randn(n, device=DEV)
+        y, gx, gw, gb = torch.empty(m, n, device=DEV), torch.empty(m, k, device=DEV), torch.empty(n, k, device=DEV), torch.empty(n, device=DEV)
+        calls = {"fprop": lambda: conv_ops._lin_call("linear_fprop", 0, x, w, b, y, m, n, k, 1.0, 1.0),
+                 "dgrad": lambda: conv_ops._lin_call("linear_dgrad", 0, gy, w, gx, m, n, k, 1.0),
+                 "wgrad": lambda: conv_ops._lin_call("linear_wgrad", 0, gy, x, gw, gb, m, n, k, 1.0, 1.0)}
+        for name, fn in calls.items():
+            def many():
+                for _ in range(50):
+                    fn()
+            t = timeit(many, max(3, args.reps // 3)) / 50
+            print(f"linear {name} M{m} N{n} K{k}  {t * 1e6:7.2f} us/launch", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", nargs="+", choices=["fir", "act", "conv", "wgrad"])
+    ap.add_argument("what", nargs="+", choices=["fir", "act", "conv", "wgrad", "mod", "lin"])
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--f32", action="store_true")
@@ -122,3 +155,7 @@ if __name__ == "__main__":
         bench_act(args)
     if "conv" in args.what or "wgrad" in args.what:
         bench_conv(args)
+    if "mod" in args.what:
+        bench_mod(args)
+    if "lin" in args.what:
+        bench_lin(args)

@@ -34,13 +34,59 @@ def _round_up(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+def _padded_nhwc(b, c, h, w, dtype, device):
+    """Logical [b, c, h, w] view of a fresh NHWC buffer whose channel stride is a whole number of 16-byte vectors (pad
+    channels zeroed): what every kernel launch accepts as is."""
+    cx = _round_up(c, _vec(dtype))
+    buf = torch.empty((b, h, w, cx), dtype=dtype, device=device)
+    if cx != c:
+        buf[..., c:].zero_()
+    return buf.permute(0, 3, 1, 2)[:, :c]
+
+
+class _CatChannels(Function):
+    """Channel concatenation written straight into a padded channels-last buffer (one strided copy per piece, no
+    re-padding at the launches that read it); the backward hands out channel-slice VIEWS of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        t0 = tensors[0]
+        ctx.splits = [t.shape[1] for t in tensors]
+        out = _padded_nhwc(t0.shape[0], sum(ctx.splits), t0.shape[2], t0.shape[3], t0.dtype, t0.device)
+        off = 0
+        for t in tensors:
+            out[:, off:off + t.shape[1]].copy_(t)
+            off += t.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for i, c in enumerate(ctx.splits):
+            outs.append(g[:, off:off + c] if ctx.needs_input_grad[i] else None)
+            off += c
+        return tuple(outs)
+
+
 def to_compute_layout(x: torch.Tensor, dtype=None) -> torch.Tensor:
-    """Feature maps are kept channels-last (NHWC in HBM, NCHW logical shape)."""
+    """Feature maps are kept channels-last (NHWC in HBM, NCHW logical shape).  Channel counts that are not a whole
+    number of 16-byte vectors (the 6-channel image pair) are padded HERE, once, instead of at every launch that reads
+    the tensor (forward, weight gradient, second-order terms)."""
     if dtype is not None and x.dtype != dtype:
         x = x.to(dtype)
     if x.ndim == 4 and x.shape[1] > 1:
+        if x.is_cuda and x.shape[1] % _vec(x.dtype):
+            return _CatChannels.apply(x)
         return x.contiguous(memory_format=torch.channels_last)
     return x.contiguous()
+
+
+def cat_channels(tensors) -> torch.Tensor:
+    """torch.cat(tensors, dim=1) in the compute layout."""
+    tensors = list(tensors)
+    if tensors[0].is_cuda and all(t.dtype == tensors[0].dtype for t in tensors):
+        return _CatChannels.apply(*tensors)
+    return to_compute_layout(torch.cat(tensors, dim=1))
 
 
 def _nhwc_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
@@ -95,6 +141,43 @@ def _relay_dgrad(w: torch.Tensor, dtype, flip: bool) -> Tuple[torch.Tensor, int]
     return out, ok
 
 
+def _s2_plan(k: int, pad: int):
+    """Stride-2 data gradient as a stride-1 gather over gy, one sub-filter per output parity (1-D plan).
+    gx[2c + ph] = sum_u gy[c + e - u] * w[t0 + 2u]  with t0 = (ph + pad) % 2, e = (ph + pad - t0) / 2.
+    -> (taps U, pad', table[ph][tau] = forward tap index or -1): gy index = c + tau - pad'."""
+    offs = {}
+    for ph in (0, 1):
+        t0 = (ph + pad) % 2
+        e = (ph + pad - t0) // 2
+        for u in range((k - t0 + 1) // 2):
+            offs[(ph, e - u)] = t0 + 2 * u
+    dmin = min(d for _, d in offs)
+    dmax = max(d for _, d in offs)
+    taps = dmax - dmin + 1
+    table = [[offs.get((ph, tau + dmin), -1) for tau in range(taps)] for ph in (0, 1)]
+    return taps, -dmin, table
+
+
+def _relay_dgrad_s2(w: torch.Tensor, dtype, pad: int) -> Tuple[torch.Tensor, int, int, int]:
+    """[..., O, I, k, k] -> [..., 4*I, U*U, Ok]: the stride-2 data gradient as ONE stride-1 conv over gy with U x U taps
+    whose 4*I output channels are the four output parities (written pixel-shuffled by the kernel).  Compared with
+    the zero-insertion form (in_up = 2) the matrix cores skip the 3/4 of the taps that only ever meet parity holes."""
+    *lead, o, i, kh, kw = w.shape
+    assert kh == kw
+    taps, pad2, table = _s2_plan(kh, pad)
+    ok = _round_up(o, 128 // (2 if dtype == torch.bfloat16 else 4))
+    out = torch.zeros((*lead, 4, i, taps * taps, ok), dtype=dtype, device=w.device)
+    wt = w.transpose(-4, -3)                                   # [..., I, O, kh, kw]
+    for ph in (0, 1):
+        for pw in (0, 1):
+            for th in range(taps):
+                for tw in range(taps):
+                    fh, fw = table[ph][th], table[pw][tw]
+                    if fh >= 0 and fw >= 0:
+                        out[..., 2 * ph + pw, :, th * taps + tw, :o] = wt[..., fh, fw]
+    return out.reshape(*lead, 4 * i, taps * taps, ok), ok, taps, pad2
+
+
 # Re-laid copies of PARAMETERS are cached between weight updates: D runs three times and G two to three times per
 # iteration on unchanged weights.  The cache lives ON the nn.Parameter object (it dies with it and can never alias a
 # recycled address) and is validated against (a) the tensor's in-place version counter and (b) a global weight
@@ -115,7 +198,7 @@ _register_step_hook(invalidate_weight_cache)
 def _cached(w, tag, dtype, wscale, build):
     if not isinstance(w, torch.nn.Parameter):
         out = build()
-        return (out[0] * wscale, out[1]) if wscale != 1.0 else out
+        return (out[0] * wscale, *out[1:]) if wscale != 1.0 else out
     store = w.__dict__.setdefault("_msg_relay", {})
     key = (tag, dtype, wscale)
     stamp = (w._version, _WEIGHT_GENERATION[0], w.data_ptr())
@@ -125,14 +208,18 @@ def _cached(w, tag, dtype, wscale, build):
     with torch.no_grad():
         out = build()
         if wscale != 1.0:
-            out = (out[0] * wscale, out[1])
+            out = (out[0] * wscale, *out[1:])
     store[key] = (stamp, out)
     return out
 
 
 # --------------------------------------------------------------------------------------------------- raw launches
+_S2_PARITY = bool(int(os.environ.get("MSG_S2_PARITY", "1")))          # 0: zero-insertion form of the stride-2 data gradient (A/B)
 _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
-def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real):
+
+
+def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real,
+                  flops=None):
     dev = _lib.require_gpu(x, wk, bias)
     xv, cx = _nhwc_view(x)
     b, _, ih, iw = xv.shape
@@ -143,7 +230,8 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
         y, ldy = _alloc_out(b, n, oh, ow, x.dtype, dev)
     wstride = wk.stride(0) if per_sample else 0
     # algorithmic FLOPs: real channels, and only the taps a transposed strided conv can reach (1/in_up^2)
-    flops = 2.0 * b * oh * ow * n * kh * kw * c_real / (in_up * in_up)
+    if flops is None:
+        flops = 2.0 * b * oh * ow * n * kh * kw * c_real / (in_up * in_up)
     key = "conv_fprop"
     if _lib.kernel_clock.enabled:                       # label the timing with the kernel the library will pick
         plan = _lib.lib().msg_conv2d_fprop_plan(_lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, kh, kw, wstride)
@@ -234,6 +322,8 @@ def _f_raw(x, w, bias, g: Geometry):
 
 
 def _d_raw(gy, w, g: Geometry):
+    if g.kind == "conv" and g.stride == 2 and _S2_PARITY:
+        return _d_raw_s2(gy, w, g)
     i = _oi(w)[1]
     wk, ok = _cached(w, "d" + g.kind, gy.dtype, g.wscale, lambda: _relay_dgrad(w, gy.dtype, flip=g.kind != "up2"))
     if g.kind == "up2":
@@ -241,6 +331,16 @@ def _d_raw(gy, w, g: Geometry):
     pad = g.kh - 1 - g.pad
     assert g.kh == g.kw
     return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample, _oi(w)[0])
+
+
+def _d_raw_s2(gy, w, g: Geometry):
+    """Data gradient of a stride-2 conv through the parity decomposition (see _relay_dgrad_s2)."""
+    o, i = _oi(w)
+    wk, ok, taps, pad2 = _cached(w, "ds2", gy.dtype, g.wscale, lambda: _relay_dgrad_s2(w, gy.dtype, g.pad))
+    hc, wc = (g.x_hw[0] + 1) // 2, (g.x_hw[1] + 1) // 2
+    flops = 2.0 * gy.shape[0] * gy.shape[2] * gy.shape[3] * o * i * g.kh * g.kw
+    gx = _launch_fprop(gy, wk, ok, None, 4 * i, (hc, wc), taps, taps, 1, pad2, 1, True, g.per_sample, o, flops=flops)
+    return gx[:, :, :g.x_hw[0], :g.x_hw[1]]
 
 
 def _g_raw(gy, x, o, i, g: Geometry):

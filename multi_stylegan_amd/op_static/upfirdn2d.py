@@ -68,6 +68,18 @@ class UpFirDn2dBackward(Function):
         return UpFirDn2d.apply(gradgrad_input, fir, up, down, pad), None, None, None, None, None, None, None
 
 
+def _flipped(fir: torch.Tensor) -> torch.Tensor:
+    """The adjoint pass's FIR.  Cached on the (module buffer) tensor object: the flip is a 16-element kernel launched
+    ~70 times per training step otherwise."""
+    hit = fir.__dict__.get("_msg_flipped")
+    if hit is not None and hit[0] == fir._version and hit[1].device == fir.device:
+        return hit[1]
+    with torch.no_grad():
+        out = torch.flip(fir, [0, 1])
+    fir.__dict__["_msg_flipped"] = (fir._version, out)
+    return out
+
+
 class UpFirDn2d(Function):
     @staticmethod
     def forward(ctx, x, fir, up, down, pad):
@@ -82,7 +94,7 @@ class UpFirDn2d(Function):
         ctx.g_pad = (kw - px0 - 1, w * up_x - ow * down_x + px0 - up_x + 1,
                      kh - py0 - 1, h * up_y - oh * down_y + py0 - up_y + 1)
         ctx.cfg = (up, down, pad, (h, w))
-        ctx.save_for_backward(fir, torch.flip(fir, [0, 1]))
+        ctx.save_for_backward(fir, _flipped(fir))
         return y
 
     @staticmethod

@@ -56,7 +56,7 @@ class MinibatchStdDev(nn.Module):
         var = (x - x.mean(dim=0, keepdim=True)).square().mean(dim=0)
         stat = torch.sqrt(var.clamp(min=self.alpha)).mean()
         plane = stat.to(input.dtype).reshape(1, 1, 1, 1).expand(input.shape[0], 1, input.shape[2], input.shape[3])
-        return conv_ops.to_compute_layout(torch.cat([input, plane], dim=1))
+        return conv_ops.cat_channels([input, plane])
 
 
 class ResNetBlock(nn.Module):
@@ -92,12 +92,15 @@ class NonLocalBlock(nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         bsz, _, height, width = input.shape
-        theta = self.theta(input).flatten(start_dim=2)
-        phi = F.max_pool2d(self.phi(input), kernel_size=2, stride=2).flatten(start_dim=2)
-        g = F.max_pool2d(self.g(input), kernel_size=2, stride=2).flatten(start_dim=2)
+        # channels-last feature maps ARE [B, HW, C] matrices: queries / values are views, and the second product is
+        # taken as beta @ v so that (a) its result is already the NHWC map the next conv reads and (b) beta is used
+        # un-transposed in both products (its gradient arrives contiguous: no [B, HW, HW/4] transpose copies).
+        query = self.theta(input).flatten(start_dim=2).transpose(1, 2)                                  # [B, HW, C/8]
+        key = F.max_pool2d(self.phi(input), kernel_size=2, stride=2).flatten(start_dim=2)               # [B, C/8, HW/4]
+        value = F.max_pool2d(self.g(input), kernel_size=2, stride=2).flatten(start_dim=2).transpose(1, 2)  # [B, HW/4, C/2]
         # softmax accumulates in fp32 whatever the storage type: no fp32 copy of the [B, HW, HW/4] map is made
-        beta = torch.softmax(torch.bmm(theta.transpose(1, 2), phi), dim=-1)
-        attended = torch.bmm(g, beta.transpose(1, 2)).view(bsz, -1, height, width)
+        beta = torch.softmax(torch.bmm(query, key), dim=-1)
+        attended = torch.bmm(beta, value).view(bsz, height, width, -1).permute(0, 3, 1, 2)
         output = self.o(conv_ops.to_compute_layout(attended))
         return scaled_add(self.gamma.to(input.dtype) * output, self.residual_mapping(input), 1.0 / math.sqrt(2))
 
@@ -158,6 +161,6 @@ class Discriminator(nn.Module):
         classification = self.classification_head(x.float()) if x.dtype != torch.float32 else \
             self.classification_head(x)
         for block, up, skip in zip(self.decoder_blocks, self.transposed_convolutions, reversed(skips)):
-            x = block(conv_ops.to_compute_layout(torch.cat([up(x), skip], dim=1)))
+            x = block(conv_ops.cat_channels([up(x), skip]))
         pixel_wise = self.final_mapping(x).float().contiguous().unsqueeze(dim=2)
         return classification, pixel_wise

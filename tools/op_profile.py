@@ -43,4 +43,12 @@ print(f"# {args.iters} iterations (none of them a regularisation iteration unles
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70,
                                                          max_name_column_width=60, max_shapes_column_width=70))
 if args.stack:
-    print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=40))
+    # torch-op kernels only (ours are launched through ctypes and carry no aten op): name, shapes, python stack
+    evs = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8)
+           if e.key.startswith("aten::") and e.self_device_time_total > 0]
+    evs.sort(key=lambda e: -e.self_device_time_total)
+    for e in evs[:45]:
+        print(f"{e.self_device_time_total / 1e3 / args.iters:8.3f} ms/iter  x{e.count / args.iters:6.1f}  {e.key}  {str(e.input_shapes)[:110]}")
+        for fr in e.stack[:8]:
+            if "multi_stylegan_amd" in fr or "bench" in fr or "tools" in fr:
+                print("            ", fr[-110:])

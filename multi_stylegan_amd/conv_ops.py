@@ -259,13 +259,16 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
     # [O][I][tap] would scatter them: measured 25 % slower end to end); the caller gets a strided VIEW in parameter
     # order, so no transposing copy is made either.
     oi_major = False
+    kp = 64 if x.dtype == torch.bfloat16 else 32
     if per_sample:
-        gw = torch.empty((b, o, taps, ldgw), dtype=torch.float32, device=dev)
-        k_chunks = 1
+        # one K sweep per (sample, tile, tap) unless that leaves most of the chip idle (the 512 -> 3 toRGB layers: 64
+        # workgroups); then the pixels are split and the slices meet in float atomics on a zeroed buffer
+        tiles = ((o + 127) // 128) * ((i + 127) // 128) * taps * b
+        k_chunks = max(1, min((oh * ow) // (16 * kp), 1024 // tiles)) if tiles < 256 else 1
+        gw = (torch.zeros if k_chunks > 1 else torch.empty)((b, o, taps, ldgw), dtype=torch.float32, device=dev)
     else:
         gw = torch.zeros((o, taps, ldgw), dtype=torch.float32, device=dev)
         tiles = ((o + 127) // 128) * ((i + 127) // 128) * taps * b
-        kp = 64 if x.dtype == torch.bfloat16 else 32
         k_chunks = max(1, min((oh * ow + 4 * kp - 1) // (4 * kp), (1024 + tiles - 1) // tiles))
         while b * k_chunks > 65535:
             k_chunks -= 1

@@ -43,6 +43,9 @@ def parse_args():
                          "the G step); identical training trajectory, not used for the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-clock", action="store_true")
+    ap.add_argument("--clock-all", action="store_true",
+                    help="HIP-event timing of EVERY launch (per-kernel table in the JSON line); by default only the two "
+                         "roofline kernels are timed, which keeps the event overhead out of the host path")
     ap.add_argument("--cpu-baseline-iters", type=int, default=4)
     return ap.parse_args()
 
@@ -123,7 +126,9 @@ def main():
         torch.cuda.synchronize(dev)
         note(f"warm-up iteration {i + 1} done")
     trainer.pop_logs()
-    _lib.kernel_clock.reset(enabled=not args.no_kernel_clock)
+    clock_all = args.clock_all or bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))
+    roofline_keys = ("conv_fprop_pp" if args.dtype == "bf16" else "conv_fprop_dma", "upfirdn2d")
+    _lib.kernel_clock.reset(enabled=not args.no_kernel_clock, only=None if clock_all else roofline_keys)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -100,7 +100,28 @@ def ptr(t):
 
 
 def stream_of(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw hipStream_t of torch's current stream on `device` (the fast accessor: no Stream object is built)."""
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """Context that makes `device` current for the launch.  One process drives one GPU, so the device is already
+    current in practice and the guard costs one integer comparison instead of two hipSetDevice round trips."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 class KernelClock:
@@ -109,13 +130,17 @@ class KernelClock:
 
     def __init__(self):
         self.enabled = False
+        self.only = None
         self.spans = {}
 
-    def reset(self, enabled: bool):
-        self.enabled, self.spans = enabled, {}
+    def reset(self, enabled: bool, only=None):
+        """only: tuple of key prefixes to time (None = every launch; two events per timed launch cost host time)."""
+        self.enabled, self.spans, self.only = enabled, {}, (tuple(only) if only else None)
 
     def span(self, key: str, work: float):
-        return _Span(self, key, work) if self.enabled else _NULL_SPAN
+        if not self.enabled or (self.only is not None and not key.startswith(self.only)):
+            return _NULL_SPAN
+        return _Span(self, key, work)
 
     def summary(self):
         """-> {key: dict(launches, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""

@@ -239,7 +239,7 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
         if _CLOCK_SHAPES:
             key += f"|B{b} {ih}x{iw}->{oh}x{ow} {c_real}->{n} {kh}x{kw} s{stride} up{in_up}" \
                    f"{' ps' if pixel_shuffle else ''}{' per-sample' if per_sample else ''}|"
-    with torch.cuda.device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
+    with _lib.on_device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_fprop(
             xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow,
             n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))
@@ -277,7 +277,7 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
     if _CLOCK_SHAPES and _lib.kernel_clock.enabled:
         key += f"|B{b} {ih}x{iw}->{oh}x{ow} {i}->{o} {kh}x{kw} s{stride}{' ps' if pixel_shuffle else ''}" \
                f"{' per-sample' if per_sample else f' chunks{k_chunks}'}|"
-    with torch.cuda.device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
+    with _lib.on_device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_wgrad(
             gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw,
             kh, kw, stride, pad, int(pixel_shuffle), int(per_sample), k_chunks, int(oi_major), float(gain),
@@ -419,7 +419,7 @@ _LINEAR_MAX_ROWS = 256        # above this the batch rows are worth an MFMA tile
 
 def _lin_call(name, flops, *args):
     dev = args[0].device
-    with torch.cuda.device(dev), _lib.kernel_clock.span(f"{name}/f32", flops):
+    with _lib.on_device(dev), _lib.kernel_clock.span(f"{name}/f32", flops):
         code = getattr(_lib.lib(), f"msg_{name}")(*[a.data_ptr() if isinstance(a, torch.Tensor) else
                                                    (0 if a is None else a) for a in args], _lib.stream_of(dev))
     _lib.check(code, f"msg_{name}")
@@ -544,7 +544,7 @@ def _scale_rows_cols(base, rowscale, colscale, out, gain):
     b, r, t, ck = out.shape
     c = base.shape[-1]
     dev = base.device
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = _lib.lib().msg_scale_rows_cols(base.data_ptr(), _lib.ptr(rowscale), _lib.ptr(colscale), out.data_ptr(),
                                               _lib.dtype_code(out), b, r, t, c, ck, float(gain), _lib.stream_of(dev))
     _lib.check(code, "msg_scale_rows_cols")
@@ -571,7 +571,7 @@ class _ModulatedConv(Function):
         d = None
         if demodulate:
             d = torch.empty((b, o), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 code = _lib.lib().msg_demod_coeff(w3.data_ptr(), s.data_ptr(), d.data_ptr(), b, o, i, t, scale, 1e-8,
                                                   _lib.stream_of(dev))
             _lib.check(code, "msg_demod_coeff")
@@ -636,7 +636,7 @@ class _ModulatedConv(Function):
             groups = (o + og - 1) // og
             gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
             gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 code = _lib.lib().msg_modulate_backward(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
                                                         gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t, ldg, og,
                                                         scale, _lib.stream_of(dev))

@@ -46,7 +46,7 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
     b32 = None if bias is None else bias.to(torch.float32).contiguous()
     nw32 = None if noise_weight is None else noise_weight.to(torch.float32).contiguous()
     nbytes = (2 + (ref is not None)) * x.numel() * x.element_size()
-    with torch.cuda.device(dev), _lib.kernel_clock.span(f"bias_act_fwd/{x.dtype}", nbytes):
+    with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_fwd/{x.dtype}", nbytes):
         code = _lib.lib().msg_fused_bias_act(
             x.data_ptr(), _lib.ptr(b32), _lib.ptr(ref), y.data_ptr(), _lib.dtype_code(x), x.numel(), step_b,
             x.shape[1], _lib.ptr(nz), _lib.ptr(nw32), nb, pix, act, grad, float(alpha), float(scale),
@@ -67,7 +67,7 @@ class FusedLeakyReLUFunctionBackward(Function):
         gb = torch.zeros(channels, dtype=torch.float32, device=dev) if need_bias else None
         nz, nb = _noise_args(noise, g)
         gnw = torch.zeros(1, dtype=torch.float32, device=dev) if noise is not None else None
-        with torch.cuda.device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
+        with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
             code = _lib.lib().msg_bias_act_backward(
                 g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g), g.numel(), step_b, channels,
                 _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
@@ -142,7 +142,7 @@ class _ScaledAdd(Function):
         ctx.gain = gain
         dev = _lib.require_gpu(a, b)
         y = torch.empty_like(a)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             code = _lib.lib().msg_scaled_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), _lib.dtype_code(a), a.numel(), 1.0,
                                              float(gain), _lib.stream_of(dev))
         _lib.check(code, "msg_scaled_add")

@@ -44,7 +44,7 @@ def _launch(x, fir, up, down, pad):
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev)
     key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up{up_x}down{down_x}/" \
           f"{'vec' if minor % (16 // x.element_size()) == 0 and kh <= 4 and kw <= 4 else 'generic'}"
-    with torch.cuda.device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
+    with _lib.on_device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
         code = _lib.lib().msg_upfirdn2d(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x),
                                         major, h, w, minor, kh, kw, up_x, up_y, down_x, down_y,
                                         px0, px1, py0, py1, _lib.stream_of(dev))

@@ -18,6 +18,7 @@ ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--resolution", type=int, default=256)
 ap.add_argument("--stack", action="store_true")
+ap.add_argument("--reg-only", action="store_true", help="profile exactly one iteration: the 16th (R1 + path length)")
 args = ap.parse_args()
 
 import multi_stylegan_amd as m
@@ -32,9 +33,11 @@ trainer = m.ModelWrapper(gen, dis, device=dev)
 trainer.generator_ema.compute_dtype = torch.bfloat16
 random.seed(1)
 real = torch.rand(args.batch, 2, 3, args.resolution, args.resolution, device=dev)
-for _ in range(3):
+for _ in range(15 if args.reg_only else 3):
     trainer.train_iteration(real)
 torch.cuda.synchronize()
+if args.reg_only:
+    args.iters = 1
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=args.stack) as prof:
     for _ in range(args.iters):
         trainer.train_iteration(real)

@@ -142,6 +142,19 @@ int msg_modulate_backward(const float* gwk, const float* W, const float* s, cons
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
 int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);
 
+/* msg_conv2d_fprop with the activation stage of the layer fused into the epilogue:
+ *   y = leaky_relu(conv(x, w) + noise_weight[0] * noise[b or 0, pixel] + act_bias[n], alpha) * scale
+ * i.e. EqualizedConv2d -> FusedLeakyReLU (u_net_2d_discriminator.py:160-171) and ModulatedConv2d -> NoiseInjection ->
+ * FusedLeakyReLU (multi_stylegan_generator.py:267-292) in one launch.  The activation is applied to the conv result
+ * rounded to the storage type, so the output is bit-identical to msg_conv2d_fprop followed by msg_fused_bias_act.
+ * act_bias [N] fp32 or NULL; noise [noise_batch][OH*OW] fp32 or NULL (noise_batch 1 or B); noise_weight: device scalar.
+ * No in_up / pixel_shuffle forms (those layers are followed by a FIR pass before their activation). */
+int msg_conv2d_fprop_act(const void* x, const void* w, void* y, int dtype,
+                         int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                         int kh, int kw, int stride, int pad, long long w_batch_stride,
+                         const float* act_bias, const float* noise, const float* noise_weight,
+                         int noise_batch, float alpha, float scale, void* stream);
+
 /* -------------------------------------------------------------------------
  * Equalized-lr fully connected layers with few rows (mapping network, style affines, classification head), fp32,
  * dense row-major operands.  Replaces F.linear(input, weight * scale, bias * scale_bias) of

@@ -214,12 +214,14 @@ def _cached(w, tag, dtype, wscale, build):
 
 
 # --------------------------------------------------------------------------------------------------- raw launches
+FUSE_ACTIVATION = bool(int(os.environ.get("MSG_FUSE_ACT", "1")))     # 0: two-pass conv + activation (A/B; results are bit-identical)
 _S2_PARITY = bool(int(os.environ.get("MSG_S2_PARITY", "1")))          # 0: zero-insertion form of the stride-2 data gradient (A/B)
 _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
 
 
 def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real,
-                  flops=None):
+                  flops=None, act=None):
+    """act = (act_bias | None, noise | None, noise_weight | None, alpha, scale): fuse the layer's activation stage."""
     dev = _lib.require_gpu(x, wk, bias)
     xv, cx = _nhwc_view(x)
     b, _, ih, iw = xv.shape
@@ -240,9 +242,18 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
             key += f"|B{b} {ih}x{iw}->{oh}x{ow} {c_real}->{n} {kh}x{kw} s{stride} up{in_up}" \
                    f"{' ps' if pixel_shuffle else ''}{' per-sample' if per_sample else ''}|"
     with _lib.on_device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
-        code = _lib.lib().msg_conv2d_fprop(
-            xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow,
-            n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))
+        if act is None:
+            code = _lib.lib().msg_conv2d_fprop(
+                xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh,
+                ow, n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))
+        else:
+            assert bias is None and in_up == 1 and not pixel_shuffle
+            act_bias, noise, noise_w, alpha, scale = act
+            _lib.require_gpu(x, act_bias, noise, noise_w)
+            code = _lib.lib().msg_conv2d_fprop_act(
+                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
+                stride, pad, wstride, _lib.ptr(act_bias), _lib.ptr(noise), _lib.ptr(noise_w),
+                1 if noise is None else noise.shape[0], float(alpha), float(scale), _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_fprop")
     return y
 
@@ -316,12 +327,25 @@ def _relay_fwd_kind(w, dtype, kind):
     return wk, ck
 
 
-def _f_raw(x, w, bias, g: Geometry):
+def _f_raw(x, w, bias, g: Geometry, act=None):
     wk, ck = _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
     o, _ = _oi(w)
     if g.kind == "up2":
         return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, _oi(w)[1])
-    return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, _oi(w)[1])
+    return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, _oi(w)[1],
+                         act=act)
+
+
+def _act_operands(bias, noise, noise_w, y_shape):
+    """fp32, contiguous operands of the fused activation stage (noise [B or 1, 1, H, W] -> [B or 1, H*W])."""
+    b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    nz = nw = None
+    if noise is not None:
+        if noise.shape[0] not in (1, y_shape[0]) or noise.shape[1] != 1 or tuple(noise.shape[2:]) != tuple(y_shape[2:]):
+            raise _lib.MsgHipError(f"noise shape {tuple(noise.shape)} does not match output {tuple(y_shape)}")
+        nz = noise.detach().to(torch.float32).contiguous()
+        nw = noise_w.detach().to(torch.float32).contiguous()
+    return b32, nz, nw
 
 
 def _d_raw(gy, w, g: Geometry):
@@ -404,7 +428,43 @@ class _ConvG(Function):
         return ggy, gx, None, None, None
 
 
+class _ConvActF(Function):
+    """conv -> (noise +) bias -> leaky ReLU in ONE launch (activation in the conv epilogue).  The backward is composed
+    of the differentiable pieces that the two-pass form uses (activation backward from the OUTPUT's sign, then the
+    D / G contractions), so first- and second-order gradients are those of conv followed by FusedLeakyReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale):
+        o = _oi(w)[0]
+        b32, nz, nw = _act_operands(act_bias, noise, noise_w, (x.shape[0], o, *g.y_hw))
+        y = _f_raw(x, w, None, g, act=(b32, nz, nw, alpha, scale))
+        ctx.g, ctx.cfg = g, (alpha, scale, act_bias is not None, noise is not None)
+        ctx.nw_shape = None if noise_w is None else noise_w.shape
+        ctx.save_for_backward(x, w, y, noise)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .op_static.fused_act import FusedLeakyReLUFunctionBackward
+        x, w, y, noise = ctx.saved_tensors
+        alpha, scale, has_bias, has_noise = ctx.cfg
+        g = ctx.g
+        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha, scale)
+        gx = _ConvD.apply(gpre, w, g) if ctx.needs_input_grad[0] else None
+        gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
+        return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
+            (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None
+
+
 # ------------------------------------------------------------------------------------------------- public entry
+def conv2d_bias_act(x, weight, act_bias, stride=1, padding=0, wscale=1.0, negative_slope=0.2, scale=1.0):
+    """leaky_relu(conv(x, wscale * weight) + act_bias) * scale in one launch (EqualizedConv2d -> FusedLeakyReLU)."""
+    s = stride if isinstance(stride, int) else stride[0]
+    p = padding if isinstance(padding, int) else padding[0]
+    g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
+    return _ConvActF.apply(x, weight, act_bias, None, None, g, float(negative_slope), float(scale))
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):
     """Shared-weight conv: y = conv(x, wscale * weight) + bias; weight [O,I,kh,kw] fp32, x [B,I,H,W]; y in x's dtype.
     Passing the raw parameter plus its equalized-lr scale lets the re-laid weights be cached between optimizer steps."""
@@ -561,7 +621,8 @@ class _ModulatedConv(Function):
     composite formulation, which is differentiable to any order."""
 
     @staticmethod
-    def forward(ctx, x, weight, style, demodulate, upsample):
+    def forward(ctx, x, weight, style, demodulate, upsample, act_bias=None, noise=None, noise_w=None, alpha=0.2,
+                act_scale=1.0, fuse_act=False):
         dev = _lib.require_gpu(x, weight, style)
         _, o, i, kh, kw = weight.shape
         b, t = x.shape[0], kh * kw
@@ -586,21 +647,39 @@ class _ModulatedConv(Function):
         rowscale = d if not (upsample and d is not None) else d.repeat(1, t)
         _scale_rows_cols(base, rowscale, s, wk, scale)
         g = Geometry(kind, kh, kw, 1, kh // 2, x.shape[2:], True)
+        act = None
+        if fuse_act:
+            assert not upsample, "the upsampling layers blur before their activation"
+            act = (*_act_operands(act_bias, noise, noise_w, (b, o, *g.y_hw)), alpha, act_scale)
         if upsample:
             y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
         else:
-            y = _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i)
-        ctx.save_for_backward(x, weight, style, d if d is not None else torch.empty(0, device=dev))
+            y = _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i, act=act)
+        ctx.save_for_backward(x, weight, style, d if d is not None else torch.empty(0, device=dev),
+                              y if fuse_act else None, noise if fuse_act else None)
         ctx.cfg = (demodulate, upsample, g, scale)
+        ctx.act = (alpha, act_scale, act_bias is not None, noise is not None,
+                   None if noise_w is None else noise_w.shape) if fuse_act else None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, style, d = ctx.saved_tensors
+        x, weight, style, d, y_act, noise = ctx.saved_tensors
         demodulate, upsample, g, scale = ctx.cfg
         _, o, i, kh, kw = weight.shape
         b, t = x.shape[0], kh * kw
         need = ctx.needs_input_grad
+        gb = gnw = None
+        if ctx.act is not None:
+            # activation stage first (slope from the sign of the saved OUTPUT); a differentiable Function, so the
+            # second-order graph of path-length regularisation runs through it exactly as in the two-pass form
+            from .op_static.fused_act import FusedLeakyReLUFunctionBackward
+            alpha, act_scale, has_bias, has_noise, nw_shape = ctx.act
+            gy, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y_act, noise if has_noise else None, has_bias,
+                                                               alpha, act_scale)
+            gb = gb if has_bias and need[5] else None
+            gnw = gnw.reshape(nw_shape) if has_noise and need[7] else None
+        tail = (None, None, gb, None, gnw, None, None, None)
         fused_ok = i <= 512 and t <= 9 and b <= 16
         if torch.is_grad_enabled() or not fused_ok:
             # higher-order request (create_graph=True): differentiate the composite formulation instead
@@ -609,7 +688,7 @@ class _ModulatedConv(Function):
                 y2 = _modulated_composite(x, weight, style, demodulate, upsample)
                 grads = list(torch.autograd.grad(y2, ins, gy, create_graph=torch.is_grad_enabled(), allow_unused=True))
             out = [grads.pop(0) if n else None for n in need[:3]]
-            return out[0], out[1], out[2], None, None
+            return (out[0], out[1], out[2]) + tail
         dev = x.device
         w3 = weight.detach().reshape(o, i, t)
         s = style.detach().float().contiguous()
@@ -643,7 +722,15 @@ class _ModulatedConv(Function):
             _lib.check(code, "msg_modulate_backward")
             gw = gw3.reshape(1, o, i, kh, kw)
             gs = gs_part.sum(dim=0).to(style.dtype)
-        return gx, gw, gs, None, None
+        return (gx, gw, gs) + tail
+
+
+def modulated_conv2d_bias_act(x, weight, style, demodulate, act_bias, noise, noise_weight, negative_slope=0.2,
+                              scale=1.0):
+    """modulated_conv2d (no upsampling) -> noise injection -> bias -> leaky ReLU, the activation stage fused into the
+    contraction's epilogue (multi_stylegan_generator.py:267-292 + 384-411 in one pass over the output map)."""
+    return _ModulatedConv.apply(x, weight, style, bool(demodulate), False, act_bias, noise, noise_weight,
+                                float(negative_slope), float(scale), True)
 
 
 def modulated_conv2d(x, weight, style, demodulate, upsample):

@@ -32,6 +32,7 @@ struct ConvParams {
     int kh, kw, stride, pad, in_up, pixel_shuffle, per_sample;
     long long x_bstride, w_bstride, y_bstride;     // elements
     int Mtot, n_chunks, n_iters, m_tiles, n_tiles;
+    ActEpilogue act;
 };
 
 constexpr int BM = 128, BN = 128, ROWB = 128;                  // tile rows / cols, bytes per staged row
@@ -258,12 +259,32 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 store_from_f32(reinterpret_cast<T*>(ep + row * PITCH) + col, acc[i][j][e] + bv);
             }
         }
-    __syncthreads();
     constexpr int LPR = 64 / VEC;                                  // lanes per 64-element row
     constexpr int RPP = 64 / LPR;                                  // rows per pass
     const int er = lane / LPR, ec = (lane % LPR) * VEC;
+    // fused activation stage: this lane's bias vector and the noise value of each of its rows are fetched HERE, before
+    // the barrier, so their latency hides behind it instead of sitting in front of every store
+    float a_bias[VEC], a_noise[64 / RPP];
+    if (p.act.enabled) {
+        const int n = n0 + wn * 64 + ec;
 #pragma unroll
-    for (int pass = 0; pass < 64 / RPP; ++pass) {
+        for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
+        const float nw = p.act.noise ? p.act.noise_w[0] : 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 64 / RPP; ++pass) {
+            const int m = m0 + wm * 64 + pass * RPP + er;
+            float nz = 0.f;
+            if (p.act.noise && m < p.Mtot) {
+                const int b = p.per_sample ? bz : m / ohw;
+                const int pix = p.per_sample ? m : m - b * ohw;
+                nz = nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix];
+            }
+            a_noise[pass] = nz;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 64 / RPP; ++pass) {                  // (fully unrolled: a_noise[pass] lives in registers)
         const int row = pass * RPP + er;
         const int m = m0 + wm * 64 + row;
         const int n = n0 + wn * 64 + ec;
@@ -283,10 +304,14 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         }
         const T* src = reinterpret_cast<const T*>(ep + row * PITCH) + ec;
         const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;  // valid elements left in this channel run
+        u32x4 v = *reinterpret_cast<const u32x4*>(src);
+        if (p.act.enabled) v = act_epilogue_apply<T>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
         if (lim >= VEC) {
-            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+            *reinterpret_cast<u32x4*>(dst) = v;
         } else {
-            for (int e = 0; e < lim; ++e) dst[e] = src[e];
+            T tmp[VEC];
+            *reinterpret_cast<u32x4*>(tmp) = v;
+            for (int e = 0; e < lim; ++e) dst[e] = tmp[e];
         }
     }
 }
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
 extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float* bias, void* y,
                                        int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                        int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
-                                       long long w_batch_stride, void* stream);
+                                       long long w_batch_stride, const ActEpilogue* act, void* stream);
 
 extern "C" int msg_conv2d_fprop_pp_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                             int kh, int kw, long long w_batch_stride);
@@ -311,10 +336,35 @@ extern "C" int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, i
     return (variant == 1 || (variant == 0 && n_iters >= 12)) ? 1 : 0;
 }
 
+static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, void* y, int dtype,
+                             int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                             int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                             long long w_batch_stride, const ActEpilogue& act, void* stream);
+
 extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, int dtype,
                                 int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                 int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
                                 long long w_batch_stride, void* stream) {
+    ActEpilogue act{};
+    return conv2d_fprop_impl(x, w, bias, y, dtype, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
+                             pixel_shuffle, w_batch_stride, act, stream);
+}
+
+extern "C" int msg_conv2d_fprop_act(const void* x, const void* w, void* y, int dtype,
+                                    int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                    int kh, int kw, int stride, int pad, long long w_batch_stride,
+                                    const float* act_bias, const float* noise, const float* noise_weight,
+                                    int noise_batch, float alpha, float scale, void* stream) {
+    if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != B))) return MSG_EINVAL;
+    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale};
+    return conv2d_fprop_impl(x, w, nullptr, y, dtype, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, 1, 0,
+                             w_batch_stride, act, stream);
+}
+
+static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, void* y, int dtype,
+                             int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                             int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                             long long w_batch_stride, const ActEpilogue& act, void* stream) {
     if (B == 0) return MSG_OK;
     if (!x || !w || !y || B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || N <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || in_up <= 0 || Cx <= 0 || Ck <= 0 || ldy <= 0)
@@ -327,12 +377,13 @@ extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias,
     if (in_up > 1 && stride != 1) return MSG_EUNSUPPORTED;
     if (dtype == MSG_BF16 &&
         msg_conv2d_fprop_pp_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
-                                pixel_shuffle, w_batch_stride, stream))
+                                pixel_shuffle, w_batch_stride, &act, stream))
         return MSG_CHECK_LAUNCH();                 // large shapes: 256x256 ping-pong kernel (conv_fprop_pp.hip)
     ConvParams p{};
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.in_up = in_up; p.pixel_shuffle = pixel_shuffle;
     p.per_sample = w_batch_stride != 0;
+    p.act = act;
     p.x_bstride = (long long)IH * IW * Cx;
     p.w_bstride = w_batch_stride;
     p.y_bstride = pixel_shuffle ? 4ll * OH * OW * ldy : (long long)OH * OW * ldy;

@@ -32,6 +32,7 @@ struct ConvParamsPP {
     int kh, kw, stride, pad, in_up, pixel_shuffle, per_sample;
     long long x_bstride, w_bstride, y_bstride;
     int Mtot, n_chunks, n_iters, m_tiles, n_tiles;
+    ActEpilogue act;
 };
 
 constexpr int PM = 256, PN = 256, PROW = 128;
@@ -288,9 +289,28 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
                 reinterpret_cast<bf16_t*>(ep + row * PITCH)[col] = f2bf(acc[i][j][e] + bv);
             }
         }
-    __syncthreads();
     const int er = lane >> 3, ec = (lane & 7) * VEC;          // 8 lanes per 64-channel row, 8 rows per pass
-#pragma unroll 4
+    // fused activation stage: bias vector and per-row noise values are fetched before the barrier (latency hidden)
+    float a_bias[VEC], a_noise[16];
+    if (p.act.enabled) {
+        const int n = n0 + wn * 64 + ec;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
+        const float nw = p.act.noise ? p.act.noise_w[0] : 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            const int m = m0 + grp * 128 + pass * 8 + er;
+            float nz = 0.f;
+            if (p.act.noise && m < p.Mtot) {
+                const int b = p.per_sample ? bz : m / ohw;
+                const int pix = p.per_sample ? m : m - b * ohw;
+                nz = nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix];
+            }
+            a_noise[pass] = nz;
+        }
+    }
+    __syncthreads();
+#pragma unroll
     for (int pass = 0; pass < 16; ++pass) {
         const int row = pass * 8 + er;
         const int m = m0 + grp * 128 + row;
@@ -310,8 +330,15 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
         }
         const bf16_t* src = reinterpret_cast<const bf16_t*>(ep + row * PITCH) + ec;
         const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;
-        if (lim >= VEC) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
-        else for (int e = 0; e < lim; ++e) dst[e] = src[e];
+        u32x4 v = *reinterpret_cast<const u32x4*>(src);
+        if (p.act.enabled) v = act_epilogue_apply<bf16_t>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+        if (lim >= VEC) {
+            *reinterpret_cast<u32x4*>(dst) = v;
+        } else {
+            bf16_t tmp[VEC];
+            *reinterpret_cast<u32x4*>(tmp) = v;
+            for (int e = 0; e < lim; ++e) dst[e] = tmp[e];
+        }
     }
 }
 
@@ -336,7 +363,7 @@ extern "C" int msg_conv2d_fprop_pp_eligible(int B, int IH, int IW, int Cx, int C
 extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float* bias, void* y,
                                        int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                        int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
-                                       long long w_batch_stride, void* stream) {
+                                       long long w_batch_stride, const ActEpilogue* act, void* stream) {
     if (!msg_conv2d_fprop_pp_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 0;
     const bool per_sample = w_batch_stride != 0;
     const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;
@@ -345,6 +372,7 @@ extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.in_up = in_up; p.pixel_shuffle = pixel_shuffle;
     p.per_sample = per_sample;
+    if (act) p.act = *act;
     p.x_bstride = (long long)IH * IW * Cx;
     p.w_bstride = w_batch_stride;
     p.y_bstride = pixel_shuffle ? 4ll * OH * OW * ldy : (long long)OH * OW * ldy;

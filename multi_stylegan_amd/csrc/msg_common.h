@@ -61,4 +61,42 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Optional activation stage of the convolution epilogues: y = lrelu(conv + noise_w * noise[b, pixel] + bias[n]) * scale,
+// applied to the ROUNDED conv result exactly as the stand-alone kernel (bias_act.hip) would apply it to the stored
+// conv output -- the fused and the two-pass forms are bit-identical, only one read + one write of the map cheaper.
+struct ActEpilogue {
+    const float* bias;       // [N] or NULL
+    const float* noise;      // [noise_batch][OH*OW] fp32 or NULL
+    const float* noise_w;    // device scalar (with noise)
+    int noise_batch;         // 1 (shared by the batch) or B
+    int enabled;
+    float alpha, scale;
+};
+
+// `raw`: VEC storage elements of VEC consecutive channels of one pixel; `bv`: their bias values (0 where absent);
+// `nv` = noise_w * noise[pixel] (or 0).  Same arithmetic, in the same order, as bias_act_vec_kernel.
+template <typename T>
+__device__ __forceinline__ u32x4 act_epilogue_apply(u32x4 raw, const float* bv, float nv, float alpha, float scale) {
+    constexpr int VEC = 16 / sizeof(T);
+    Vec16<T> v, o;
+    v.raw = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float add = nv + bv[e];
+        const float val = v.get(e) + add;
+        f[e] = ((val > 0.f) ? val : val * alpha) * scale;
+    }
+    if constexpr (VEC == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+    }
+    u32x4 r;
+    r[0] = o.raw.x; r[1] = o.raw.y; r[2] = o.raw.z; r[3] = o.raw.w;
+    return r;
+}
+
 #define MSG_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? MSG_OK : MSG_ELAUNCH)

@@ -13,6 +13,7 @@ path is laid out for MI355X:
   ``elide_dead_branch=True`` -- outputs and gradients are identical either way.
 """
 import math
+import os
 from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
@@ -132,6 +133,18 @@ class StyledConv2d(nn.Module):
         self.activation = FusedLeakyReLU(out_channels)
 
     def forward(self, input: torch.Tensor, style: torch.Tensor, noise: torch.Tensor = None):
+        mc = self.modulated_convolution
+        if not mc.upsampling and conv_ops.FUSE_ACTIVATION and input.is_cuda:
+            # conv -> noise -> bias -> leaky ReLU in one launch (the upsampling layers blur in between: two passes)
+            bsz = input.shape[0]
+            style_out = mc.modulation_mapping(style).view(bsz, 1, mc.in_channels, 1, 1) \
+                if mc.modulation_mapping is not None else style
+            if noise is None:
+                noise = torch.randn(bsz, 1, input.shape[2], input.shape[3], device=input.device, dtype=torch.float32)
+            output = conv_ops.modulated_conv2d_bias_act(
+                input, mc.weight, style_out.reshape(bsz, mc.in_channels), mc.demodulate, self.activation.bias, noise,
+                self.noise_injection.weight, self.activation.negative_slope, self.activation.scale)
+            return (output, style_out) if self.modulation_mapping else output
         result = self.modulated_convolution(input, style)
         output, style_out = result if self.modulation_mapping else (result, None)
         if noise is None:

@@ -75,7 +75,8 @@ class ResNetBlock(nn.Module):
             bias=False) if in_channels != out_channels else nn.Identity()
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        output = self.main_mapping(self.mini_batch_std_dev(input))
+        conv1, act1, conv2, act2 = self.main_mapping            # conv -> bias + leaky ReLU fused per pair
+        output = conv2.forward_activated(conv1.forward_activated(self.mini_batch_std_dev(input), act1), act2)
         return scaled_add(output, self.residual_mapping(input), 1.0 / math.sqrt(2))
 
 

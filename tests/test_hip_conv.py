@@ -142,6 +142,68 @@ def test_conv_full_size_properties():
     assert rel_err(y.float(), ref) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 12, 12, 3), (1, 72, 136, 20, 20, 3), (3, 40, 9, 8, 8, 1),
+                                   (2, 64, 256, 64, 64, 3)], ids=["small", "multi_tile", "ragged_1x1", "pp_tile"])
+def test_conv_with_fused_activation_is_bit_identical(shape, dtype):
+    """msg_conv2d_fprop_act == msg_conv2d_fprop followed by msg_fused_bias_act, bit for bit (the activation is applied
+    to the rounded conv result in the epilogue), and so are first- and second-order gradients."""
+    from multi_stylegan_amd import conv_ops
+    from multi_stylegan_amd.op_static import fused_leaky_relu
+    b, i, o, h, w_, k = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(b, i, h, w_, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(o, i, k, k, generator=g) / math.sqrt(i * k * k)).to(DEV)
+    bias = torch.randn(o, generator=g).to(DEV)
+    gy = torch.randn(b, o, h, w_, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    v = torch.randn(b, i, h, w_, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        if fused:
+            y = conv_ops.conv2d_bias_act(xs, ws, bs, stride=1, padding=k // 2, wscale=0.7, negative_slope=0.2, scale=1.4)
+        else:
+            y = fused_leaky_relu(conv_ops.conv2d(xs, ws, None, stride=1, padding=k // 2, wscale=0.7), bs, 0.2, 1.4)
+        gx, gw, gb = torch.autograd.grad(y, (xs, ws, bs), gy, create_graph=True)
+        ggw, = torch.autograd.grad(gx, ws, v, retain_graph=True)        # R1-type second-order term
+        outs.append((y, gx, gw, gb, ggw))
+    for name, a, r in zip(("y", "gx", "gw", "gb", "ggw"), *outs):
+        if name in ("gw", "gb", "ggw"):                                 # float atomics: order-dependent rounding
+            assert rel_err(a.float(), r.float()) < 1e-5, name
+        else:
+            assert torch.equal(a, r), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("noise_batch", [1, 3])
+def test_modulated_conv_with_fused_activation_is_bit_identical(noise_batch, dtype):
+    from multi_stylegan_amd import conv_ops
+    from multi_stylegan_amd.op_static import fused_bias_noise_leaky_relu
+    b, i, o, h = 3, 24, 40, 16
+    g = torch.Generator().manual_seed(77 + noise_batch)
+    x = torch.randn(b, i, h, h, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(1, o, i, 3, 3, generator=g).to(DEV)
+    style = (torch.randn(b, i, generator=g) * 0.3 + 1).to(DEV)
+    bias, nw = torch.randn(o, generator=g).to(DEV), torch.tensor([0.37], device=DEV)
+    noise = torch.randn(noise_batch, 1, h, h, generator=g).to(DEV)
+    gy = torch.randn(b, o, h, h, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (x, w, style, bias, nw)]
+        xs, ws, ss, bs, ns = leaves
+        if fused:
+            y = conv_ops.modulated_conv2d_bias_act(xs, ws, ss, True, bs, noise, ns, 0.2, 1.0)
+        else:
+            y = fused_bias_noise_leaky_relu(conv_ops.modulated_conv2d(xs, ws, ss, True, False), bs, noise, ns, 0.2, 1.0)
+        first = torch.autograd.grad(y, leaves, gy, retain_graph=True)                     # fused first-order path
+        gs, = torch.autograd.grad(y, ss, gy, create_graph=True)                           # path-length-type term
+        second = torch.autograd.grad(gs.square().sum(), [ws, ss])
+        res.append((y, first, second))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, r in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert rel_err(a.float(), r.float()) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
 @pytest.mark.parametrize("m,n,k", [(16, 512, 512), (5, 7, 70), (33, 20, 1100), (1, 1, 3), (64, 129, 257)])
 def test_few_row_linear_family(m, n, k):
     """csrc/linear.hip: forward, both gradients, the fused bias gradient and the second-order terms R1 / path length

@@ -171,8 +171,10 @@ def main():
                    "conv_fprop_pp_kernel (implicit-GEMM conv fwd + data-grad, 256x256 ping-pong tile, MFMA 32x32x16 bf16)") \
             if mf else leg(f"conv_fprop_dma/{args.dtype}", "mfma", MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                            "conv_fprop_kernel<float, true> (implicit-GEMM conv, MFMA 32x32x2 f32)")
-        roof_fir = leg(f"upfirdn2d/{args.dtype}/up1down1/vec", "hbm", HBM_PEAK_GBS, "GB/s",
-                       "upfirdn2d_vec_kernel<up=1,down=1> (4x4 FIR blur, channels-last)")
+        roof_fir = leg(f"upfirdn2d/{args.dtype}/up1down1/sep", "hbm", HBM_PEAK_GBS, "GB/s",
+                       "blur_sep_kernel (4x4 FIR blur up=down=1, separable sliding window, channels-last)") or \
+            leg(f"upfirdn2d/{args.dtype}/up1down1/vec", "hbm", HBM_PEAK_GBS, "GB/s",
+                "upfirdn2d_vec_kernel<up=1,down=1> (4x4 FIR blur, channels-last)")
         kernels = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                        ("TFLOP/s" if k.startswith("conv") else "GB/s"):
                            round(v["work"] / (v["total_ms"] * 1e-3) / (1e12 if k.startswith("conv") else 1e9), 1)}

@@ -49,6 +49,14 @@ int msg_upfirdn2d(const void* x, const float* fir, void* y, int dtype,
                   int up_x, int up_y, int down_x, int down_y,
                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* msg_upfirdn2d for up = down = 1 and a SEPARABLE 4x4 FIR given by its factors (fir2d = fir_y fir_x^T, which is how
+ * every FIR of the models is built: multi_stylegan_generator.py:244-258, u_net_2d_discriminator.py:186-203), on a
+ * channels-last map (major = B, minor = C, minor % vec == 0).  Sliding-window evaluation, 8 instead of 16 taps per
+ * output; results equal msg_upfirdn2d's up to fp32 re-association.  Other shapes: MSG_EUNSUPPORTED (use msg_upfirdn2d). */
+int msg_upfirdn2d_separable(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                            int major, int in_h, int in_w, int minor, int kh, int kw,
+                            int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
 /* ---------------------------------------------------------------------------
  * a2  fused bias + (noise) + leaky-ReLU -- replaces fused_act_cuda.fused_bias_act
  *     (multi_stylegan/op_static/fused_bias_act.cpp:11-17 -> fused_bias_act_op,

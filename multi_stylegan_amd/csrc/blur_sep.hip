@@ -1,0 +1,149 @@
+// a1 (fast path): the 4x4 FIR blur of the path as a SEPARABLE sliding-window filter, channels-last.
+//
+// Every FIR the models pass to upfirdn2d is an outer product (k k^T / sum, k = [1,3,3,1]:
+// multi_stylegan_generator.py:244-258, u_net_2d_discriminator.py:186-203).  For up = down = 1 (the blur behind every
+// upsampling conv of G and every strided conv of D -- the most frequent FIR launch of a training step) the generic
+// kernel (upfirdn2d.hip) spends 16 taps per output and keeps a 5x5 input footprint per lane in registers (200 VGPRs,
+// two waves per SIMD: it is latency-bound at ~36 % of HBM).  Here a lane owns 16 bytes of channels of TWO adjacent
+// output columns and walks down TH rows: per row it loads 5 input vectors, reduces them horizontally (4 taps) to two
+// row sums, and the output is the 4-tap vertical combination of the last four row sums, which live in registers
+// (a sliding window; the unrolled loop renames them, no moves).  2.5 loads and 64 FMAs per output vector instead of
+// 6.25 and 128, ~100 VGPRs (four waves per SIMD), every load a whole 16-B-per-lane row segment.
+//
+// Result: the same sum in a different association ((x*fx) first, then *fy) -- fp32 rounding-level differences from
+// the 2-D form (the host only takes this path when fir == fy fx^T to within 1e-6 relative).
+#include "msg_common.h"
+#include <stdlib.h>
+
+struct BlurParams {
+    int B, IH, IW, OH, OW, CV;      // CV = 16-byte vectors per pixel (channel stride / VEC)
+    int px0, py0;
+};
+
+// horizontal pass of input row iy -> two row sums (columns ox, ox+1), fp32
+template <typename T>
+__device__ __forceinline__ void blur_hrow(const uint4* xin, int iy, int IH, long long rstride, int o0, int o1, int o2,
+                                          int o3, int o4, bool k0, bool k1, bool k2, bool k3, bool k4,
+                                          f32x4 wx, float (&h)[2][Vec16<T>::N]) {
+    constexpr int VEC = Vec16<T>::N;
+    if ((unsigned)iy < (unsigned)IH) {                               // (workgroup-uniform)
+        const uint4* row = xin + (long long)iy * rstride;
+        Vec16<T> v0, v1, v2, v3, v4;
+        v0.zero(); v1.zero(); v2.zero(); v3.zero(); v4.zero();
+        if (k0) v0.raw = row[o0];
+        if (k1) v1.raw = row[o1];
+        if (k2) v2.raw = row[o2];
+        if (k3) v3.raw = row[o3];
+        if (k4) v4.raw = row[o4];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float a0 = v0.get(e), a1 = v1.get(e), a2 = v2.get(e), a3 = v3.get(e), a4 = v4.get(e);
+            h[0][e] = fmaf(wx[3], a3, fmaf(wx[2], a2, fmaf(wx[1], a1, wx[0] * a0)));
+            h[1][e] = fmaf(wx[3], a4, fmaf(wx[2], a3, fmaf(wx[1], a2, wx[0] * a1)));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) h[0][e] = h[1][e] = 0.f;
+    }
+}
+
+template <typename T, int TH, int OCC>
+__global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict__ x, const float* __restrict__ fy,
+                                                          const float* __restrict__ fx, T* __restrict__ y,
+                                                          BlurParams p) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int xp = (int)(t / p.CV), cv = (int)(t - (long long)xp * p.CV);
+    const int ox = 2 * xp;
+    if (ox >= p.OW) return;
+    const int oy0 = blockIdx.y * TH, b = blockIdx.z;
+    // true convolution: tap j of the window meets fir[K-1-j] (upfirdn2d_kernel.cu:100-121 flips the same way)
+    f32x4 wx, wy;
+    wx[0] = fx[3]; wx[1] = fx[2]; wx[2] = fx[1]; wx[3] = fx[0];
+    wy[0] = fy[3]; wy[1] = fy[2]; wy[2] = fy[1]; wy[3] = fy[0];
+    const uint4* xin = reinterpret_cast<const uint4*>(x) + (long long)b * p.IH * p.IW * p.CV + cv;
+    uint4* yout = reinterpret_cast<uint4*>(y) + (long long)b * p.OH * p.OW * p.CV + cv;
+    // the five input columns of this lane's window: validity + vector offset (scalars, not arrays: no scratch)
+    const int c0 = ox - p.px0;
+    const bool k0 = (unsigned)(c0 + 0) < (unsigned)p.IW, k1 = (unsigned)(c0 + 1) < (unsigned)p.IW,
+               k2 = (unsigned)(c0 + 2) < (unsigned)p.IW, k3 = (unsigned)(c0 + 3) < (unsigned)p.IW,
+               k4 = (unsigned)(c0 + 4) < (unsigned)p.IW;
+    const int o0 = (c0 + 0) * p.CV, o1 = (c0 + 1) * p.CV, o2 = (c0 + 2) * p.CV, o3 = (c0 + 3) * p.CV, o4 = (c0 + 4) * p.CV;
+    const long long rstride = (long long)p.IW * p.CV;
+    const bool c1ok = ox + 1 < p.OW;
+
+    float w0[2][VEC], w1[2][VEC], w2[2][VEC];                        // the three previous row sums
+    blur_hrow<T>(xin, oy0 - p.py0 + 0, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w0);
+    blur_hrow<T>(xin, oy0 - p.py0 + 1, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w1);
+    blur_hrow<T>(xin, oy0 - p.py0 + 2, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w2);
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= p.OH) break;                                       // (uniform)
+        float w3[2][VEC];
+        blur_hrow<T>(xin, oy - p.py0 + 3, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w3);
+        uint4* dst = yout + ((long long)oy * p.OW + ox) * p.CV;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c == 1 && !c1ok) break;
+            V o;
+            float f[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                f[e] = fmaf(wy[3], w3[c][e], fmaf(wy[2], w2[c][e], fmaf(wy[1], w1[c][e], wy[0] * w0[c][e])));
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+            }
+            dst[c * p.CV] = o.raw;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { w0[c][e] = w1[c][e]; w1[c][e] = w2[c][e]; w2[c][e] = w3[c][e]; }
+    }
+}
+
+// x [B, in_h, in_w, minor] channels-last, fir_y [4], fir_x [4] fp32 with fir2d = fir_y fir_x^T; up = down = 1.
+extern "C" int msg_upfirdn2d_separable(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                                       int major, int in_h, int in_w, int minor, int kh, int kw,
+                                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    if (major == 0) return MSG_OK;
+    if (!x || !fir_y || !fir_x || !y || major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (kh != 4 || kw != 4 || minor % vec || (((uintptr_t)x | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
+    const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
+    if (oh <= 0 || ow <= 0) return MSG_EINVAL;
+    BlurParams p{major, in_h, in_w, oh, ow, minor / vec, pad_x0, pad_y0};
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("MSG_BLUR_VARIANT"); variant = e ? atoi(e) : 0; }
+    const long long threads = (long long)((ow + 1) / 2) * p.CV;
+    const long long gx = (threads + 255) / 256;
+    // rows per lane: 32 amortises the 3 warm-up rows best (4.36 vs 3.48 TB/s on 512ch @256^2), as long as the grid still
+    // has >= 1024 workgroups; smaller maps take 16-row strips (31 vs 40 us on 128ch @128^2)
+    int th = (gx * ((oh + 31) / 32) * major >= 1024) ? 32 : 16;
+    if (variant == 1) th = 32;
+    if (variant == 2) th = 16;
+    const int gy = (oh + th - 1) / th;
+    if (gx >= (1ll << 31) || gy > 65535 || major > 65535) return MSG_EUNSUPPORTED;
+    dim3 grid((unsigned)gx, gy, major);
+    hipStream_t s = (hipStream_t)stream;
+#define BLUR_LAUNCH(TH_)                                                                                               \
+    do {                                                                                                               \
+        if (dtype == MSG_BF16)                                                                                         \
+            hipLaunchKernelGGL((blur_sep_kernel<bf16_t, TH_, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, fir_y,     \
+                               fir_x, (bf16_t*)y, p);                                                                 \
+        else                                                                                                           \
+            hipLaunchKernelGGL((blur_sep_kernel<float, TH_, 4>), grid, dim3(256), 0, s, (const float*)x, fir_y,       \
+                               fir_x, (float*)y, p);                                                                  \
+    } while (0)
+    if (th == 32) BLUR_LAUNCH(32);
+    else BLUR_LAUNCH(16);
+#undef BLUR_LAUNCH
+    return MSG_CHECK_LAUNCH();
+}

@@ -9,6 +9,8 @@ Memory layout: a channels-last input ([B,C,H,W] with NHWC strides) is handed to 
 ``major = B, minor = C``, anything else as NCHW planes ``major = B*C, minor = 1`` -- the two layouts the
 reference's native signature already distinguishes (upfirdn2d.cpp:12-19).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -21,6 +23,28 @@ def _is_channels_last(x):
 
 def _out_size(n, up, down, p0, p1, k):
     return (n * up + p0 + p1 - k) // down + 1
+
+
+# 1: the bf16 blur takes the separable kernel (4.4 vs 2.8 TB/s); fp32 stays on the 2-D kernel, which is faster there
+# (4.1 vs 3.5 TB/s: half the taps per byte).  0: always the 2-D kernels, 2: separable for both types (tests, A/B).
+_SEPARABLE = int(os.environ.get("MSG_FIR_SEPARABLE", "1"))
+
+
+def _separable(fir: torch.Tensor):
+    """(fir_y, fir_x) on the device with fir == outer(fir_y, fir_x) to 1e-6 relative, or None.  Needs the FIR's values
+    on the host, i.e. one synchronising copy -- done once per FIR tensor (module buffer) and cached on it."""
+    hit = fir.__dict__.get("_msg_separable")
+    if hit is not None and hit[0] == fir._version:
+        return hit[1]
+    k = fir.detach().to("cpu", torch.float64)
+    i, j = divmod(int(k.abs().argmax()), k.shape[1])
+    out = None
+    if k[i, j] != 0:
+        fy, fx = k[:, j] / k[i, j], k[i, :]
+        if (torch.outer(fy, fx) - k).abs().max() <= 1e-6 * k.abs().max():
+            out = (fy.to(fir.device, torch.float32).contiguous(), fx.to(fir.device, torch.float32).contiguous())
+    fir.__dict__["_msg_separable"] = (fir._version, out)
+    return out
 
 
 def _launch(x, fir, up, down, pad):
@@ -42,8 +66,19 @@ def _launch(x, fir, up, down, pad):
         x = x.contiguous()
         major, minor = b * c, 1
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev)
-    key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up{up_x}down{down_x}/" \
-          f"{'vec' if minor % (16 // x.element_size()) == 0 and kh <= 4 and kw <= 4 else 'generic'}"
+    vec_ok = minor % (16 // x.element_size()) == 0 and kh <= 4 and kw <= 4
+    key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up{up_x}down{down_x}/"
+    if vec_ok and minor > 1 and up == (1, 1) and down == (1, 1) and kh == 4 and kw == 4 and \
+            (_SEPARABLE == 2 or (_SEPARABLE == 1 and x.dtype == torch.bfloat16)):
+        factors = _separable(fir)
+        if factors is not None:                       # the blur: separable sliding-window kernel (csrc/blur_sep.hip)
+            with _lib.on_device(dev), _lib.kernel_clock.span(key + "sep", (x.numel() + y.numel()) * x.element_size()):
+                code = _lib.lib().msg_upfirdn2d_separable(
+                    x.data_ptr(), factors[0].data_ptr(), factors[1].data_ptr(), y.data_ptr(), _lib.dtype_code(x),
+                    major, h, w, minor, kh, kw, px0, px1, py0, py1, _lib.stream_of(dev))
+            _lib.check(code, "msg_upfirdn2d_separable")
+            return y
+    key += "vec" if vec_ok else "generic"
     with _lib.on_device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
         code = _lib.lib().msg_upfirdn2d(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x),
                                         major, h, w, minor, kh, kw, up_x, up_y, down_x, down_y,

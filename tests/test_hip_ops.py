@@ -68,6 +68,50 @@ def test_upfirdn2d_channels_last_vs_oracle(cfg, dtype, tol):
     assert rel_err(ggy.float(), ggyr) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOL16)])
+@pytest.mark.parametrize("cfg", [((2, 1), 16, 12, 10, 2), ((2, 2), 8, 15, 15, 3), ((1, 1), 24, 5, 33, 1),
+                                 ((2, 1), 64, 40, 19, 2), ((3, 3), 8, 3, 2, 1), ((0, 0), 8, 9, 9, 1),
+                                 ((-1, 0), 16, 20, 20, 1)])
+def test_blur_separable_kernel(cfg, dtype, tol):
+    """up = down = 1 with a rank-1 4x4 FIR takes csrc/blur_sep.hip (sliding-window separable form).  Asymmetric
+    factors so a flipped / transposed tap order shows; checked against the CPU oracle (forward, adjoint, second
+    order) and against the 2-D kernel on the same data; ragged widths, rows beyond one 16-row strip, crops."""
+    from oracle import ops as oo
+    import importlib
+    mod = importlib.import_module("multi_stylegan_amd.op_static.upfirdn2d")
+    ops = _ops()
+    pad, c, h, w, b = cfg
+    g = torch.Generator().manual_seed(c * 100 + h)
+    fy, fx = torch.randn(4, generator=g), torch.randn(4, generator=g)
+    fir = torch.outer(fy, fx)
+    x = torch.randn(b, c, h, w, generator=g).to(dtype).float()
+    xr = x.clone().requires_grad_(True)
+    yr = oo.upfirdn2d(xr, fir, pad=pad)
+    gy = torch.randn(yr.shape, generator=g).to(dtype).float()
+    gyr = gy.clone().requires_grad_(True)
+    gxr, = torch.autograd.grad(yr, xr, gyr, create_graph=True)
+    ggx = torch.randn(x.shape, generator=g).to(dtype).float()
+    ggyr, = torch.autograd.grad(gxr, gyr, ggx)
+    fird = fir.to(DEV)
+    assert mod._separable(fird) is not None and mod._separable(torch.randn(4, 4, generator=g).to(DEV)) is None
+    xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gyd = gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    saved = mod._SEPARABLE
+    try:
+        mod._SEPARABLE = 2                              # both storage types through the separable kernel
+        y = ops.upfirdn2d(xd, fird, pad=pad)
+        gx, = torch.autograd.grad(y, xd, gyd, create_graph=True)
+        ggy, = torch.autograd.grad(gx, gyd, ggx.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+        mod._SEPARABLE = 0
+        y2d = ops.upfirdn2d(xd, fird, pad=pad)
+    finally:
+        mod._SEPARABLE = saved
+    assert rel_err(y.float(), yr) < tol
+    assert rel_err(gx.float(), gxr) < tol
+    assert rel_err(ggy.float(), ggyr) < tol
+    assert rel_err(y.float(), y2d.float()) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
 def test_upfirdn2d_edge_cases():
     ops = _ops()
     from multi_stylegan_amd._lib import MsgHipError

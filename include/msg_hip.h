@@ -142,6 +142,12 @@ int msg_demod_coeff(const float* W, const float* s, float* d, int B, int O, int 
                     float scale, float eps, void* stream);
 int msg_scale_rows_cols(const float* base, const float* rowscale, const float* colscale, void* out,
                         int dtype, int B, int R, int T, int C, int Ck, float gain, void* stream);
+/* Demodulation coefficients + forward per-sample weights in one launch (supersedes msg_demod_coeff followed by
+ * msg_scale_rows_cols on the forward path): wsq [O][C] = sum over taps of W^2 (cached by the caller per weight update),
+ * base [R][T][C] (R = O, or 4*O for the 2x2 transposed conv), style [B][C];
+ * out[b][r][t][c] = scale * d[b][r % O] * base[r][t][c] * style[b][c],  d_out[b][o] = d (may be NULL). */
+int msg_modulate_weights(const float* base, const float* wsq, const float* style, void* out, float* d_out,
+                         int dtype, int B, int R, int O, int T, int C, int Ck, float scale, float eps, void* stream);
 int msg_modulate_backward(const float* gwk, const float* W, const float* s, const float* d, float* gW,
                           float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
                           float scale, void* stream);

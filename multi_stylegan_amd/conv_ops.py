@@ -496,14 +496,14 @@ class _LinF(Function):
     """y = gain * x @ w^T (+ bias).  csrc/linear.hip; derivatives are _LinD / _LinG (closed family, any order)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, gain):
+    def forward(ctx, x, w, bias, gain, bias_gain=1.0):
         _lib.require_gpu(x, w, bias)
         x, w, bias = _dense32(x, w, bias)
         (m, k), n = x.shape, w.shape[0]
         y = torch.empty((m, n), dtype=torch.float32, device=x.device)
-        _lin_call("linear_fprop", 2.0 * m * n * k, x, w, bias, y, m, n, k, float(gain), 1.0)
+        _lin_call("linear_fprop", 2.0 * m * n * k, x, w, bias, y, m, n, k, float(gain), float(bias_gain))
         ctx.save_for_backward(x, w)
-        ctx.gain, ctx.has_bias = float(gain), bias is not None
+        ctx.gain, ctx.has_bias, ctx.bias_gain = float(gain), bias is not None, float(bias_gain)
         return y
 
     @staticmethod
@@ -517,13 +517,13 @@ class _LinF(Function):
             (m, n), k = gy_.shape, x.shape[1]
             gw = torch.empty((n, k), dtype=torch.float32, device=x.device)
             gb = torch.empty((n,), dtype=torch.float32, device=x.device)
-            _lin_call("linear_wgrad", 2.0 * m * n * k, gy_, x, gw, gb, m, n, k, ctx.gain, 1.0)
+            _lin_call("linear_wgrad", 2.0 * m * n * k, gy_, x, gw, gb, m, n, k, ctx.gain, ctx.bias_gain)
         else:
             if need_w:
                 gw = _LinG.apply(gy, x, ctx.gain)
             if need_b and ctx.has_bias:
-                gb = gy.sum(dim=0)
-        return gx, gw, gb, None
+                gb = gy.sum(dim=0) if ctx.bias_gain == 1.0 else gy.sum(dim=0) * ctx.bias_gain
+        return gx, gw, gb, None, None
 
 
 class _LinD(Function):
@@ -570,14 +570,16 @@ class _LinG(Function):
         return d_gy, d_x, None
 
 
-def linear(x, weight, bias=None, wscale=1.0):
-    """x [B,I] @ (wscale * weight[O,I])^T (+ bias).  Few fp32 rows (the mapping network, the style affines, the
+def linear(x, weight, bias=None, wscale=1.0, bias_scale=1.0):
+    """x [B,I] @ (wscale * weight[O,I])^T (+ bias_scale * bias).  Few fp32 rows (the mapping network, the style affines, the
     classification head) go to the one-launch kernels of csrc/linear.hip; anything else is the same contraction as a
     1x1 convolution with the batch rows as 'pixels' of one sample."""
     b, i = x.shape
     o = weight.shape[0]
     if x.dtype == torch.float32 and weight.dtype == torch.float32 and b <= _LINEAR_MAX_ROWS:
-        return _LinF.apply(x, weight, None if bias is None else bias.float(), float(wscale))
+        return _LinF.apply(x, weight, None if bias is None else bias.float(), float(wscale), float(bias_scale))
+    if bias is not None and bias_scale != 1.0:
+        bias = bias * bias_scale
     g = Geometry("conv", 1, 1, 1, 0, (b, 1), False, wscale)
     y = _ConvF.apply(x.reshape(1, b, 1, i).permute(0, 3, 1, 2), weight, None if bias is None else bias.float(), g)
     return y.permute(0, 2, 3, 1).reshape(b, o)
@@ -630,12 +632,6 @@ class _ModulatedConv(Function):
         w3 = weight.detach().reshape(o, i, t)
         s = style.detach().float().contiguous()
         d = None
-        if demodulate:
-            d = torch.empty((b, o), dtype=torch.float32, device=dev)
-            with _lib.on_device(dev):
-                code = _lib.lib().msg_demod_coeff(w3.data_ptr(), s.data_ptr(), d.data_ptr(), b, o, i, t, scale, 1e-8,
-                                                  _lib.stream_of(dev))
-            _lib.check(code, "msg_demod_coeff")
         esz = 2 if x.dtype == torch.bfloat16 else 4
         ck = _round_up(i, 128 // esz)
         kind = "up2" if upsample else "conv"
@@ -644,8 +640,17 @@ class _ModulatedConv(Function):
             (w3.permute(2, 0, 1).reshape(t * o, 1, i) if upsample else w3.transpose(1, 2)).contiguous(), 0))
         rows = t * o if upsample else o
         wk = torch.empty((b, rows, 1 if upsample else t, ck), dtype=x.dtype, device=dev)
-        rowscale = d if not (upsample and d is not None) else d.repeat(1, t)
-        _scale_rows_cols(base, rowscale, s, wk, scale)
+        if demodulate:
+            # demodulation coefficients + weight set in one launch; sum_t W^2 is cached with the weight
+            wsq, _ = _cached(weight, "wsq", torch.float32, 1.0, lambda: (w3.square().sum(dim=2).contiguous(), 0))
+            d = torch.empty((b, o), dtype=torch.float32, device=dev)
+            with _lib.on_device(dev):
+                code = _lib.lib().msg_modulate_weights(base.data_ptr(), wsq.data_ptr(), s.data_ptr(), wk.data_ptr(),
+                                                       d.data_ptr(), _lib.dtype_code(wk), b, rows, o,
+                                                       1 if upsample else t, i, ck, scale, 1e-8, _lib.stream_of(dev))
+            _lib.check(code, "msg_modulate_weights")
+        else:
+            _scale_rows_cols(base, None, s, wk, scale)
         g = Geometry(kind, kh, kw, 1, kh // 2, x.shape[2:], True)
         act = None
         if fuse_act:

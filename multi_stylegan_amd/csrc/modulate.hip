@@ -124,6 +124,110 @@ extern "C" int msg_scale_rows_cols(const float* base, const float* rowscale, con
     return MSG_CHECK_LAUNCH();
 }
 
+// Forward weight set of the modulated conv in ONE launch: demodulation coefficient + per-sample weights.
+//   d[b][o]        = rsqrt(scale^2 * sum_i s[b][i]^2 * wsq[o][i] + eps)        (wsq[o][i] = sum_t W[o][i][t]^2, cached)
+//   out[b][r][t][c] = scale * d[b][r % O] * base[r][t][c] * s[b][c]
+// Same tiling as scale_rows_cols (row r, group of BG samples); the BG coefficients of the row come from one block
+// reduction over the input channels.  Replaces msg_demod_coeff (which re-read all of W per call) + msg_scale_rows_cols.
+template <typename TO>
+__global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __restrict__ base, const float* __restrict__ wsq,
+                                                               const float* __restrict__ style, TO* __restrict__ out,
+                                                               float* __restrict__ d_out, int B, int BG, int R, int O,
+                                                               int T, int C, int Ck, float scale, float eps) {
+    using V = Vec16<TO>;
+    constexpr int VEC = V::N;
+    __shared__ float red[4 * 8];
+    __shared__ float dsh[8];
+    const int r = blockIdx.x, b0 = blockIdx.y * BG, b1 = min(B, b0 + BG);
+    const int o = r % O;
+    // ---- demodulation coefficients of this row for the BG samples
+    {
+        float part[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part[k] = 0.f;
+        for (int i = threadIdx.x; i < C; i += 256) {
+            const float q = wsq[(size_t)o * C + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < b1) { const float sv = style[(size_t)(b0 + k) * C + i]; part[k] = fmaf(q, sv * sv, part[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = wave_sum(part[k]);
+            if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 8 + k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && b0 + (int)threadIdx.x < b1) {
+            const int k = threadIdx.x;
+            const float tot = red[k] + red[8 + k] + red[16 + k] + red[24 + k];
+            const float dv = rsqrtf(scale * scale * tot + eps);
+            dsh[k] = dv;
+            if (d_out && r < O) d_out[(size_t)(b0 + k) * O + r] = dv;
+        }
+        __syncthreads();
+    }
+    const int cvecs = Ck / VEC;
+    const float* src_row = base + (size_t)r * T * C;
+    const int tstep = 256 / cvecs > 0 ? 256 / cvecs : 1;
+    for (int cv = threadIdx.x % cvecs; cv < cvecs; cv += 256) {
+        const int c0 = cv * VEC;
+        const int t0 = threadIdx.x / cvecs;
+        for (int tb = t0; tb < T; tb += tstep * SRC_ITEMS) {
+            float f[SRC_ITEMS][VEC];
+#pragma unroll
+            for (int k = 0; k < SRC_ITEMS; ++k) {
+                const int t = tb + k * tstep;
+                const float* src = src_row + (size_t)t * C + c0;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[k][e] = (t < T && c0 + e < C) ? src[e] : 0.f;
+            }
+            for (int b = b0; b < b1; ++b) {
+                const float rs = scale * dsh[b - b0];
+                const float* cs = style + (size_t)b * C;
+                float sc[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sc[e] = (c0 + e < C) ? rs * cs[c0 + e] : 0.f;
+                TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
+#pragma unroll
+                for (int k = 0; k < SRC_ITEMS; ++k) {
+                    const int t = tb + k * tstep;
+                    if (t >= T) break;
+                    V ov;
+                    if constexpr (VEC == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov.set(e, f[k][e] * sc[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov.set2(e, f[k][2 * e] * sc[2 * e], f[k][2 * e + 1] * sc[2 * e + 1]);
+                    }
+                    *reinterpret_cast<uint4*>(dst_row + (size_t)t * Ck + c0) = ov.raw;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int msg_modulate_weights(const float* base, const float* wsq, const float* style, void* out, float* d_out,
+                                    int dtype, int B, int R, int O, int T, int C, int Ck, float scale, float eps,
+                                    void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!base || !wsq || !style || !out || B < 0 || R <= 0 || O <= 0 || R % O || T <= 0 || C <= 0 || Ck < C) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (Ck % vec || ((uintptr_t)out & 15u) || B > 65535) return MSG_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    int bg = 1;
+    while (bg < 8 && bg * 2 <= B && (long long)R * ((B + 2 * bg - 1) / (2 * bg)) >= 2048) bg *= 2;
+    dim3 grid(R, (B + bg - 1) / bg);
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((modulate_weights_kernel<bf16_t>), grid, dim3(256), 0, s, base, wsq, style, (bf16_t*)out, d_out,
+                           B, bg, R, O, T, C, Ck, scale, eps);
+    else
+        hipLaunchKernelGGL((modulate_weights_kernel<float>), grid, dim3(256), 0, s, base, wsq, style, (float*)out, d_out,
+                           B, bg, R, O, T, C, Ck, scale, eps);
+    return MSG_CHECK_LAUNCH();
+}
+
 // One workgroup per group of OG output channels.  Thread = input channel(s) i = tid + 256*slot (all taps of it):
 // the style gradient of its channels never leaves the thread; <g_w,u> needs one block reduction per (o, all b at once).
 constexpr int MB_SLOTS = 2;      // I <= 512

@@ -56,6 +56,8 @@ class EqualizedLinear(nn.Module):
         return f"{self.weight.shape[1]}, {self.weight.shape[0]}, bias={self.bias is not None}"
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if input.is_cuda:                       # both equalized-lr gains ride inside the kernel (no bias * scale launch)
+            return conv_ops.linear(input, self.weight, self.bias, wscale=self.scale, bias_scale=self.scale_bias)
         b = None if self.bias is None else self.bias * self.scale_bias
         return conv_ops.linear(input, self.weight, b, wscale=self.scale)
 

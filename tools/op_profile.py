@@ -50,6 +50,10 @@ if args.stack:
     evs = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8)
            if e.key.startswith("aten::") and e.self_device_time_total > 0]
     evs.sort(key=lambda e: -e.self_device_time_total)
+    counts = sorted(evs, key=lambda e: -e.count)
+    print("# most frequent aten ops with device time (launch count matters for the host path)")
+    for e in counts[:40]:
+        print(f"  x{e.count / args.iters:6.1f}/iter {e.self_device_time_total / 1e3 / args.iters:7.3f} ms/iter  {e.key}  {str(e.input_shapes)[:90]}")
     for e in evs[:45]:
         print(f"{e.self_device_time_total / 1e3 / args.iters:8.3f} ms/iter  x{e.count / args.iters:6.1f}  {e.key}  {str(e.input_shapes)[:110]}")
         for fr in e.stack[:8]:

@@ -90,6 +90,12 @@ def bench_conv(args):
             w = torch.randn((b, o, i, k, k) if ps else (o, i, k, k), device=DEV) / math.sqrt(i * k * k)
             g = conv_ops.Geometry(kind, k, k, s, p, (r, r), ps)
             wk, ck = conv_ops._relay_fwd(w, dt)
+            extra = int(os.environ.get("MSG_BIG_WPITCH", "0"))       # experiment: padded weight-row pitch (big kernel only)
+            if extra and kind != "up2":
+                flat = wk.reshape(*wk.shape[:-2], -1)
+                wk_p = torch.zeros(*flat.shape[:-1], flat.shape[-1] + extra, device=DEV, dtype=dt)
+                wk_p[..., :flat.shape[-1]] = flat
+                wk = wk_p
             if kind == "up2":
                 wk = wk.transpose(-3, -2).reshape(*wk.shape[:-3], 4 * o, 1, ck).contiguous()
                 fn = lambda: conv_ops._launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, ps, i)

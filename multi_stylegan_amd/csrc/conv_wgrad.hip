@@ -386,7 +386,9 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
         const long long tiles = (long long)((O + WT - 1) / WT) * ((I + WT - 1) / WT) * kh * kw;
         long long chunks = (1536 + tiles - 1) / tiles;
         if (chunks > steps / 4) chunks = steps / 4;
-        if (tiles == (long long)kh * kw && chunks >= 8) chunks &= ~7ll;   // single channel tile: slices are dealt 8 at a time
+        static int slice_tiles = -1;                     // MSG_WGRAD_SLICE_TILES: largest channel-tile count that takes the slice-per-XCD order
+        if (slice_tiles < 0) { const char* e = getenv("MSG_WGRAD_SLICE_TILES"); slice_tiles = e ? atoi(e) : 6; }
+        if (tiles <= (long long)kh * kw * slice_tiles && chunks >= 8) chunks &= ~7ll;   // slices are dealt 8 at a time
         if (chunks < 1) chunks = 1;
         if (chunks > 65535) chunks = 65535;
         p.fold = 1;
@@ -403,7 +405,10 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     p.oi_major = oi_major;
     p.gain = gain;
     p.nz = (int)zs;
-    p.xcd_slices = (p.o_tiles * p.i_tiles == 1 && variant != 4) || (variant == 5 && zs % 8 == 0);   // 4 / 5: A/B switches
+    static int slice_tiles2 = -1;
+    if (slice_tiles2 < 0) { const char* e = getenv("MSG_WGRAD_SLICE_TILES"); slice_tiles2 = e ? atoi(e) : 6; }
+    p.xcd_slices = (p.o_tiles * p.i_tiles <= slice_tiles2 && variant != 4 && (slice_tiles2 == 1 || zs % 8 == 0 || zs >= 64)) ||
+                   (variant == 5 && zs % 8 == 0);   // 4 / 5: A/B switches
     const long long nblk = (p.xcd_slices ? ((zs + 7) / 8) * 8 : zs) * p.o_tiles * p.i_tiles * kh * kw;
     if (zs > (1 << 24) || nblk >= (1ll << 31)) return MSG_EUNSUPPORTED;
     dim3 grid((unsigned)nblk);

@@ -80,7 +80,14 @@ def bench_conv(args):
              ("3x3 128->128 256^2 shared", "conv", 128, 128, 256, 3, 1, 1, False),
              ("3x3 256->256 128^2 shared", "conv", 256, 256, 128, 3, 1, 1, False),
              ("3x3 1024->1024 16^2 shared", "conv", 1024, 1024, 16, 3, 1, 1, False),
-             ("3x3 s2 128->128 256->127 shared", "conv", 128, 128, 256, 3, 2, 0, False)]
+             ("3x3 s2 128->128 256->127 shared", "conv", 128, 128, 256, 3, 2, 0, False),
+             ("D 3x3 256->128 256^2 shared", "conv", 256, 128, 256, 3, 1, 1, False),
+             ("D 3x3 128->256 256^2 shared", "conv", 128, 256, 256, 3, 1, 1, False),
+             ("D 3x3 384->256 128^2 shared", "conv", 384, 256, 128, 3, 1, 1, False),
+             ("D 3x3 768->768 32^2 shared", "conv", 768, 768, 32, 3, 1, 1, False),
+             ("D 3x3 1024->768 32^2 shared", "conv", 1024, 768, 32, 3, 1, 1, False),
+             ("D 1x1 256->128 256^2 shared", "conv", 256, 128, 256, 1, 1, 0, False),
+             ("D 3x3 6->128 256^2 shared", "conv", 6, 128, 256, 3, 1, 1, False)]
     for dt in ((torch.bfloat16,) if not args.f32 else (torch.bfloat16, torch.float32)):
         for name, kind, i, o, r, k, s, p, ps in cases:
             if args.only and args.only not in name:

@@ -112,6 +112,8 @@ def main():
     torch.manual_seed(1234 + rank)                            # different data / z / noise per rank
     import random
     random.seed(1234 + rank)
+    import numpy
+    numpy.random.seed(1234 + rank)                            # the style-mixing crossover layer is drawn with numpy
     real = torch.rand(args.batch, 2, 3, args.resolution, args.resolution, device=dev)
 
     def barrier():

@@ -27,7 +27,7 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -39,13 +39,23 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local_rank
 
 
+# MSG_FORCE_COLLECTIVES=1: run every collective even with ONE rank (a one-rank RCCL communicator is legal).  That is how
+# the RCCL code paths -- broadcast at start-up, hook -> side stream -> async all-reduce -> wait, the scalar all-reduce of
+# the path-length mean -- are exercised on a single-GPU box (tests/test_hip_ddp.py); results are unchanged.
+_FORCE_COLLECTIVES = bool(int(os.environ.get("MSG_FORCE_COLLECTIVES", "0")))
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def collectives_active() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES)
+
+
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
     """Identical initial replicas: parameters and buffers of ``module`` are overwritten with rank ``src``'s."""
-    if world_size() == 1:
+    if not collectives_active():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -53,7 +63,7 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
 
 
 def all_reduce_mean(t: torch.Tensor) -> torch.Tensor:
-    if world_size() == 1:
+    if not collectives_active():
         return t
     out = t.clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM)
@@ -81,6 +91,7 @@ class GradBucketReducer:
         params = [p for p in params if p.requires_grad]
         self.group, self.overlap = group, overlap
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or collectives_active()      # collectives are issued (see MSG_FORCE_COLLECTIVES)
         self.buckets: List[_Bucket] = []
         self._armed = False
         self._next = 0
@@ -109,7 +120,7 @@ class GradBucketReducer:
                 self._bucket_of[p] = bucket
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.comm_stream = None
-        if self.world > 1 and params and params[0].is_cuda:
+        if self.active and params and params[0].is_cuda:
             self.comm_stream = torch.cuda.Stream(device=params[0].device)
 
     # -------------------------------------------------------------------------------------------------
@@ -151,7 +162,7 @@ class GradBucketReducer:
         if p.grad is not None and p.grad.data_ptr() != self._view_ptr(b, p):
             self._reattach(b)                      # autograd swapped the tensor (out-of-place accumulation)
         b.pending -= 1
-        if b.pending == 0 and self.overlap and self.world > 1:
+        if b.pending == 0 and self.overlap and self.active:
             self._launch_ready()
 
     def _view_ptr(self, b, p):
@@ -182,7 +193,7 @@ class GradBucketReducer:
     def finish(self) -> None:
         """Reduce whatever has not been sent yet, wait for everything, turn sums into means."""
         self._armed = False
-        if self.world == 1:
+        if not self.active:
             return
         while self._next < len(self.buckets):             # whatever is left (incl. buckets with unused parameters)
             self._launch(self.buckets[self._next])

@@ -199,7 +199,7 @@ class ModelWrapper(object):
             self.generator_reducer.arm()
             grads = G(input=z, inject_index=dr.inject_pl, noise=dr.noise_pl, return_path_length_grads=True,
                       path_length_noise=dr.pl_image_noise)
-            reduce_fn = msg_dist.all_reduce_mean if msg_dist.world_size() > 1 else None
+            reduce_fn = msg_dist.all_reduce_mean if msg_dist.collectives_active() else None
             pl_loss, path_length = self.path_length_regularization(grads, reduce_fn)
             (hp["w_generator_regularization"] * pl_loss).backward()
             self._step(self.generator_reducer, self.generator_optimizer)

@@ -50,3 +50,80 @@ def test_trainer_two_ranks_one_gpu_gloo():
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=5) == "ok"
+
+
+def _rccl_worker(port, out):
+    """ONE rank, real RCCL communicator, collectives forced on: must reproduce the plain single-process run bit for bit
+    (a one-rank all-reduce / broadcast is the identity)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MSG_FORCE_COLLECTIVES="1")
+    sys.path.insert(0, ROOT)
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd import dist as msg_dist
+    from tools.gen_golden import TINY_D, TINY_G
+    msg_dist.init_from_env()                                       # backend "nccl" == RCCL
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and msg_dist.collectives_active()
+    torch.manual_seed(10)
+    g, d = m.MultiStyleGANGenerator(TINY_G).to("cuda:0"), m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True).to("cuda:0")
+    # plain SGD: a gradient perturbation moves the parameters proportionally (Adam with beta1 = 0 would turn the
+    # float-atomic noise of the weight-gradient kernels into steps of size lr and hide a 1e-3 exchange error)
+    tr = m.ModelWrapper(g, d, device="cuda:0", bucket_bytes=1 << 15,
+                        generator_optimizer=torch.optim.SGD(g.parameters(), lr=1e-3),
+                        discriminator_optimizer=torch.optim.SGD(d.parameters(), lr=1e-3))
+    assert tr.generator_reducer.active and tr.generator_reducer.comm_stream is not None
+    tr.iteration = 15
+    torch.manual_seed(1000)
+    import random
+    random.seed(1000)                                              # style-mixing draws come from Python's RNG ...
+    import numpy
+    numpy.random.seed(1000)                                        # ... and the crossover layer from numpy's (as in the reference)
+    for _ in range(2):
+        tr.train_iteration(torch.rand(2, 2, 3, 32, 32, device="cuda:0"))
+    logs = tr.pop_logs()
+    flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())]).cpu()
+    out.put((flat, logs))
+    dist.destroy_process_group()
+
+
+def _plain_worker(out):
+    sys.path.insert(0, ROOT)
+    import multi_stylegan_amd as m
+    from tools.gen_golden import TINY_D, TINY_G
+    torch.manual_seed(10)
+    g, d = m.MultiStyleGANGenerator(TINY_G).to("cuda:0"), m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True).to("cuda:0")
+    tr = m.ModelWrapper(g, d, device="cuda:0", bucket_bytes=1 << 15,
+                        generator_optimizer=torch.optim.SGD(g.parameters(), lr=1e-3),
+                        discriminator_optimizer=torch.optim.SGD(d.parameters(), lr=1e-3))
+    tr.iteration = 15
+    torch.manual_seed(1000)
+    import random
+    random.seed(1000)                                              # style-mixing draws come from Python's RNG ...
+    import numpy
+    numpy.random.seed(1000)                                        # ... and the crossover layer from numpy's (as in the reference)
+    for _ in range(2):
+        tr.train_iteration(torch.rand(2, 2, 3, 32, 32, device="cuda:0"))
+    logs = tr.pop_logs()
+    flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())]).cpu()
+    out.put((flat, logs))
+
+
+def test_trainer_one_rank_rccl_collectives_forced():
+    ctx = mp.get_context("spawn")
+    q1, q2 = ctx.Queue(), ctx.Queue()
+    p1 = ctx.Process(target=_rccl_worker, args=(29900 + os.getpid() % 90, q1))
+    p1.start()
+    flat1, logs1 = q1.get(timeout=600)
+    p1.join(120)
+    p2 = ctx.Process(target=_plain_worker, args=(q2,))
+    p2.start()
+    flat2, logs2 = q2.get(timeout=600)
+    p2.join(120)
+    assert p1.exitcode == 0 and p2.exitcode == 0
+    assert all(all(v == v for v in vals) for vals in logs1.values()), "NaN in losses"
+    # same trajectory up to float-atomic ordering inside the weight-gradient kernels; a broken exchange (double counting,
+    # a missing bucket, a stale gradient) changes the SGD step at the 1e-1 level
+    rel = (flat1 - flat2).norm() / flat2.norm()
+    assert rel < 1e-5, rel
+    for key in logs2:
+        a, b = torch.tensor(logs1[key]), torch.tensor(logs2[key])
+        assert torch.allclose(a, b, rtol=2e-3, atol=1e-4), (key, logs1[key], logs2[key])

@@ -384,11 +384,30 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
         (long long)B * npix < (1ll << 31) && variant != 3) {
         const long long steps = ((long long)B * npix + kp - 1) / kp;
         const long long tiles = (long long)((O + WT - 1) / WT) * ((I + WT - 1) / WT) * kh * kw;
-        long long chunks = (1536 + tiles - 1) / tiles;
-        if (chunks > steps / 4) chunks = steps / 4;
+        // K split: pick the chunk count that minimises (rounds of 512 co-resident workgroups) x (K-steps per workgroup +
+        // a fixed prologue/epilogue/atomics cost of ~8 steps).  A fixed target count left a quarter of the chip idle in
+        // the last round on some layers (768->768 @32^2: 5 chunks = 3.2 rounds, 274 us; 3 chunks = 1.9 rounds, 226 us).
+        static int target_wgs = -1;                      // MSG_WGRAD_TARGET_WGS > 0: the old fixed-target rule (A/B)
+        if (target_wgs < 0) { const char* e = getenv("MSG_WGRAD_TARGET_WGS"); target_wgs = e ? atoi(e) : 0; }
         static int slice_tiles = -1;                     // MSG_WGRAD_SLICE_TILES: largest channel-tile count that takes the slice-per-XCD order
         if (slice_tiles < 0) { const char* e = getenv("MSG_WGRAD_SLICE_TILES"); slice_tiles = e ? atoi(e) : 6; }
-        if (tiles <= (long long)kh * kw * slice_tiles && chunks >= 8) chunks &= ~7ll;   // slices are dealt 8 at a time
+        const bool sliced = tiles <= (long long)kh * kw * slice_tiles;       // slices are dealt to the XCDs 8 at a time
+        long long chunks = 1;
+        if (target_wgs > 0) {
+            chunks = (target_wgs + tiles - 1) / tiles;
+            if (chunks > steps / 4) chunks = steps / 4;
+            if (sliced && chunks >= 8) chunks &= ~7ll;
+        } else {
+            long long best = -1;
+            const long long cmax = steps / 4 < 4096 ? steps / 4 : 4096;
+            for (long long c = 1; c <= cmax; c += (sliced && c >= 8 ? 8 : 1)) {
+                if (sliced && c > 1 && c < 8) continue;
+                const long long rounds = (tiles * c + 511) / 512;
+                const long long cost = rounds * ((steps + c - 1) / c + 8);
+                if (best < 0 || cost < best) { best = cost; chunks = c; }
+                if (tiles * c > 8192) break;
+            }
+        }
         if (chunks < 1) chunks = 1;
         if (chunks > 65535) chunks = 65535;
         p.fold = 1;

@@ -84,6 +84,9 @@ def bench_conv(args):
              ("D 3x3 256->128 256^2 shared", "conv", 256, 128, 256, 3, 1, 1, False),
              ("D 3x3 128->256 256^2 shared", "conv", 128, 256, 256, 3, 1, 1, False),
              ("D 3x3 384->256 128^2 shared", "conv", 384, 256, 128, 3, 1, 1, False),
+             ("D 3x3 256->384 128^2 shared", "conv", 256, 384, 128, 3, 1, 1, False),
+             ("D 3x3 384->384 64^2 shared", "conv", 384, 384, 64, 3, 1, 1, False),
+             ("D 1x1 768->384 64^2 shared", "conv", 768, 384, 64, 1, 1, 0, False),
              ("D 3x3 768->768 32^2 shared", "conv", 768, 768, 32, 3, 1, 1, False),
              ("D 3x3 1024->768 32^2 shared", "conv", 1024, 768, 32, 3, 1, 1, False),
              ("D 1x1 256->128 256^2 shared", "conv", 256, 128, 256, 1, 1, 0, False),

@@ -125,12 +125,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     const bool oc_ok = oc + VEC <= p.ldgy, ic_ok = ic + VEC <= p.Cx;
     const gptr_t gyb = (gptr_t)gy + ((long long)b * gyh * gyw * p.ldgy + oc) * (long long)sizeof(T);
     const gptr_t xb = (gptr_t)x + ((long long)b * p.IH * p.IW * p.Cx + ic) * (long long)sizeof(T);
-    int pix[NLD], oh[NLD], ow[NLD];
+    int pix[NLD], oh[NLD], ow[NLD], bq[NLD];           // generic addressing: (sample, row, column) of each staged pixel
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         pix[j] = pix0 + r0 + (DMA ? 4 * RPW : RSTEP) * j;
-        oh[j] = pix[j] / p.OW;
-        ow[j] = pix[j] - oh[j] * p.OW;
+        bq[j] = p.fold ? pix[j] / npix : 0;           // (folded K: the pixel index runs over all samples)
+        const int rem = pix[j] - bq[j] * npix;
+        oh[j] = rem / p.OW;
+        ow[j] = rem - oh[j] * p.OW;
     }
     int st_off[NLD];
 #pragma unroll
@@ -210,10 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             } else {
                 xh = oh[j] * p.stride + kh_ - p.pad; xw = ow[j] * p.stride + kw_ - p.pad;
             }
-            gptr_t ga = gyb + ((long long)gh * gyw + gwc) * p.ldgy * (long long)sizeof(T);
+            gptr_t ga = gyb + (((long long)bq[j] * gyh + gh) * gyw + gwc) * p.ldgy * (long long)sizeof(T);
             if (!(pok & oc_ok)) ga = zsrc;
             const bool xok = pok & ic_ok & (xh >= 0) & (xw >= 0) & (xh < p.IH) & (xw < p.IW);
-            gptr_t xa = xb + ((long long)xh * p.IW + xw) * p.Cx * (long long)sizeof(T);
+            gptr_t xa = xb + (((long long)bq[j] * p.IH + xh) * p.IW + xw) * p.Cx * (long long)sizeof(T);
             if (!xok) xa = zsrc;
             if constexpr (DMA) {
                 lds_t la = (lds_t)(smem + dma_stage * 2 * TILE + (wid_u * RPW + 4 * RPW * j) * ROW);
@@ -224,9 +226,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
                 rb[j] = *(gvec_t)xa;
             }
             pix[j] += KP;
+            bq[j] += step_b;
             oh[j] += step_h;
             ow[j] += step_w;
             if (ow[j] >= p.OW) { ow[j] -= p.OW; ++oh[j]; }
+            if (p.fold && oh[j] >= p.OH) { oh[j] -= p.OH; ++bq[j]; }
         }
     };
     auto park = [&](int stage) __attribute__((always_inline)) {
@@ -376,12 +380,16 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     if (variant < 0) { const char* e = getenv("MSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
     const long long gy_bytes = (long long)(pixel_shuffle ? 4 : 1) * OH * OW * ldgy * esz;
     const long long x_bytes = (long long)IH * IW * Cx * esz;
-    const bool uni = variant != 2 && variant != 1 && (kp % OW == 0 || OW % kp == 0) && gy_bytes < (1ll << 31) &&
-                     x_bytes < (1ll << 31);
+    bool uni = variant != 2 && variant != 1 && (kp % OW == 0 || OW % kp == 0) && gy_bytes < (1ll << 31) &&
+               x_bytes < (1ll << 31);
+    const bool can_fold = !per_sample && variant != 3 && (long long)B * npix < (1ll << 31);
+    // (a folded K loop with uniform-row addressing needs whole samples per K-step or whole K-steps per sample, and
+    //  32-bit offsets over the whole batch; otherwise the folded loop runs on the generic addressing)
+    if (can_fold && uni && !((npix % kp == 0 || kp % npix == 0) && B * gy_bytes < (1ll << 32) && B * x_bytes < (1ll << 32)))
+        uni = false;
     // shared weights: fold the batch into K (one sweep over the concatenated pixels of all samples), so that small maps
     // still give every workgroup a long K loop and the float atomics shrink from B*chunks to `chunks` per element
-    if (uni && !per_sample && (npix % kp == 0 || kp % npix == 0) && B * gy_bytes < (1ll << 32) && B * x_bytes < (1ll << 32) &&
-        (long long)B * npix < (1ll << 31) && variant != 3) {
+    if (can_fold) {
         const long long steps = ((long long)B * npix + kp - 1) / kp;
         const long long tiles = (long long)((O + WT - 1) / WT) * ((I + WT - 1) / WT) * kh * kw;
         // K split: pick the chunk count that minimises (rounds of 512 co-resident workgroups) x (K-steps per workgroup +

@@ -155,6 +155,10 @@ int msg_modulate_backward(const float* gwk, const float* W, const float* s, cons
 /* y = (a + beta*b) * gain over n elements (n multiple of the 16-byte vector, all pointers 16-B aligned): the
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
 int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);
+/* The same for [rows][cols] operands with row pitches (elements): channel-slices of channels-last buffers, e.g. the
+ * gradient of a skip connection (a slice of the concatenated map's gradient).  cols and pitches multiples of the vector. */
+int msg_scaled_add_rows(const void* a, const void* b, void* y, int dtype, long long rows, int cols,
+                        long long lda, long long ldb, long long ldy, float beta, float gain, void* stream);
 
 /* msg_conv2d_fprop with the activation stage of the layer fused into the epilogue:
  *   y = leaky_relu(conv(x, w) + noise_weight[0] * noise[b or 0, pixel] + act_bias[n], alpha) * scale

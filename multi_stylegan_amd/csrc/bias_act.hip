@@ -341,3 +341,52 @@ extern "C" int msg_scaled_add(const void* a, const void* b, void* y, int dtype, 
         hipLaunchKernelGGL((scaled_add_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)y, nvec, beta, gain);
     return MSG_CHECK_LAUNCH();
 }
+
+// Same, for operands that are channel-slices of channels-last buffers: [rows][cols] with row pitches lda / ldb / ldy
+// (elements).  This is what the gradient of a skip connection looks like (a slice of the concatenated map's gradient).
+template <typename T>
+__global__ __launch_bounds__(256) void scaled_add_rows_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                                                              long long rows, int cvecs, long long lda, long long ldb,
+                                                              long long ldy, float beta, float gain) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    const long long nvec = rows * cvecs;
+    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * 256) {
+        const long long r = vi / cvecs;
+        const int c = (int)(vi - r * cvecs) * VEC;
+        V va, vb, o;
+        va.raw = *reinterpret_cast<const uint4*>(a + r * lda + c);
+        vb.raw = *reinterpret_cast<const uint4*>(b + r * ldb + c);
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = fmaf(beta, vb.get(e), va.get(e)) * gain;
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+        }
+        *reinterpret_cast<uint4*>(y + r * ldy + c) = o.raw;
+    }
+}
+
+extern "C" int msg_scaled_add_rows(const void* a, const void* b, void* y, int dtype, long long rows, int cols,
+                                   long long lda, long long ldb, long long ldy, float beta, float gain, void* stream) {
+    if (rows == 0 || cols == 0) return MSG_OK;
+    if (!a || !b || !y || rows < 0 || cols < 0 || lda < cols || ldb < cols || ldy < cols) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (cols % vec || lda % vec || ldb % vec || ldy % vec || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15u))
+        return MSG_EUNSUPPORTED;
+    const long long nvec = rows * (cols / vec);
+    const unsigned blocks = (unsigned)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((scaled_add_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b,
+                           (bf16_t*)y, rows, cols / vec, lda, ldb, ldy, beta, gain);
+    else
+        hipLaunchKernelGGL((scaled_add_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)a, (const float*)b,
+                           (float*)y, rows, cols / vec, lda, ldb, ldy, beta, gain);
+    return MSG_CHECK_LAUNCH();
+}

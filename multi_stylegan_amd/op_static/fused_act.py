@@ -154,6 +154,80 @@ class _ScaledAdd(Function):
         return g, g, None
 
 
+def _rows_view(t):
+    """(rows, cols, pitch) if `t` [B,C,H,W] is a channels-last map or a channel-slice of one, else None."""
+    if t.ndim != 4 or not t.is_cuda:
+        return None
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    if (sc == 1 or c == 1) and sh == w * sw and (sb == h * w * sw or b == 1) and sw >= c:
+        return b * h * w, c, sw
+    return None
+
+
+class _ScaledAddRows(Function):
+    """(a + b) * gain for channels-last maps / channel-slices with different pitches (csrc: msg_scaled_add_rows)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gain):
+        ctx.gain = gain
+        dev = _lib.require_gpu(a, b)
+        (rows, cols, lda), (_, _, ldb) = _rows_view(a), _rows_view(b)
+        y = torch.empty(a.shape, dtype=a.dtype, device=dev, memory_format=torch.channels_last)
+        with _lib.on_device(dev):
+            code = _lib.lib().msg_scaled_add_rows(a.data_ptr(), b.data_ptr(), y.data_ptr(), _lib.dtype_code(a), rows, cols,
+                                                  lda, ldb, cols, 1.0, float(gain), _lib.stream_of(dev))
+        _lib.check(code, "msg_scaled_add_rows")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = gy * ctx.gain
+        return g, g, None
+
+
+def _rows_ok(a, b):
+    if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    va, vb = _rows_view(a), _rows_view(b)
+    vec = 16 // a.element_size()
+    return va is not None and vb is not None and va[1] % vec == 0 and va[2] % vec == 0 and vb[2] % vec == 0 and \
+        a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and a.shape[1] > 1
+
+
+class _ScaledAddFork(Function):
+    """(a + b) * gain handed out TWICE (two aliases of one result), for a tensor with exactly two consumers: autograd
+    then delivers the two incoming gradients to THIS node separately, and the backward is ONE pass (g1 + g2) * gain
+    (msg_scaled_add again) instead of autograd's accumulation add followed by the gain multiply."""
+
+    @staticmethod
+    def forward(ctx, a, b, gain):
+        ctx.gain = gain
+        y = _ScaledAdd.forward(ctx, a, b, gain)
+        return y, y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            g = (g1 if g1 is not None else g2) * ctx.gain
+        elif _rows_ok(g1, g2):
+            g = _ScaledAddRows.apply(g1, g2, ctx.gain)  # differentiable (R1 runs a second-order pass through here)
+        else:
+            g = (g1 + g2) * ctx.gain
+        return g, g, None
+
+
+def scaled_add_fork(a, b, gain):
+    """scaled_add whose result feeds two consumers: returns two aliases (see _ScaledAddFork)."""
+    same = a.shape == b.shape and a.dtype == b.dtype and a.stride() == b.stride() and a.is_cuda and \
+        a.numel() % 8 == 0 and a.dtype in (torch.float32, torch.bfloat16) and \
+        (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last))
+    if not same:
+        y = (a + b) * gain
+        return y, y
+    return _ScaledAddFork.apply(a, b, gain)
+
+
 def scaled_add(a, b, gain):
     """(a + b) * gain for two tensors of identical shape, dtype and memory layout (falls back to torch otherwise)."""
     same = a.shape == b.shape and a.dtype == b.dtype and a.stride() == b.stride() and a.is_cuda and \

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv_ops, equalized_layer
-from .op_static import FusedLeakyReLU, scaled_add, upfirdn2d
+from .op_static import FusedLeakyReLU, scaled_add, scaled_add_fork, upfirdn2d
 
 
 def _fir2d(taps, gain=1.0):
@@ -75,9 +75,17 @@ class ResNetBlock(nn.Module):
             bias=False) if in_channels != out_channels else nn.Identity()
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return self._merge(input, scaled_add)
+
+    def forward_forked(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """forward() for an output with two consumers (the skip connection and the downscale path): two aliases of the
+        result, so that their two gradients are merged and rescaled in one pass (op_static.scaled_add_fork)."""
+        return self._merge(input, scaled_add_fork)
+
+    def _merge(self, input: torch.Tensor, merge):
         conv1, act1, conv2, act2 = self.main_mapping            # conv -> bias + leaky ReLU fused per pair
         output = conv2.forward_activated(conv1.forward_activated(self.mini_batch_std_dev(input), act1), act2)
-        return scaled_add(output, self.residual_mapping(input), 1.0 / math.sqrt(2))
+        return merge(output, self.residual_mapping(input), 1.0 / math.sqrt(2))
 
 
 class NonLocalBlock(nn.Module):
@@ -155,6 +163,11 @@ class Discriminator(nn.Module):
         skips = []
         last = len(self.encoder_blocks) - 1
         for index, block in enumerate(self.encoder_blocks):
+            if index != last and hasattr(block, "forward_forked"):
+                skip, x = block.forward_forked(x)          # same tensor, two autograd edges (see forward_forked)
+                skips.append(skip)
+                x = self.downscale_convolutions[index](x)
+                continue
             x = block(x)
             if index != last:
                 skips.append(x)

@@ -152,6 +152,13 @@ int msg_modulate_backward(const float* gwk, const float* W, const float* s, cons
                           float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
                           float scale, void* stream);
 
+/* Every K-contiguous image the contraction / modulation kernels read from ONE parameter, in one pass (all outputs
+ * optional): w [O][I][T] fp32 as the reference stores it (equalized_layer.py, multi_stylegan_generator.py:330);
+ * fwd [O][T][Ck] (t_major: [T][O][Ck]) = gain*w zero-padded in i; dgrad [I][T][Ok] with the taps flipped when flip != 0,
+ * zero-padded in o; wsq [O][I] = sum over taps of w^2.  fwd/dgrad in `dtype`.  T <= 16. */
+int msg_relayout_weight(const float* w, void* fwd, void* dgrad, float* wsq, int dtype,
+                        int O, int I, int T, int Ck, int Ok, int flip, int t_major, float gain, void* stream);
+
 /* y = (a + beta*b) * gain over n elements (n multiple of the 16-byte vector, all pointers 16-B aligned): the
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
 int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);

@@ -213,7 +213,44 @@ def _cached(w, tag, dtype, wscale, build):
     return out
 
 
+def _param_images(w, dtype, gain, kind, modulation=False):
+    """{'f': (fwd image, ck), 'd': (dgrad image, ok)[, 'wsq': sum_t w^2]} of a shared-weight PARAMETER, built by ONE
+    kernel (csrc/relayout.hip) per weight update and cached on the parameter.  `modulation`: the fp32, unpadded base
+    images + wsq that the modulated conv scales per sample.  Returns None when the fast path does not apply (then the
+    torch re-layout functions are used)."""
+    if not (isinstance(w, torch.nn.Parameter) and w.is_cuda and w.dtype == torch.float32 and _FUSED_RELAYOUT):
+        return None
+    o, i = _oi(w)
+    t = w.numel() // (o * i)
+    if t > 16 or w.numel() != o * i * t:
+        return None
+    store = w.__dict__.setdefault("_msg_relay", {})
+    key = ("img", dtype, gain, kind, modulation)
+    stamp = (w._version, _WEIGHT_GENERATION[0], w.data_ptr())
+    hit = store.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    dev = w.device
+    unit = 1 if modulation else 128 // (2 if dtype == torch.bfloat16 else 4)
+    ck, ok = _round_up(i, unit), _round_up(o, unit)
+    up2 = kind == "up2"
+    with torch.no_grad():
+        w3 = w.detach().reshape(o, i, t).contiguous()
+        fwd = torch.empty((t * o, 1, ck) if up2 else (o, t, ck), dtype=dtype, device=dev)
+        dgr = torch.empty((i, t, ok), dtype=dtype, device=dev)
+        wsq = torch.empty((o, i), dtype=torch.float32, device=dev) if modulation else None
+        with _lib.on_device(dev):
+            code = _lib.lib().msg_relayout_weight(w3.data_ptr(), fwd.data_ptr(), dgr.data_ptr(), _lib.ptr(wsq),
+                                                  _lib.dtype_code(fwd), o, i, t, ck, ok, int(not up2), int(up2),
+                                                  float(gain), _lib.stream_of(dev))
+        _lib.check(code, "msg_relayout_weight")
+    out = {"f": (fwd, ck), "d": (dgr, ok), "wsq": wsq}
+    store[key] = (stamp, out)
+    return out
+
+
 # --------------------------------------------------------------------------------------------------- raw launches
+_FUSED_RELAYOUT = bool(int(os.environ.get("MSG_FUSED_RELAYOUT", "1")))   # 0: torch transpose-copies (A/B)
 FUSE_ACTIVATION = bool(int(os.environ.get("MSG_FUSE_ACT", "1")))     # 0: two-pass conv + activation (A/B; results are bit-identical)
 _S2_PARITY = bool(int(os.environ.get("MSG_S2_PARITY", "1")))          # 0: zero-insertion form of the stride-2 data gradient (A/B)
 _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
@@ -328,7 +365,9 @@ def _relay_fwd_kind(w, dtype, kind):
 
 
 def _f_raw(x, w, bias, g: Geometry, act=None):
-    wk, ck = _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
+    img = _param_images(w, x.dtype, g.wscale, g.kind) if not g.per_sample else None
+    wk, ck = img["f"] if img is not None else \
+        _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
     o, _ = _oi(w)
     if g.kind == "up2":
         return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, _oi(w)[1])
@@ -352,7 +391,9 @@ def _d_raw(gy, w, g: Geometry):
     if g.kind == "conv" and g.stride == 2 and _S2_PARITY:
         return _d_raw_s2(gy, w, g)
     i = _oi(w)[1]
-    wk, ok = _cached(w, "d" + g.kind, gy.dtype, g.wscale, lambda: _relay_dgrad(w, gy.dtype, flip=g.kind != "up2"))
+    img = _param_images(w, gy.dtype, g.wscale, g.kind) if not g.per_sample else None
+    wk, ok = img["d"] if img is not None else \
+        _cached(w, "d" + g.kind, gy.dtype, g.wscale, lambda: _relay_dgrad(w, gy.dtype, flip=g.kind != "up2"))
     if g.kind == "up2":
         return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample, _oi(w)[0])
     pad = g.kh - 1 - g.pad
@@ -636,13 +677,15 @@ class _ModulatedConv(Function):
         ck = _round_up(i, 128 // esz)
         kind = "up2" if upsample else "conv"
         # base [R][T][C]: conv -> [O][taps][I];  up2 -> rows n = q*O + o, one tap
-        base, _ = _cached(weight, "mb" + kind, torch.float32, 1.0, lambda: (
-            (w3.permute(2, 0, 1).reshape(t * o, 1, i) if upsample else w3.transpose(1, 2)).contiguous(), 0))
+        img = _param_images(weight, torch.float32, 1.0, kind, modulation=True)
+        base = img["f"][0] if img is not None else _cached(weight, "mb" + kind, torch.float32, 1.0, lambda: (
+            (w3.permute(2, 0, 1).reshape(t * o, 1, i) if upsample else w3.transpose(1, 2)).contiguous(), 0))[0]
         rows = t * o if upsample else o
         wk = torch.empty((b, rows, 1 if upsample else t, ck), dtype=x.dtype, device=dev)
         if demodulate:
             # demodulation coefficients + weight set in one launch; sum_t W^2 is cached with the weight
-            wsq, _ = _cached(weight, "wsq", torch.float32, 1.0, lambda: (w3.square().sum(dim=2).contiguous(), 0))
+            wsq = img["wsq"] if img is not None else \
+                _cached(weight, "wsq", torch.float32, 1.0, lambda: (w3.square().sum(dim=2).contiguous(), 0))[0]
             d = torch.empty((b, o), dtype=torch.float32, device=dev)
             with _lib.on_device(dev):
                 code = _lib.lib().msg_modulate_weights(base.data_ptr(), wsq.data_ptr(), s.data_ptr(), wk.data_ptr(),
@@ -702,8 +745,9 @@ class _ModulatedConv(Function):
         gx = None
         if need[0]:
             okp = _round_up(o, 128 // esz)
-            base, _ = _cached(weight, "md" + g.kind, torch.float32, 1.0, lambda: (
-                (w3 if upsample else w3.flip(-1)).permute(1, 2, 0).contiguous(), 0))       # [I][taps'][O]
+            img = _param_images(weight, torch.float32, 1.0, g.kind, modulation=True)
+            base = img["d"][0] if img is not None else _cached(weight, "md" + g.kind, torch.float32, 1.0, lambda: (
+                (w3 if upsample else w3.flip(-1)).permute(1, 2, 0).contiguous(), 0))[0]       # [I][taps'][O]
             wd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
             _scale_rows_cols(base, s, dd, wd, scale)
             if upsample:

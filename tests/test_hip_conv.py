@@ -204,6 +204,39 @@ def test_modulated_conv_with_fused_activation_is_bit_identical(noise_batch, dtyp
         assert rel_err(a.float(), r.float()) < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(24, 16, 3), (136, 72, 3), (8, 40, 1), (40, 24, 2), (3, 512, 1), (512, 6, 3)],
+                         ids=["small", "multi_tile", "1x1", "2x2", "to_rgb", "from_rgb"])
+def test_fused_weight_relayout_matches_torch_relayout(shape, dtype):
+    """csrc/relayout.hip (one kernel: forward image, data-gradient image, sum of squared taps) against the torch
+    transpose-copy functions it replaces, bit for bit, for the plain and the transposed-conv (up2) layouts."""
+    from multi_stylegan_amd import conv_ops
+    o, i, k = shape
+    torch.manual_seed(o + i)
+    w = torch.nn.Parameter(torch.randn(o, i, k, k, device=DEV))
+    for kind in (("conv", "up2") if k == 2 else ("conv",)):
+        img = conv_ops._param_images(w, dtype, 0.37, kind)
+        assert img is not None
+        f_ref, ck = conv_ops._relay_fwd_kind(w.detach(), dtype, kind)
+        d_ref, ok = conv_ops._relay_dgrad(w.detach(), dtype, flip=kind != "up2")
+        # reference path scales AFTER rounding to the storage type; the fused kernel scales in fp32 and rounds once
+        tol = 0 if dtype == torch.float32 else 1e-2
+        assert img["f"][1] == ck and img["d"][1] == ok
+        assert img["f"][0].shape == f_ref.shape and img["d"][0].shape == d_ref.shape
+        assert rel_err(img["f"][0].float(), (f_ref.float() * 0.37)) <= tol + 1e-7
+        assert rel_err(img["d"][0].float(), (d_ref.float() * 0.37)) <= tol + 1e-7
+        assert (img["f"][0][..., i:] == 0).all() and (img["d"][0][..., o:] == 0).all()          # padding is zero
+    mod = conv_ops._param_images(w, torch.float32, 1.0, "conv", modulation=True)
+    w3 = w.detach().reshape(o, i, k * k)
+    assert torch.equal(mod["f"][0], w3.transpose(1, 2).contiguous())
+    assert torch.equal(mod["d"][0], w3.flip(-1).permute(1, 2, 0).contiguous())
+    assert rel_err(mod["wsq"], w3.square().sum(dim=2)) < 1e-6
+    # cache: same object until the weight generation changes
+    assert conv_ops._param_images(w, dtype, 0.37, "conv") is conv_ops._param_images(w, dtype, 0.37, "conv")
+    conv_ops.invalidate_weight_cache()
+    assert conv_ops._param_images(w, torch.float32, 1.0, "conv", modulation=True) is not mod
+
+
 @pytest.mark.parametrize("m,n,k", [(16, 512, 512), (5, 7, 70), (33, 20, 1100), (1, 1, 3), (64, 129, 257)])
 def test_few_row_linear_family(m, n, k):
     """csrc/linear.hip: forward, both gradients, the fused bias gradient and the second-order terms R1 / path length

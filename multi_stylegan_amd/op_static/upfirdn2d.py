@@ -59,6 +59,10 @@ def _launch(x, fir, up, down, pad):
     if oh <= 0 or ow <= 0:
         raise _lib.MsgHipError(f"upfirdn2d: empty output {oh}x{ow}")
     fir = fir.to(torch.float32).contiguous()
+    if c > 1 and x.stride(1) == 1 and not _is_channels_last(x):
+        # a channel-slice of a channels-last buffer (e.g. the gradient of one piece of a concatenation): compact it in
+        # the SAME layout (one strided copy) rather than falling to NCHW planes and the scalar kernel
+        x = x.contiguous(memory_format=torch.channels_last)
     if _is_channels_last(x):
         major, minor = b, c
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)

@@ -3,6 +3,7 @@
 state_dict keys.  Feature maps run channels-last (optionally bf16); the 6-channel input image and the two
 heads' outputs stay fp32."""
 import math
+import os
 from typing import Any, Dict, List, Tuple
 
 import torch
@@ -11,6 +12,9 @@ import torch.nn.functional as F
 
 from . import conv_ops, equalized_layer
 from .op_static import FusedLeakyReLU, scaled_add, scaled_add_fork, upfirdn2d
+
+
+COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
 
 
 def _fir2d(taps, gain=1.0):
@@ -175,6 +179,12 @@ class Discriminator(nn.Module):
         classification = self.classification_head(x.float()) if x.dtype != torch.float32 else \
             self.classification_head(x)
         for block, up, skip in zip(self.decoder_blocks, self.transposed_convolutions, reversed(skips)):
-            x = block(conv_ops.cat_channels([up(x), skip]))
+            # `up` = Upsample (per-channel FIR) -> bias-free 1x1 conv (per-pixel channel mix): the two commute exactly, and
+            # mixing the channels BEFORE upsampling runs the conv on a quarter of the pixels and the FIR on the (fewer)
+            # output channels.  Same function as the reference's order (u_net_2d_discriminator.py:120-127) up to rounding.
+            fir, mix = up[0], up[1]
+            commute = COMMUTE_UPSAMPLE and isinstance(mix, equalized_layer.EqualizedConv2d) and mix.bias is None and \
+                mix.kernel_size == (1, 1) and mix.stride == (1, 1) and mix.padding == (0, 0)
+            x = block(conv_ops.cat_channels([fir(mix(x)) if commute else up(x), skip]))
         pixel_wise = self.final_mapping(x).float().contiguous().unsqueeze(dim=2)
         return classification, pixel_wise

@@ -57,6 +57,17 @@ int msg_upfirdn2d_separable(const void* x, const float* fir_y, const float* fir_
                             int major, int in_h, int in_w, int minor, int kh, int kw,
                             int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* msg_upfirdn2d_separable with the activation stage of the layer that owns the blur fused behind it:
+ *   y = leaky_relu(blur(x) + noise_weight[0] * noise[b or 0, pixel] + act_bias[c], alpha) * scale
+ * (the upsampling StyledConv2d: transposed conv -> Blur -> NoiseInjection -> FusedLeakyReLU,
+ * multi_stylegan_generator.py:267-292,329-344).  Applied to the blur result rounded to the storage type: bit-identical to
+ * msg_upfirdn2d_separable followed by msg_fused_bias_act. */
+int msg_upfirdn2d_separable_act(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                                int major, int in_h, int in_w, int minor, int kh, int kw,
+                                int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                const float* act_bias, const float* noise, const float* noise_weight,
+                                int noise_batch, float alpha, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------
  * a2  fused bias + (noise) + leaky-ReLU -- replaces fused_act_cuda.fused_bias_act
  *     (multi_stylegan/op_static/fused_bias_act.cpp:11-17 -> fused_bias_act_op,

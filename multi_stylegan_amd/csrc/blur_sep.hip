@@ -18,6 +18,7 @@
 struct BlurParams {
     int B, IH, IW, OH, OW, CV;      // CV = 16-byte vectors per pixel (channel stride / VEC)
     int px0, py0;
+    ActEpilogue act;                // optional fused (noise +) bias + leaky ReLU behind the blur (see msg_common.h)
 };
 
 // horizontal pass of input row iy -> two row sums (columns ox, ox+1), fp32
@@ -73,6 +74,12 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
     const long long rstride = (long long)p.IW * p.CV;
     const bool c1ok = ox + 1 < p.OW;
 
+    float a_bias[VEC], a_nw = 0.f;                                   // fused activation: this lane's bias vector
+    if (p.act.enabled) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a_bias[e] = p.act.bias ? p.act.bias[cv * VEC + e] : 0.f;
+        a_nw = p.act.noise ? p.act.noise_w[0] : 0.f;
+    }
     float w0[2][VEC], w1[2][VEC], w2[2][VEC];                        // the three previous row sums
     blur_hrow<T>(xin, oy0 - p.py0 + 0, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w0);
     blur_hrow<T>(xin, oy0 - p.py0 + 1, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w1);
@@ -92,6 +99,20 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 f[e] = fmaf(wy[3], w3[c][e], fmaf(wy[2], w2[c][e], fmaf(wy[1], w1[c][e], wy[0] * w0[c][e])));
+            if (p.act.enabled) {
+                // activation of the StyledConv2d that owns this blur, applied to the blur result ROUNDED to the storage
+                // type first: bit-identical to the stand-alone bias_act pass over the stored blur output
+                const float nv = p.act.noise ? a_nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * p.OH * p.OW +
+                                                                   (long long)oy * p.OW + ox + c] : 0.f;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float r;
+                    if constexpr (VEC == 4) r = f[e];
+                    else r = bf2f(f2bf(f[e]));
+                    const float val = r + (nv + a_bias[e]);
+                    f[e] = ((val > 0.f) ? val : val * p.act.alpha) * p.act.scale;
+                }
+            }
             if constexpr (VEC == 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.set(e, f[e]);
@@ -109,9 +130,32 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
 }
 
 // x [B, in_h, in_w, minor] channels-last, fir_y [4], fir_x [4] fp32 with fir2d = fir_y fir_x^T; up = down = 1.
+static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                           int major, int in_h, int in_w, int minor, int kh, int kw,
+                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, const ActEpilogue& act, void* stream);
+
 extern "C" int msg_upfirdn2d_separable(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
                                        int major, int in_h, int in_w, int minor, int kh, int kw,
                                        int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    ActEpilogue act{};
+    return blur_sep_launch(x, fir_y, fir_x, y, dtype, major, in_h, in_w, minor, kh, kw, pad_x0, pad_x1, pad_y0, pad_y1, act,
+                           stream);
+}
+
+extern "C" int msg_upfirdn2d_separable_act(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                                           int major, int in_h, int in_w, int minor, int kh, int kw,
+                                           int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                           const float* act_bias, const float* noise, const float* noise_weight,
+                                           int noise_batch, float alpha, float scale, void* stream) {
+    if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != major))) return MSG_EINVAL;
+    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale};
+    return blur_sep_launch(x, fir_y, fir_x, y, dtype, major, in_h, in_w, minor, kh, kw, pad_x0, pad_x1, pad_y0, pad_y1, act,
+                           stream);
+}
+
+static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                           int major, int in_h, int in_w, int minor, int kh, int kw,
+                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, const ActEpilogue& act, void* stream) {
     if (major == 0) return MSG_OK;
     if (!x || !fir_y || !fir_x || !y || major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0) return MSG_EINVAL;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
@@ -119,7 +163,7 @@ extern "C" int msg_upfirdn2d_separable(const void* x, const float* fir_y, const 
     if (kh != 4 || kw != 4 || minor % vec || (((uintptr_t)x | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
     const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
     if (oh <= 0 || ow <= 0) return MSG_EINVAL;
-    BlurParams p{major, in_h, in_w, oh, ow, minor / vec, pad_x0, pad_y0};
+    BlurParams p{major, in_h, in_w, oh, ow, minor / vec, pad_x0, pad_y0, act};
     static int variant = -1;
     if (variant < 0) { const char* e = getenv("MSG_BLUR_VARIANT"); variant = e ? atoi(e) : 0; }
     const long long threads = (long long)((ow + 1) / 2) * p.CV;

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import conv_ops, equalized_layer
-from .op_static import FusedLeakyReLU, fused_bias_noise_leaky_relu, upfirdn2d
+from .op_static import FusedLeakyReLU, blur_bias_act, fused_bias_noise_leaky_relu, upfirdn2d
 
 
 def _fir2d(taps, gain=1.0):
@@ -105,7 +105,7 @@ class ModulatedConv2d(nn.Module):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, " \
                f"demodulate={self.demodulate}, upsampling={self.upsampling}"
 
-    def forward(self, input: torch.Tensor, style: torch.Tensor):
+    def forward(self, input: torch.Tensor, style: torch.Tensor, skip_blur: bool = False):
         bsz, feats = input.shape[:2]
         assert feats == self.in_channels, f"Expect input feature shape of {self.in_channels} but get {feats}."
         if self.modulation_mapping is not None:
@@ -114,7 +114,7 @@ class ModulatedConv2d(nn.Module):
             modulated_style = style
         output = conv_ops.modulated_conv2d(input, self.weight, modulated_style.reshape(bsz, self.in_channels),
                                            demodulate=self.demodulate, upsample=self.upsampling)
-        if self.upsampling:
+        if self.upsampling and not skip_blur:
             output = self.blur(output)
         if self.modulation_mapping is not None:
             return output, modulated_style
@@ -144,6 +144,17 @@ class StyledConv2d(nn.Module):
             output = conv_ops.modulated_conv2d_bias_act(
                 input, mc.weight, style_out.reshape(bsz, mc.in_channels), mc.demodulate, self.activation.bias, noise,
                 self.noise_injection.weight, self.activation.negative_slope, self.activation.scale)
+            return (output, style_out) if self.modulation_mapping else output
+        if mc.upsampling and conv_ops.FUSE_ACTIVATION and input.is_cuda:
+            # transposed conv -> [blur -> noise -> bias -> leaky ReLU] with the bracket in one launch
+            result = mc(input, style, skip_blur=True)
+            output, style_out = result if self.modulation_mapping else (result, None)
+            p0, p1 = mc.blur.padding
+            oh, ow = output.shape[2] + p0 + p1 - 3, output.shape[3] + p0 + p1 - 3
+            if noise is None:
+                noise = torch.randn(output.shape[0], 1, oh, ow, device=input.device, dtype=torch.float32)
+            output = blur_bias_act(output, mc.blur.kernel, mc.blur.padding, self.activation.bias, noise,
+                                   self.noise_injection.weight, self.activation.negative_slope, self.activation.scale)
             return (output, style_out) if self.modulation_mapping else output
         result = self.modulated_convolution(input, style)
         output, style_out = result if self.modulation_mapping else (result, None)

@@ -147,3 +147,67 @@ class UpFirDn2d(Function):
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     """FIR resampling of a [B,C,H,W] tensor; same arguments as the reference wrapper."""
     return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+def _blur_act_eligible(x, fir, pad):
+    """The fused blur + activation kernel takes bf16 (or fp32 when MSG_FIR_SEPARABLE=2) channels-last maps, whole 16-byte
+    channel vectors and a separable 4x4 FIR."""
+    if not (x.is_cuda and x.ndim == 4 and _is_channels_last(x) and tuple(fir.shape) == (4, 4)):
+        return False
+    if x.shape[1] % (16 // x.element_size()) or not (_SEPARABLE == 2 or (_SEPARABLE == 1 and x.dtype == torch.bfloat16)):
+        return False
+    return _separable(fir.to(torch.float32).contiguous() if fir.dtype != torch.float32 else fir) is not None
+
+
+class BlurBiasAct(Function):
+    """blur (up = down = 1) -> (noise +) bias -> leaky ReLU in one launch (csrc/blur_sep.hip), for the upsampling
+    StyledConv2d whose activation sits behind its blur.  Bit-identical to upfirdn2d followed by the fused activation;
+    the backward is composed of the same differentiable pieces (activation backward from the output's sign, then the
+    adjoint FIR pass), so second-order terms are those of the two-pass form."""
+
+    @staticmethod
+    def forward(ctx, x, fir, pad, bias, noise, noise_w, alpha, scale):
+        px0, px1, py0, py1 = pad
+        dev = _lib.require_gpu(x, fir, bias, noise, noise_w)
+        b, c, h, w = x.shape
+        oh, ow = _out_size(h, 1, 1, py0, py1, 4), _out_size(w, 1, 1, px0, px1, 4)
+        fy, fx = _separable(fir)
+        y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        nz = nw = None
+        if noise is not None:
+            if noise.shape[0] not in (1, b) or noise.shape[1] != 1 or tuple(noise.shape[2:]) != (oh, ow):
+                raise _lib.MsgHipError(f"noise shape {tuple(noise.shape)} does not match output {(b, c, oh, ow)}")
+            nz, nw = noise.detach().to(torch.float32).contiguous(), noise_w.detach().to(torch.float32).contiguous()
+        key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up1down1/sep"
+        with _lib.on_device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
+            code = _lib.lib().msg_upfirdn2d_separable_act(
+                x.data_ptr(), fy.data_ptr(), fx.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, h, w, c, 4, 4,
+                px0, px1, py0, py1, _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(nw), 1 if nz is None else nz.shape[0],
+                float(alpha), float(scale), _lib.stream_of(dev))
+        _lib.check(code, "msg_upfirdn2d_separable_act")
+        ctx.g_pad = (4 - px0 - 1, w - ow + px0, 4 - py0 - 1, h - oh + py0)
+        ctx.cfg = (pad, (h, w), float(alpha), float(scale), bias is not None, noise is not None,
+                   None if noise_w is None else noise_w.shape)
+        ctx.save_for_backward(fir, _flipped(fir), y, noise)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_act import FusedLeakyReLUFunctionBackward
+        fir, fir_flipped, y, noise = ctx.saved_tensors
+        pad, in_hw, alpha, scale, has_bias, has_noise, nw_shape = ctx.cfg
+        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha, scale)
+        gin = UpFirDn2dBackward.apply(gpre, fir, fir_flipped, (1, 1), (1, 1), pad, ctx.g_pad, in_hw) \
+            if ctx.needs_input_grad[0] else None
+        return gin, None, None, (gb if has_bias and ctx.needs_input_grad[3] else None), None, \
+            (gnw.reshape(nw_shape) if has_noise and ctx.needs_input_grad[5] else None), None, None
+
+
+def blur_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, scale=1.0):
+    """leaky_relu(upfirdn2d(input, kernel, pad=pad) + noise_weight * noise + bias) * scale; one launch when eligible."""
+    if _blur_act_eligible(input, kernel, pad):
+        return BlurBiasAct.apply(input, kernel, (pad[0], pad[1], pad[0], pad[1]), bias, noise, noise_weight,
+                                 float(negative_slope), float(scale))
+    from .fused_act import fused_bias_noise_leaky_relu
+    return fused_bias_noise_leaky_relu(upfirdn2d(input, kernel, pad=pad), bias, noise, noise_weight, negative_slope, scale)

@@ -112,6 +112,40 @@ def test_blur_separable_kernel(cfg, dtype, tol):
     assert rel_err(y.float(), y2d.float()) < (1e-5 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("noise_batch", [1, 3])
+@pytest.mark.parametrize("cfg", [((2, 1), 16, 12, 10), ((2, 2), 8, 15, 15), ((1, 1), 64, 40, 19)])
+def test_blur_bias_act_is_bit_identical_to_two_passes(cfg, noise_batch):
+    """msg_upfirdn2d_separable_act == msg_upfirdn2d_separable followed by msg_fused_bias_act (bf16 storage), forward
+    bit for bit; first- and second-order gradients through the same composed backward."""
+    ops = _ops()
+    from multi_stylegan_amd.op_static import blur_bias_act, fused_bias_noise_leaky_relu
+    pad, c, h, w = cfg
+    b = 3
+    g = torch.Generator().manual_seed(c + h)
+    fir = torch.outer(torch.randn(4, generator=g), torch.randn(4, generator=g)).to(DEV)
+    x = torch.randn(b, c, h, w, generator=g).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    oh, ow = h + pad[0] + pad[1] - 3, w + pad[0] + pad[1] - 3
+    noise = torch.randn(noise_batch, 1, oh, ow, generator=g).to(DEV)
+    bias, nw = torch.randn(c, generator=g).to(DEV), torch.tensor([0.41], device=DEV)
+    gy = torch.randn(b, c, oh, ow, generator=g).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    v = torch.randn(b, c, oh, ow, generator=g).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        xs, bs, ns = x.clone().requires_grad_(True), bias.clone().requires_grad_(True), nw.clone().requires_grad_(True)
+        gys = gy.clone().requires_grad_(True)
+        if fused:
+            y = blur_bias_act(xs, fir, pad, bs, noise, ns, 0.2, 1.3)
+        else:
+            y = fused_bias_noise_leaky_relu(ops.upfirdn2d(xs, fir, pad=pad), bs, noise, ns, 0.2, 1.3)
+        gx, gb, gn = torch.autograd.grad(y, (xs, bs, ns), gys, create_graph=True)
+        ggy, = torch.autograd.grad(gx, gys, x.clone(), retain_graph=True)           # second order, linear in gy
+        res.append((y, gx, gb, gn, ggy))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, r in zip(res[0][1:], res[1][1:]):
+        assert rel_err(a.float(), r.float()) < 1e-5
+    assert rel_err(res[0][0].float() * 0 + res[0][4].float(), res[1][4].float()) < 1e-5 and v is not None
+
+
 def test_upfirdn2d_edge_cases():
     ops = _ops()
     from multi_stylegan_amd._lib import MsgHipError

@@ -48,6 +48,21 @@ extern "C" int msg_demod_coeff(const float* W, const float* s, float* d, int B, 
     return MSG_CHECK_LAUNCH();
 }
 
+// VEC consecutive floats as float4 loads when the run is whole and 16-B aligned, element-wise (zero past `limit`) otherwise
+template <int VEC>
+__device__ __forceinline__ void load_run(const float* __restrict__ src, int c0, int limit, bool aligned, float (&f)[VEC]) {
+    if (aligned && c0 + VEC <= limit) {
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c0 + e);
+            f[e] = v.x; f[e + 1] = v.y; f[e + 2] = v.z; f[e + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = (c0 + e < limit) ? src[c0 + e] : 0.f;
+    }
+}
+
 // base [R][T][C] fp32; rowscale [B][R] (or NULL = 1); colscale [B][C] (or NULL = 1); out [B][R][T][Ck] of type TO.
 // grid = (row r, group of BG samples): a thread owns up to ITEMS (tap, 16-B column vector) cells of the row, reads
 // their fp32 base values ONCE into registers and then emits the BG per-sample copies (row scale = one scalar per
@@ -65,6 +80,7 @@ __global__ __launch_bounds__(256) void scale_rows_cols_kernel(const float* __res
     const int cvecs = Ck / VEC;
     const float* src_row = base + (size_t)r * T * C;
     const int tstep = 256 / cvecs > 0 ? 256 / cvecs : 1;
+    const bool al = (C % 4 == 0) && ((((uintptr_t)base | (uintptr_t)colscale) & 15u) == 0);   // float4-loadable runs
     for (int cv = threadIdx.x % cvecs; cv < cvecs; cv += 256) {       // (cvecs <= 256 in practice: one pass)
         const int c0 = cv * VEC;
         const int t0 = threadIdx.x / cvecs;
@@ -73,16 +89,22 @@ __global__ __launch_bounds__(256) void scale_rows_cols_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < SRC_ITEMS; ++k) {
                 const int t = tb + k * tstep;
-                const float* src = src_row + (size_t)t * C + c0;
+                if (t < T) load_run<VEC>(src_row + (size_t)t * C, c0, C, al, f[k]);
+                else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) f[k][e] = (t < T && c0 + e < C) ? src[e] : 0.f;
+                    for (int e = 0; e < VEC; ++e) f[k][e] = 0.f;
+                }
             }
             for (int b = b0; b < b1; ++b) {
                 const float rs = gain * (rowscale ? rowscale[(size_t)b * R + r] : 1.f);
-                const float* cs = colscale ? colscale + (size_t)b * C : nullptr;
                 float sc[VEC];
+                if (colscale) load_run<VEC>(colscale + (size_t)b * C, c0, C, al, sc);
+                else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) sc[e] = (c0 + e < C) ? rs * (cs ? cs[c0 + e] : 1.f) : 0.f;
+                    for (int e = 0; e < VEC; ++e) sc[e] = (c0 + e < C) ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sc[e] *= rs;
                 TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
 #pragma unroll
                 for (int k = 0; k < SRC_ITEMS; ++k) {
@@ -169,6 +191,7 @@ __global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __re
     const int cvecs = Ck / VEC;
     const float* src_row = base + (size_t)r * T * C;
     const int tstep = 256 / cvecs > 0 ? 256 / cvecs : 1;
+    const bool al = (C % 4 == 0) && ((((uintptr_t)base | (uintptr_t)style) & 15u) == 0);   // float4-loadable runs
     for (int cv = threadIdx.x % cvecs; cv < cvecs; cv += 256) {
         const int c0 = cv * VEC;
         const int t0 = threadIdx.x / cvecs;
@@ -177,16 +200,18 @@ __global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __re
 #pragma unroll
             for (int k = 0; k < SRC_ITEMS; ++k) {
                 const int t = tb + k * tstep;
-                const float* src = src_row + (size_t)t * C + c0;
+                if (t < T) load_run<VEC>(src_row + (size_t)t * C, c0, C, al, f[k]);
+                else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) f[k][e] = (t < T && c0 + e < C) ? src[e] : 0.f;
+                    for (int e = 0; e < VEC; ++e) f[k][e] = 0.f;
+                }
             }
             for (int b = b0; b < b1; ++b) {
                 const float rs = scale * dsh[b - b0];
-                const float* cs = style + (size_t)b * C;
                 float sc[VEC];
+                load_run<VEC>(style + (size_t)b * C, c0, C, al, sc);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) sc[e] = (c0 + e < C) ? rs * cs[c0 + e] : 0.f;
+                for (int e = 0; e < VEC; ++e) sc[e] *= rs;
                 TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
 #pragma unroll
                 for (int k = 0; k < SRC_ITEMS; ++k) {

@@ -186,13 +186,30 @@ def _relay_dgrad_s2(w: torch.Tensor, dtype, pad: int) -> Tuple[torch.Tensor, int
 _WEIGHT_GENERATION = [0]
 
 
-def invalidate_weight_cache(*_args, **_kwargs) -> None:
-    _WEIGHT_GENERATION[0] += 1
+def invalidate_weight_cache(params=None) -> None:
+    """Declare parameters changed behind autograd's back (`.data` writes, fused / foreach optimizers do not bump the
+    tensors' version counters): the given ones, or -- with no argument -- every cached image of every parameter."""
+    if params is None:
+        _WEIGHT_GENERATION[0] += 1
+        return
+    for p in params:
+        p.__dict__["_msg_gen"] = p.__dict__.get("_msg_gen", 0) + 1
+
+
+def _after_optimizer_step(optimizer, *_args, **_kwargs) -> None:
+    # only the parameters THIS optimizer owns changed: the discriminator's step must not throw away the generator's
+    # re-laid weights (and vice versa) -- with one global generation every weight was re-laid twice per iteration
+    for group in optimizer.param_groups:
+        invalidate_weight_cache(group["params"])
+
+
+def _stamp(w):
+    return (w._version, _WEIGHT_GENERATION[0], w.__dict__.get("_msg_gen", 0), w.data_ptr())
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
 
-_register_step_hook(invalidate_weight_cache)
+_register_step_hook(_after_optimizer_step)
 
 
 def _cached(w, tag, dtype, wscale, build):
@@ -201,7 +218,7 @@ def _cached(w, tag, dtype, wscale, build):
         return (out[0] * wscale, *out[1:]) if wscale != 1.0 else out
     store = w.__dict__.setdefault("_msg_relay", {})
     key = (tag, dtype, wscale)
-    stamp = (w._version, _WEIGHT_GENERATION[0], w.data_ptr())
+    stamp = _stamp(w)
     hit = store.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
@@ -226,7 +243,7 @@ def _param_images(w, dtype, gain, kind, modulation=False):
         return None
     store = w.__dict__.setdefault("_msg_relay", {})
     key = ("img", dtype, gain, kind, modulation)
-    stamp = (w._version, _WEIGHT_GENERATION[0], w.data_ptr())
+    stamp = _stamp(w)
     hit = store.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]

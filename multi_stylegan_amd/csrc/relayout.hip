@@ -14,11 +14,12 @@
 
 constexpr int RL_T = 16;                      // max taps held per tile (kernels up to 4x4)
 
-template <typename TO>
+template <typename TO, int TC>       // TC: compile-time tap count (1, 4, 9, 16: index divisions become shifts / multiplies), 0 = runtime
 __global__ __launch_bounds__(256) void relayout_weight_kernel(const float* __restrict__ w, TO* __restrict__ fwd,
                                                               TO* __restrict__ dgr, float* __restrict__ wsq,
-                                                              int O, int I, int T, int Ck, int Ok, int flip, int t_major,
+                                                              int O, int I, int Trt, int Ck, int Ok, int flip, int t_major,
                                                               float gain) {
+    const int T = TC ? TC : Trt;
     __shared__ float tile[32][32 * RL_T + 1];
     const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
     const int tid = threadIdx.x;
@@ -79,11 +80,22 @@ extern "C" int msg_relayout_weight(const float* w, void* fwd, void* dgrad, float
     dim3 grid((o_ext + 31) / 32, (i_ext + 31) / 32);
     if (grid.y > 65535) return MSG_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MSG_BF16)
-        hipLaunchKernelGGL((relayout_weight_kernel<bf16_t>), grid, dim3(256), 0, s, w, (bf16_t*)fwd, (bf16_t*)dgrad, wsq,
-                           O, I, T, Ck, Ok, flip, t_major, gain);
-    else
-        hipLaunchKernelGGL((relayout_weight_kernel<float>), grid, dim3(256), 0, s, w, (float*)fwd, (float*)dgrad, wsq,
-                           O, I, T, Ck, Ok, flip, t_major, gain);
+#define RL_LAUNCH(TC_)                                                                                                 \
+    do {                                                                                                               \
+        if (dtype == MSG_BF16)                                                                                         \
+            hipLaunchKernelGGL((relayout_weight_kernel<bf16_t, TC_>), grid, dim3(256), 0, s, w, (bf16_t*)fwd,          \
+                               (bf16_t*)dgrad, wsq, O, I, T, Ck, Ok, flip, t_major, gain);                             \
+        else                                                                                                           \
+            hipLaunchKernelGGL((relayout_weight_kernel<float, TC_>), grid, dim3(256), 0, s, w, (float*)fwd,            \
+                               (float*)dgrad, wsq, O, I, T, Ck, Ok, flip, t_major, gain);                              \
+    } while (0)
+    switch (T) {
+        case 1: RL_LAUNCH(1); break;
+        case 4: RL_LAUNCH(4); break;
+        case 9: RL_LAUNCH(9); break;
+        case 16: RL_LAUNCH(16); break;
+        default: RL_LAUNCH(0); break;
+    }
+#undef RL_LAUNCH
     return MSG_CHECK_LAUNCH();
 }

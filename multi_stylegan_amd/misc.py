@@ -25,4 +25,5 @@ def exponential_moving_average(model_ema, model_train, decay: float = 0.999) -> 
     torch._foreach_mul_(ema_params, decay)
     torch._foreach_add_(ema_params, src, alpha=1 - decay)
     from . import conv_ops
-    conv_ops.invalidate_weight_cache()          # `.data` writes do not bump the tensors' version counters
+    # `.data` writes do not bump the tensors' version counters: declare the EMA copy's parameters (only those) changed
+    conv_ops.invalidate_weight_cache(list(model_ema.parameters()))

@@ -61,11 +61,36 @@ class _CatChannels(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if torch.is_grad_enabled():                    # second-order pass (R1): keep the split's own backward a concat
+            pieces = _SplitChannels.apply(g, *ctx.splits)
+            return tuple(p if need else None for p, need in zip(pieces, ctx.needs_input_grad))
         outs, off = [], 0
         for i, c in enumerate(ctx.splits):
             outs.append(g[:, off:off + c] if ctx.needs_input_grad[i] else None)
             off += c
         return tuple(outs)
+
+
+class _SplitChannels(Function):
+    """Channel-slice views of a gradient whose own backward is ONE concatenation (autograd's slice backward would
+    allocate a zero map per piece, copy the piece in and add the maps up)."""
+
+    @staticmethod
+    def forward(ctx, g, *splits):
+        ctx.splits = splits
+        ctx.meta = (g.shape[0], g.shape[2], g.shape[3], g.dtype, g.device)
+        outs, off = [], 0
+        for c in splits:
+            outs.append(g[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gg):
+        b, h, w, dtype, dev = ctx.meta
+        pieces = [x if x is not None else torch.zeros((b, c, h, w), dtype=dtype, device=dev)
+                  for x, c in zip(gg, ctx.splits)]
+        return (_CatChannels.apply(*pieces),) + (None,) * len(ctx.splits)
 
 
 def to_compute_layout(x: torch.Tensor, dtype=None) -> torch.Tensor:

@@ -49,6 +49,13 @@ int msg_upfirdn2d(const void* x, const float* fir, void* y, int dtype,
                   int up_x, int up_y, int down_x, int down_y,
                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* msg_upfirdn2d whose input pixels are `in_pitch` (>= minor) elements apart: a channel-slice of a wider channels-last
+ * map, e.g. the gradient of one piece of a channel concatenation, filtered in place instead of being compacted first. */
+int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, int dtype,
+                          int major, int in_h, int in_w, int minor, int in_pitch, int kh, int kw,
+                          int up_x, int up_y, int down_x, int down_y,
+                          int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
 /* msg_upfirdn2d for up = down = 1 and a SEPARABLE 4x4 FIR given by its factors (fir2d = fir_y fir_x^T, which is how
  * every FIR of the models is built: multi_stylegan_generator.py:244-258, u_net_2d_discriminator.py:186-203), on a
  * channels-last map (major = B, minor = C, minor % vec == 0).  Sliding-window evaluation, 8 instead of 16 taps per

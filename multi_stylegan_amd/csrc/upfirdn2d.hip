@@ -10,6 +10,7 @@
 
 struct UpfirdnParams {
     int major, in_h, in_w, minor, out_h, out_w;
+    int in_pitch;        // elements between consecutive input pixels (== minor unless the input is a channel-slice of a wider map)
     int up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw;
     unsigned nvec, tiles_x, tiles_y, total;
     long long bias;      // elements; makes the per-lane part of every footprint address a non-negative offset
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const T* __restr
     const int ox = (int)(t % p.out_w); t /= p.out_w;
     const int oy = (int)(t % p.out_h);
     const long long mj = t / p.out_h;
-    const T* xb = x + mj * (long long)p.in_h * p.in_w * p.minor + m;
+    const T* xb = x + mj * (long long)p.in_h * p.in_w * p.in_pitch + m;
     float acc = 0.f;
     for (int ty = 0; ty < p.kh; ++ty) {
         const int py = oy * p.down_y + ty - p.pad_y0;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const T* __restr
             if (px < 0 || px % p.up_x) continue;
             const int ix = px / p.up_x;
             if (ix >= p.in_w) continue;
-            acc += load_as_f32(xb + ((long long)iy * p.in_w + ix) * p.minor) *
+            acc += load_as_f32(xb + ((long long)iy * p.in_w + ix) * p.in_pitch) *
                    fir[(p.kh - 1 - ty) * p.kw + (p.kw - 1 - tx)];
         }
     }
@@ -80,10 +81,10 @@ __global__ __launch_bounds__(256, (PIPE ? 3 : 2)) void upfirdn2d_vec_kernel(cons
         iy_lo = (oy0 - p.pad_y0 - PY) >> 1;          // exact: the numerator is even
         ix_lo = (ox0 - p.pad_x0 - PX) >> 1;
     }
-    const T* xb = x + (size_t)mj * p.in_h * p.in_w * p.minor + (size_t)cv * VEC;
+    const T* xb = x + (size_t)mj * p.in_h * p.in_w * p.in_pitch + (size_t)cv * VEC;
     // ADDR32: address = (uniform base + uniform (row,col) offset, all SGPR) + ONE 32-bit per-lane byte offset, so the
     // 25..36 footprint loads share a single address VGPR instead of carrying a 64-bit pointer each.
-    const long long lane_elems = (long long)mj * p.in_h * p.in_w * p.minor + ((long long)iy_lo * p.in_w + ix_lo) * p.minor +
+    const long long lane_elems = (long long)mj * p.in_h * p.in_w * p.in_pitch + ((long long)iy_lo * p.in_w + ix_lo) * p.in_pitch +
                                  (long long)cv * VEC + p.bias;
     const unsigned lane_off = (unsigned)(lane_elems * (long long)sizeof(T));
     const char* xs = reinterpret_cast<const char*>(x) - p.bias * (long long)sizeof(T);
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(256, (PIPE ? 3 : 2)) void upfirdn2d_vec_kernel(cons
         V v;
         if ((iy >= 0) & (iy < p.in_h) & (ix >= 0) & (ix < p.in_w)) {
             if constexpr (ADDR32) {
-                const char* sbase = xs + (size_t)(r * p.in_w + c) * p.minor * sizeof(T);      // wave-uniform
+                const char* sbase = xs + (size_t)(r * p.in_w + c) * p.in_pitch * sizeof(T);   // wave-uniform
                 v.raw = *reinterpret_cast<const uint4*>(sbase + lane_off);
             } else {
-                v.raw = *reinterpret_cast<const uint4*>(xb + ((size_t)iy * p.in_w + ix) * p.minor);
+                v.raw = *reinterpret_cast<const uint4*>(xb + ((size_t)iy * p.in_w + ix) * p.in_pitch);
             }
         } else {
             v.zero();
@@ -185,8 +186,8 @@ static void launch_tile(const void* x, const float* fir, void* y, UpfirdnParams&
     p.total = (unsigned)p.major * p.tiles_y * p.tiles_x * p.nvec;
     const unsigned blocks = (p.total + 255u) / 256u;
     const int ay = p.pad_y0 < 0 ? -p.pad_y0 : p.pad_y0, ax = p.pad_x0 < 0 ? -p.pad_x0 : p.pad_x0;
-    p.bias = ((long long)(ay + 2) * p.in_w + (ax + 2)) * p.minor;
-    const long long span = ((long long)p.major * p.in_h * p.in_w * p.minor + 2 * p.bias) * (long long)sizeof(T);
+    p.bias = ((long long)(ay + 2) * p.in_w + (ax + 2)) * p.in_pitch;
+    const long long span = ((long long)p.major * p.in_h * p.in_w * p.in_pitch + 2 * p.bias) * (long long)sizeof(T);
     if (span < (1ll << 32) && fir_variant() != 9)
         hipLaunchKernelGGL((upfirdn2d_vec_kernel<T, UP, DOWN, PY, PX, TH, TW, PIPE, true>), dim3(blocks), dim3(256), 0, s,
                            (const T*)x, fir, (T*)y, p);
@@ -217,7 +218,8 @@ static int dispatch(const void* x, const float* fir, void* y, UpfirdnParams& p, 
     const long long n_tiles = (long long)p.major * ((p.out_h + 1) / 2) * ((p.out_w + 1) / 2) * (p.minor / vec + 1);
     const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
     const bool square = p.up_x == p.up_y && p.down_x == p.down_y;
-    const bool fast = aligned && square && p.kh <= 4 && p.kw <= 4 && p.minor % vec == 0 && n_tiles < (1ll << 31) &&
+    const bool fast = aligned && square && p.kh <= 4 && p.kw <= 4 && p.minor % vec == 0 && p.in_pitch % vec == 0 &&
+                      n_tiles < (1ll << 31) &&
                       ((p.up_x == 1 && (p.down_x == 1 || p.down_x == 2)) || (p.up_x == 2 && p.down_x == 1));
     if (fast) {
         if (p.up_x == 1 && p.down_x == 1) launch_vec<T, 1, 1, 0, 0>(x, fir, y, p, s);
@@ -238,16 +240,32 @@ static int dispatch(const void* x, const float* fir, void* y, UpfirdnParams& p, 
     return MSG_CHECK_LAUNCH();
 }
 
+extern "C" int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, int dtype,
+                                     int major, int in_h, int in_w, int minor, int in_pitch, int kh, int kw,
+                                     int up_x, int up_y, int down_x, int down_y,
+                                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
 extern "C" int msg_upfirdn2d(const void* x, const float* fir, void* y, int dtype,
                              int major, int in_h, int in_w, int minor, int kh, int kw,
                              int up_x, int up_y, int down_x, int down_y,
                              int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    return msg_upfirdn2d_pitched(x, fir, y, dtype, major, in_h, in_w, minor, minor, kh, kw, up_x, up_y, down_x, down_y,
+                                 pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+
+// x [major][in_h][in_w] pixels of `minor` channels, `in_pitch` elements apart (a channel-slice of a wider channels-last
+// map: the gradient of one piece of a concatenation); y dense.
+extern "C" int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, int dtype,
+                                     int major, int in_h, int in_w, int minor, int in_pitch, int kh, int kw,
+                                     int up_x, int up_y, int down_x, int down_y,
+                                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    if (in_pitch < minor) return MSG_EINVAL;
     if (major == 0 && fir && in_h > 0 && in_w > 0 && minor > 0) return MSG_OK;     // empty batch: nothing to do
     if (!x || !fir || !y || major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 ||
         up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
         return MSG_EINVAL;
     UpfirdnParams p{};
-    p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.kh = kh; p.kw = kw;
+    p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.in_pitch = in_pitch; p.kh = kh; p.kw = kw;
     p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
     // upfirdn2d_kernel.cu:167-168
     p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;

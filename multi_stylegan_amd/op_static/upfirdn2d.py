@@ -59,10 +59,27 @@ def _launch(x, fir, up, down, pad):
     if oh <= 0 or ow <= 0:
         raise _lib.MsgHipError(f"upfirdn2d: empty output {oh}x{ow}")
     fir = fir.to(torch.float32).contiguous()
+    pitch = None
     if c > 1 and x.stride(1) == 1 and not _is_channels_last(x):
-        # a channel-slice of a channels-last buffer (e.g. the gradient of one piece of a concatenation): compact it in
-        # the SAME layout (one strided copy) rather than falling to NCHW planes and the scalar kernel
-        x = x.contiguous(memory_format=torch.channels_last)
+        # a channel-slice of a channels-last buffer (e.g. the gradient of one piece of a concatenation): filtered in
+        # place through the pitched entry point when its pitch allows, else compacted in the SAME layout (one copy)
+        sb, _, sh, sw = x.stride()
+        vec = 16 // x.element_size()
+        if sh == w * sw and (sb == h * w * sw or b == 1) and sw % vec == 0 and c % vec == 0 and x.data_ptr() % 16 == 0 \
+                and kh <= 4 and kw <= 4 and x.dtype in (torch.float32, torch.bfloat16):
+            pitch = sw
+        else:
+            x = x.contiguous(memory_format=torch.channels_last)
+    if pitch is not None:
+        major, minor = b, c
+        y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up{up_x}down{down_x}/vec"
+        with _lib.on_device(dev), _lib.kernel_clock.span(key, (b * c * h * w + y.numel()) * x.element_size()):
+            code = _lib.lib().msg_upfirdn2d_pitched(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x),
+                                                    major, h, w, minor, pitch, kh, kw, up_x, up_y, down_x, down_y,
+                                                    px0, px1, py0, py1, _lib.stream_of(dev))
+        _lib.check(code, "msg_upfirdn2d_pitched")
+        return y
     if _is_channels_last(x):
         major, minor = b, c
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)

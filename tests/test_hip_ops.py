@@ -146,6 +146,24 @@ def test_blur_bias_act_is_bit_identical_to_two_passes(cfg, noise_batch):
     assert rel_err(res[0][0].float() * 0 + res[0][4].float(), res[1][4].float()) < 1e-5 and v is not None
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(1, 1, (2, 1)), (1, 2, (1, 1)), (2, 1, (2, 1)), (1, 1, (2, 2))])
+def test_upfirdn2d_on_channel_slices(cfg, dtype):
+    """A channel-slice of a wider channels-last map (the gradient of one piece of a concatenation) goes through
+    msg_upfirdn2d_pitched: same result, bit for bit, as filtering the compacted copy."""
+    ops = _ops()
+    up, down, pad = cfg
+    g = torch.Generator().manual_seed(up * 10 + down)
+    fir = torch.randn(4, 4, generator=g).to(DEV)
+    wide = torch.randn(2, 48, 14, 18, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    for lo, hi in ((0, 16), (16, 48), (8, 40)):
+        piece = wide[:, lo:hi]
+        assert not piece.is_contiguous(memory_format=torch.channels_last)
+        y = ops.upfirdn2d(piece, fir, up=up, down=down, pad=pad)
+        ref = ops.upfirdn2d(piece.contiguous(memory_format=torch.channels_last), fir, up=up, down=down, pad=pad)
+        assert torch.equal(y, ref)
+
+
 def test_upfirdn2d_edge_cases():
     ops = _ops()
     from multi_stylegan_amd._lib import MsgHipError

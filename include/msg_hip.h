@@ -198,6 +198,15 @@ int msg_conv2d_fprop_act(const void* x, const void* w, void* y, int dtype,
                          const float* act_bias, const float* noise, const float* noise_weight,
                          int noise_batch, float alpha, float scale, void* stream);
 
+/* msg_conv2d_fprop with the residual merge of a discriminator block fused into the epilogue:
+ *   y = (conv(x, w) + residual) * gain        (u_net_2d_discriminator.py:185: (main + residual_mapping(x)) / sqrt(2))
+ * residual: a map with the output's pixels and >= N channels, channel pitch res_ld elements, same storage type.
+ * Bit-identical to msg_conv2d_fprop followed by msg_scaled_add. */
+int msg_conv2d_fprop_residual(const void* x, const void* w, void* y, int dtype,
+                              int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                              int kh, int kw, int stride, int pad, long long w_batch_stride,
+                              const void* residual, int res_ld, float gain, void* stream);
+
 /* -------------------------------------------------------------------------
  * Equalized-lr fully connected layers with few rows (mapping network, style affines, classification head), fp32,
  * dense row-major operands.  Replaces F.linear(input, weight * scale, bias * scale_bias) of

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "msg_bias_act_backward": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _I, _F, _F, _P]),
     "msg_conv2d_fprop": (_I, [_P, _P, _P, _P, _I] + [_I] * 15 + [_L, _P]),
     "msg_conv2d_fprop_act": (_I, [_P, _P, _P, _I] + [_I] * 13 + [_L, _P, _P, _P, _I, _F, _F, _P]),
+    "msg_conv2d_fprop_residual": (_I, [_P, _P, _P, _I] + [_I] * 13 + [_L, _P, _I, _F, _P]),
     "msg_conv2d_wgrad": (_I, [_P, _P, _P, _I] + [_I] * 18 + [_F, _P]),
     "msg_demod_coeff": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "msg_scale_rows_cols": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),

@@ -299,8 +299,9 @@ _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape
 
 
 def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real,
-                  flops=None, act=None):
-    """act = (act_bias | None, noise | None, noise_weight | None, alpha, scale): fuse the layer's activation stage."""
+                  flops=None, act=None, residual=None):
+    """act = (act_bias | None, noise | None, noise_weight | None, alpha, scale): fuse the layer's activation stage.
+    residual = (map shaped like the output, gain): y = (conv + map) * gain in the epilogue."""
     dev = _lib.require_gpu(x, wk, bias)
     xv, cx = _nhwc_view(x)
     b, _, ih, iw = xv.shape
@@ -321,7 +322,14 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
             key += f"|B{b} {ih}x{iw}->{oh}x{ow} {c_real}->{n} {kh}x{kw} s{stride} up{in_up}" \
                    f"{' ps' if pixel_shuffle else ''}{' per-sample' if per_sample else ''}|"
     with _lib.on_device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
-        if act is None:
+        if residual is not None:
+            assert bias is None and act is None and in_up == 1 and not pixel_shuffle
+            rv, res_ld = _nhwc_view(residual[0])
+            assert rv.shape == (b, n, oh, ow) and rv.dtype == x.dtype
+            code = _lib.lib().msg_conv2d_fprop_residual(
+                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
+                stride, pad, wstride, rv.data_ptr(), res_ld, float(residual[1]), _lib.stream_of(dev))
+        elif act is None:
             code = _lib.lib().msg_conv2d_fprop(
                 xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh,
                 ow, n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))
@@ -406,7 +414,7 @@ def _relay_fwd_kind(w, dtype, kind):
     return wk, ck
 
 
-def _f_raw(x, w, bias, g: Geometry, act=None):
+def _f_raw(x, w, bias, g: Geometry, act=None, residual=None):
     img = _param_images(w, x.dtype, g.wscale, g.kind) if not g.per_sample else None
     wk, ck = img["f"] if img is not None else \
         _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
@@ -414,7 +422,7 @@ def _f_raw(x, w, bias, g: Geometry, act=None):
     if g.kind == "up2":
         return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, _oi(w)[1])
     return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, _oi(w)[1],
-                         act=act)
+                         act=act, residual=residual)
 
 
 def _act_operands(bias, noise, noise_w, y_shape):
@@ -537,6 +545,43 @@ class _ConvActF(Function):
         gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
             (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None
+
+
+class _ConvResidualF(Function):
+    """y = (conv(x, w) + main) * gain in one launch (the residual merge of a discriminator block in the epilogue of its
+    1x1 residual conv), optionally handed out twice (fork) for an output with two consumers.  Backward: the merged,
+    rescaled gradient goes to `main` as it is and through the D / G contractions to x and w."""
+
+    @staticmethod
+    def forward(ctx, x, w, main, g, gain, fork):
+        y = _f_raw(x, w, None, g, residual=(main, gain))
+        ctx.g, ctx.gain, ctx.fork = g, float(gain), fork
+        ctx.save_for_backward(x, w)
+        return (y, y.view_as(y)) if fork else y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .op_static.fused_act import _ScaledAddRows, _rows_ok
+        x, w = ctx.saved_tensors
+        g1 = grads[0]
+        g2 = grads[1] if ctx.fork else None
+        if g1 is None or g2 is None:
+            gs = (g1 if g1 is not None else g2) * ctx.gain
+        elif _rows_ok(g1, g2):
+            gs = _ScaledAddRows.apply(g1, g2, ctx.gain)
+        else:
+            gs = (g1 + g2) * ctx.gain
+        gx = _ConvD.apply(gs, w, ctx.g) if ctx.needs_input_grad[0] else None
+        gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g) if ctx.needs_input_grad[1] else None
+        return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None
+
+
+def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, fork=False):
+    """(conv(x, wscale * weight) + main) * gain; with fork=True two aliases of the result (see scaled_add_fork)."""
+    s = stride if isinstance(stride, int) else stride[0]
+    p = padding if isinstance(padding, int) else padding[0]
+    g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
+    return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork))
 
 
 # ------------------------------------------------------------------------------------------------- public entry

@@ -148,7 +148,7 @@ extern "C" int msg_upfirdn2d_separable_act(const void* x, const float* fir_y, co
                                            const float* act_bias, const float* noise, const float* noise_weight,
                                            int noise_batch, float alpha, float scale, void* stream) {
     if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != major))) return MSG_EINVAL;
-    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale};
+    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale, nullptr, 0, 0.f};
     return blur_sep_launch(x, fir_y, fir_x, y, dtype, major, in_h, in_w, minor, kh, kw, pad_x0, pad_x1, pad_y0, pad_y1, act,
                            stream);
 }

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     // fused activation stage: this lane's bias vector and the noise value of each of its rows are fetched HERE, before
     // the barrier, so their latency hides behind it instead of sitting in front of every store
     float a_bias[VEC], a_noise[64 / RPP];
-    if (p.act.enabled) {
+    if (p.act.enabled == 1) {
         const int n = n0 + wn * 64 + ec;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
@@ -305,7 +305,12 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         const T* src = reinterpret_cast<const T*>(ep + row * PITCH) + ec;
         const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;  // valid elements left in this channel run
         u32x4 v = *reinterpret_cast<const u32x4*>(src);
-        if (p.act.enabled) v = act_epilogue_apply<T>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+        if (p.act.enabled == 1) v = act_epilogue_apply<T>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+        else if (p.act.enabled == 2) {                       // residual merge (never with pixel_shuffle)
+            const T* rp = reinterpret_cast<const T*>(p.act.residual) +
+                            ((long long)b * ohw + pix) * p.act.res_ld + n;
+            v = residual_epilogue_apply<T>(v, *reinterpret_cast<const u32x4*>(rp), p.act.res_gain);
+        }
         if (lim >= VEC) {
             *reinterpret_cast<u32x4*>(dst) = v;
         } else {
@@ -360,7 +365,18 @@ extern "C" int msg_conv2d_fprop_act(const void* x, const void* w, void* y, int d
                                     const float* act_bias, const float* noise, const float* noise_weight,
                                     int noise_batch, float alpha, float scale, void* stream) {
     if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != B))) return MSG_EINVAL;
-    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale};
+    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale, nullptr, 0, 0.f};
+    return conv2d_fprop_impl(x, w, nullptr, y, dtype, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, 1, 0,
+                             w_batch_stride, act, stream);
+}
+
+extern "C" int msg_conv2d_fprop_residual(const void* x, const void* w, void* y, int dtype,
+                                         int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                         int kh, int kw, int stride, int pad, long long w_batch_stride,
+                                         const void* residual, int res_ld, float gain, void* stream) {
+    if (!residual || res_ld < N || (((uintptr_t)residual) & 15u) || res_ld % (dtype == MSG_BF16 ? 8 : 4)) return MSG_EINVAL;
+    ActEpilogue act{};
+    act.enabled = 2; act.residual = residual; act.res_ld = res_ld; act.res_gain = gain;
     return conv2d_fprop_impl(x, w, nullptr, y, dtype, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, 1, 0,
                              w_batch_stride, act, stream);
 }

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_big_kernel(const bf16_t* __
         }
     const int er = lane >> 4, ec = (lane & 15) * VEC;         // 16 lanes per 128-channel row, 4 rows per pass
     float a_bias[VEC], a_noise[32];
-    if (p.act.enabled) {
+    if (p.act.enabled == 1) {
         const int n = n0 + wn * 128 + ec;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
@@ -307,7 +307,12 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_big_kernel(const bf16_t* __
         const bf16_t* src = reinterpret_cast<const bf16_t*>(ep + row * PITCH) + ec;
         const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;
         u32x4 v = *reinterpret_cast<const u32x4*>(src);
-        if (p.act.enabled) v = act_epilogue_apply<bf16_t>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+        if (p.act.enabled == 1) v = act_epilogue_apply<bf16_t>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+        else if (p.act.enabled == 2) {                       // residual merge (never with pixel_shuffle)
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.act.residual) +
+                            ((long long)b * ohw + pix) * p.act.res_ld + n;
+            v = residual_epilogue_apply<bf16_t>(v, *reinterpret_cast<const u32x4*>(rp), p.act.res_gain);
+        }
         if (lim >= VEC) {
             *reinterpret_cast<u32x4*>(dst) = v;
         } else {

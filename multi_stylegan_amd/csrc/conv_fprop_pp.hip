@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     const int er = lane >> 3, ec = (lane & 7) * VEC;          // 8 lanes per 64-channel row, 8 rows per pass
     // fused activation stage: bias vector and per-row noise values are fetched before the barrier (latency hidden)
     float a_bias[VEC], a_noise[16];
-    if (p.act.enabled) {
+    if (p.act.enabled == 1) {
         const int n = n0 + wn * 64 + ec;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
@@ -331,7 +331,12 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
         const bf16_t* src = reinterpret_cast<const bf16_t*>(ep + row * PITCH) + ec;
         const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;
         u32x4 v = *reinterpret_cast<const u32x4*>(src);
-        if (p.act.enabled) v = act_epilogue_apply<bf16_t>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+        if (p.act.enabled == 1) v = act_epilogue_apply<bf16_t>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+        else if (p.act.enabled == 2) {                       // residual merge (never with pixel_shuffle)
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.act.residual) +
+                            ((long long)b * ohw + pix) * p.act.res_ld + n;
+            v = residual_epilogue_apply<bf16_t>(v, *reinterpret_cast<const u32x4*>(rp), p.act.res_gain);
+        }
         if (lim >= VEC) {
             *reinterpret_cast<u32x4*>(dst) = v;
         } else {

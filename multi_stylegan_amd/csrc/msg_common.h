@@ -69,9 +69,35 @@ struct ActEpilogue {
     const float* noise;      // [noise_batch][OH*OW] fp32 or NULL
     const float* noise_w;    // device scalar (with noise)
     int noise_batch;         // 1 (shared by the batch) or B
-    int enabled;
+    int enabled;             // 0: off, 1: (noise +) bias + leaky ReLU, 2: residual merge y = (conv + residual) * res_gain
     float alpha, scale;
+    const void* residual;    // enabled == 2: a map shaped like the output (same pixels), channel pitch res_ld elements
+    int res_ld;
+    float res_gain;
 };
+
+// (conv + residual) * gain on VEC storage elements, the arithmetic of scaled_add_kernel (bias_act.hip): the residual
+// merge of a discriminator block done in the epilogue of its 1x1 residual conv, bit-identical to the two-pass form.
+template <typename T>
+__device__ __forceinline__ u32x4 residual_epilogue_apply(u32x4 raw, u32x4 res, float gain) {
+    constexpr int VEC = 16 / sizeof(T);
+    Vec16<T> v, r, o;
+    v.raw = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+    r.raw = make_uint4(res[0], res[1], res[2], res[3]);
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f[e] = fmaf(1.f, v.get(e), r.get(e)) * gain;
+    if constexpr (VEC == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+    }
+    u32x4 out;
+    out[0] = o.raw.x; out[1] = o.raw.y; out[2] = o.raw.z; out[3] = o.raw.w;
+    return out;
+}
 
 // `raw`: VEC storage elements of VEC consecutive channels of one pixel; `bv`: their bias values (0 where absent);
 // `nv` = noise_w * noise[pixel] (or 0).  Same arithmetic, in the same order, as bias_act_vec_kernel.

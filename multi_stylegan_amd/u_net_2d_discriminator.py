@@ -14,6 +14,7 @@ from . import conv_ops, equalized_layer
 from .op_static import FusedLeakyReLU, scaled_add, scaled_add_fork, upfirdn2d
 
 
+FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
 COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
 
 
@@ -89,7 +90,13 @@ class ResNetBlock(nn.Module):
     def _merge(self, input: torch.Tensor, merge):
         conv1, act1, conv2, act2 = self.main_mapping            # conv -> bias + leaky ReLU fused per pair
         output = conv2.forward_activated(conv1.forward_activated(self.mini_batch_std_dev(input), act1), act2)
-        return merge(output, self.residual_mapping(input), 1.0 / math.sqrt(2))
+        res = self.residual_mapping
+        if FUSE_RESIDUAL and isinstance(res, equalized_layer.EqualizedConv2d) and res.bias is None and \
+                input.is_cuda and output.dtype == input.dtype:
+            # (main + conv1x1(input)) / sqrt(2) in the epilogue of the 1x1 conv: no separate merge pass
+            return conv_ops.conv2d_add_residual(input, res.weight, output, 1.0 / math.sqrt(2), stride=res.stride,
+                                                padding=res.padding, wscale=res.scale, fork=merge is scaled_add_fork)
+        return merge(output, res(input), 1.0 / math.sqrt(2))
 
 
 class NonLocalBlock(nn.Module):

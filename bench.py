@@ -173,8 +173,13 @@ def main():
                    "conv_fprop_pp_kernel (implicit-GEMM conv fwd + data-grad, 256x256 ping-pong tile, MFMA 32x32x16 bf16)") \
             if mf else leg(f"conv_fprop_dma/{args.dtype}", "mfma", MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                            "conv_fprop_kernel<float, true> (implicit-GEMM conv, MFMA 32x32x2 f32)")
-        roof_fir = leg(f"upfirdn2d/{args.dtype}/up1down1/sep", "hbm", HBM_PEAK_GBS, "GB/s",
-                       "blur_sep_kernel (4x4 FIR blur up=down=1, separable sliding window, channels-last)") or \
+        # the FIR launches that carry the bytes: the blur behind every upsampling styled conv, which also applies that
+        # layer's noise + bias + leaky ReLU (algorithmic bytes: input + output + noise plane)
+        roof_fir = leg(f"upfirdn2d/{args.dtype}/up1down1/sep+act", "hbm", HBM_PEAK_GBS, "GB/s",
+                       "blur_sep_kernel (4x4 FIR blur up=down=1 + fused noise/bias/leaky-ReLU, separable sliding window, "
+                       "channels-last)") or \
+            leg(f"upfirdn2d/{args.dtype}/up1down1/sep", "hbm", HBM_PEAK_GBS, "GB/s",
+                "blur_sep_kernel (4x4 FIR blur up=down=1, separable sliding window, channels-last)") or \
             leg(f"upfirdn2d/{args.dtype}/up1down1/vec", "hbm", HBM_PEAK_GBS, "GB/s",
                 "upfirdn2d_vec_kernel<up=1,down=1> (4x4 FIR blur, channels-last)")
         kernels = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),

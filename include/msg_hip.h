@@ -67,8 +67,8 @@ int msg_upfirdn2d_separable(const void* x, const float* fir_y, const float* fir_
 /* msg_upfirdn2d_separable with the activation stage of the layer that owns the blur fused behind it:
  *   y = leaky_relu(blur(x) + noise_weight[0] * noise[b or 0, pixel] + act_bias[c], alpha) * scale
  * (the upsampling StyledConv2d: transposed conv -> Blur -> NoiseInjection -> FusedLeakyReLU,
- * multi_stylegan_generator.py:267-292,329-344).  Applied to the blur result rounded to the storage type: bit-identical to
- * msg_upfirdn2d_separable followed by msg_fused_bias_act. */
+ * multi_stylegan_generator.py:267-292,329-344).  The activation sees the fp32 blur result, i.e. one rounding less than
+ * msg_upfirdn2d_separable followed by msg_fused_bias_act (within one unit in the last place of the storage type). */
 int msg_upfirdn2d_separable_act(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
                                 int major, int in_h, int in_w, int minor, int kh, int kw,
                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1,

@@ -178,7 +178,8 @@ def _blur_act_eligible(x, fir, pad):
 
 class BlurBiasAct(Function):
     """blur (up = down = 1) -> (noise +) bias -> leaky ReLU in one launch (csrc/blur_sep.hip), for the upsampling
-    StyledConv2d whose activation sits behind its blur.  Bit-identical to upfirdn2d followed by the fused activation;
+    StyledConv2d whose activation sits behind its blur.  Equal to upfirdn2d followed by the fused activation up to the
+    intermediate rounding the two-pass form applies to the blur result (the fused kernel keeps it in fp32);
     the backward is composed of the same differentiable pieces (activation backward from the output's sign, then the
     adjoint FIR pass), so second-order terms are those of the two-pass form."""
 
@@ -196,8 +197,9 @@ class BlurBiasAct(Function):
             if noise.shape[0] not in (1, b) or noise.shape[1] != 1 or tuple(noise.shape[2:]) != (oh, ow):
                 raise _lib.MsgHipError(f"noise shape {tuple(noise.shape)} does not match output {(b, c, oh, ow)}")
             nz, nw = noise.detach().to(torch.float32).contiguous(), noise_w.detach().to(torch.float32).contiguous()
-        key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up1down1/sep"
-        with _lib.on_device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
+        key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up1down1/sep+act"    # blur + activation: own key
+        nbytes = (x.numel() + y.numel()) * x.element_size() + (0 if nz is None else nz.numel() * 4)
+        with _lib.on_device(dev), _lib.kernel_clock.span(key, nbytes):
             code = _lib.lib().msg_upfirdn2d_separable_act(
                 x.data_ptr(), fy.data_ptr(), fx.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, h, w, c, 4, 4,
                 px0, px1, py0, py1, _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(nw), 1 if nz is None else nz.shape[0],

@@ -114,9 +114,10 @@ def test_blur_separable_kernel(cfg, dtype, tol):
 
 @pytest.mark.parametrize("noise_batch", [1, 3])
 @pytest.mark.parametrize("cfg", [((2, 1), 16, 12, 10), ((2, 2), 8, 15, 15), ((1, 1), 64, 40, 19)])
-def test_blur_bias_act_is_bit_identical_to_two_passes(cfg, noise_batch):
-    """msg_upfirdn2d_separable_act == msg_upfirdn2d_separable followed by msg_fused_bias_act (bf16 storage), forward
-    bit for bit; first- and second-order gradients through the same composed backward."""
+def test_blur_bias_act_matches_two_passes(cfg, noise_batch):
+    """msg_upfirdn2d_separable_act vs msg_upfirdn2d_separable followed by msg_fused_bias_act (bf16 storage): equal up to
+    the intermediate rounding of the blur result that only the two-pass form applies (<= ~1 bf16 ulp), and closer to the
+    fp32 oracle; first- and second-order gradients through the same composed backward."""
     ops = _ops()
     from multi_stylegan_amd.op_static import blur_bias_act, fused_bias_noise_leaky_relu
     pad, c, h, w = cfg
@@ -140,10 +141,17 @@ def test_blur_bias_act_is_bit_identical_to_two_passes(cfg, noise_batch):
         gx, gb, gn = torch.autograd.grad(y, (xs, bs, ns), gys, create_graph=True)
         ggy, = torch.autograd.grad(gx, gys, x.clone(), retain_graph=True)           # second order, linear in gy
         res.append((y, gx, gb, gn, ggy))
-    assert torch.equal(res[0][0], res[1][0])
+    from oracle import ops as oo
+    ref = oo.fused_leaky_relu(oo.upfirdn2d(x.float().cpu(), fir.cpu(), pad=pad) +
+                              nw.cpu() * noise.cpu(), bias.cpu(), 0.2, 1.3)
+    e_fused, e_two = rel_err(res[0][0].float(), ref), rel_err(res[1][0].float(), ref)
+    assert e_fused < 1e-2 and e_fused <= e_two * 1.05 + 1e-6            # no less accurate than the two-pass form
+    assert rel_err(res[0][0].float(), res[1][0].float()) < 1e-2
+    # the gradient masks come from the sign of the outputs, which may differ where an output sits within rounding of
+    # zero: a handful of elements change slope, so the gradients are compared in the L2 sense
     for a, r in zip(res[0][1:], res[1][1:]):
-        assert rel_err(a.float(), r.float()) < 1e-5
-    assert rel_err(res[0][0].float() * 0 + res[0][4].float(), res[1][4].float()) < 1e-5 and v is not None
+        assert (a.float() - r.float()).norm() / r.float().norm() < 2e-2
+    assert v is not None
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

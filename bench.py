@@ -163,7 +163,8 @@ def main():
             rate = c["work"] / (c["total_ms"] * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
             return {"kernel": name, "bound": bound, "achieved": round(rate, 1), "peak": peak, "unit": unit,
                     "frac": round(rate / peak, 4),
-                    "traffic": pmc.get(key, {}).get("traffic_bytes_per_launch") if args.batch == 16 and
+                    "traffic": (pmc.get(key) or pmc.get(key.replace("+act", ""), {})).get("traffic_bytes_per_launch")
+                    if args.batch == 16 and
                     args.resolution == 256 and args.dtype == "bf16" else None,
                     "traffic_unit": "HBM-side bytes per launch, rocprofv3 PMC (profiles/r01_pmc_traffic.json)",
                     "launches": c["launches"],

@@ -55,7 +55,7 @@ __device__ __forceinline__ void blur_hrow(const uint4* xin, int iy, int IH, long
     }
 }
 
-template <typename T, int TH, int OCC>
+template <typename T, int TH, int OCC, bool ACT>     // ACT: with the fused noise + bias + leaky-ReLU stage
 __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict__ x, const float* __restrict__ fy,
                                                           const float* __restrict__ fx, T* __restrict__ y,
                                                           BlurParams p) {
@@ -82,14 +82,14 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
     const bool c1ok = ox + 1 < p.OW;
 
     float a_bias[VEC], a_nw = 0.f;                                   // fused activation: this lane's bias vector
-    if (p.act.enabled) {
+    if constexpr (ACT) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) a_bias[e] = p.act.bias ? p.act.bias[cv * VEC + e] : 0.f;
         a_nw = p.act.noise ? p.act.noise_w[0] : 0.f;
     }
     // noise values of the two columns, fetched ONE ROW AHEAD of their use (a dependent load in front of every row's
     // activation would stall the lane once per row)
-    const float* nz_base = p.act.noise ? p.act.noise + (long long)(p.act.noise_batch == 1 ? 0 : b) * p.OH * p.OW + ox : nullptr;
+    const float* nz_base = (ACT && p.act.noise) ? p.act.noise + (long long)(p.act.noise_batch == 1 ? 0 : b) * p.OH * p.OW + ox : nullptr;
     float nz_cur[2] = {0.f, 0.f};
     if (nz_base && oy0 < p.OH) {
         nz_cur[0] = nz_base[(long long)oy0 * p.OW];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 f[e] = fmaf(wy[3], w3[c][e], fmaf(wy[2], w2[c][e], fmaf(wy[1], w1[c][e], wy[0] * w0[c][e])));
-            if (p.act.enabled) {
+            if constexpr (ACT) {
                 // activation of the StyledConv2d that owns this blur (see BLUR_ACT_ROUND above)
                 const float nv = a_nw * nz_cur[c];
                 const float pos = p.act.scale, neg = p.act.alpha * p.act.scale;
@@ -198,17 +198,22 @@ static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x
     if (gx >= (1ll << 31) || gy > 65535 || major > 65535) return MSG_EUNSUPPORTED;
     dim3 grid((unsigned)gx, gy, major);
     hipStream_t s = (hipStream_t)stream;
-#define BLUR_LAUNCH(TH_)                                                                                               \
+#define BLUR_LAUNCH(TH_, ACT_)                                                                                            \
     do {                                                                                                               \
         if (dtype == MSG_BF16)                                                                                         \
-            hipLaunchKernelGGL((blur_sep_kernel<bf16_t, TH_, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, fir_y,     \
-                               fir_x, (bf16_t*)y, p);                                                                 \
+            hipLaunchKernelGGL((blur_sep_kernel<bf16_t, TH_, 4, ACT_>), grid, dim3(256), 0, s, (const bf16_t*)x,      \
+                               fir_y, fir_x, (bf16_t*)y, p);                                                          \
         else                                                                                                           \
-            hipLaunchKernelGGL((blur_sep_kernel<float, TH_, 4>), grid, dim3(256), 0, s, (const float*)x, fir_y,       \
+            hipLaunchKernelGGL((blur_sep_kernel<float, TH_, 4, ACT_>), grid, dim3(256), 0, s, (const float*)x, fir_y, \
                                fir_x, (float*)y, p);                                                                  \
     } while (0)
-    if (th == 32) BLUR_LAUNCH(32);
-    else BLUR_LAUNCH(16);
+    if (act.enabled) {
+        if (th == 32) BLUR_LAUNCH(32, true);
+        else BLUR_LAUNCH(16, true);
+    } else {
+        if (th == 32) BLUR_LAUNCH(32, false);
+        else BLUR_LAUNCH(16, false);
+    }
 #undef BLUR_LAUNCH
     return MSG_CHECK_LAUNCH();
 }

@@ -33,6 +33,8 @@ KEYS = [("conv_fprop_pp_kernel", "conv_fprop_pp/bf16"), ("conv_fprop_kernel<unsi
         ("conv_fprop_kernel<unsigned short, false>", "conv_fprop_reg/bf16"),
         ("conv_wgrad_kernel<unsigned short", "conv_wgrad/bf16"),
         ("upfirdn2d_vec_kernel<unsigned short, 1, 1", "upfirdn2d/bf16/up1down1/vec"),
+        ("blur_sep_kernel<unsigned short, 32, 4, true>", "upfirdn2d/bf16/up1down1/sep+act"),
+        ("blur_sep_kernel<unsigned short, 16, 4, true>", "upfirdn2d/bf16/up1down1/sep+act"),
         ("blur_sep_kernel<unsigned short", "upfirdn2d/bf16/up1down1/sep"),
         ("bias_act_vec_kernel<unsigned short", "bias_act_fwd/torch.bfloat16"),
         ("bias_act_bwd_cl_kernel<unsigned short", "bias_act_bwd/torch.bfloat16")]

@@ -1,4 +1,6 @@
-"""Dense contractions of the hot path on the hand-written MFMA kernels (csrc/conv_fprop.hip, conv_wgrad.hip).
+"""Dense contractions of the hot path on the hand-written MFMA kernels (csrc/conv_fprop_pp.hip, conv_fprop.hip,
+conv_wgrad.hip), the modulation arithmetic around them (csrc/modulate.hip, relayout.hip) and the few-row linear
+layers (csrc/linear.hip).
 
 Three primitives per convolution geometry, closed under differentiation so that first AND second order autograd
 (R1 on the discriminator, path-length regularisation on the generator) run on the same two kernels:
@@ -11,8 +13,10 @@ Three primitives per convolution geometry, closed under differentiation so that 
 
 Geometries: "conv" (kh x kw, stride 1 or 2, any padding) and "up2" (the generator's 2x2 stride-2 transposed conv,
 run as a 1x1 contraction to 4*O channels stored pixel-shuffled).  Weights are given in the reference's parameter
-layout ([O,I,kh,kw], or [B,O,I,kh,kw] for the per-sample weights of the modulated convolution) and re-laid per call
-into the kernels' K-contiguous form; activations are channels-last with a 16-byte-aligned channel stride.
+layout ([O,I,kh,kw], or [B,O,I,kh,kw] for the per-sample weights of the modulated convolution); their K-contiguous
+kernel-side images are built by one kernel per parameter and cached until that parameter's optimizer steps
+(_param_images); activations are channels-last with a 16-byte-aligned channel stride.  Fused forms: conv + activation
+(_ConvActF, _ModulatedConv with fuse_act), conv + residual merge (_ConvResidualF).
 There is no CPU or library fallback.
 """
 import math

@@ -10,9 +10,13 @@
 // operand is one element per lane.  A 64-B rotation of every LDS row by (pixel & 3) keeps the transposed reads of the
 // four pixels of a block on disjoint banks.
 // Tiling: workgroup = 128 (o) x 128 (i) of ONE tap, 4 waves as 2x2 (64x64 each, 64 accumulator VGPRs); K advances
-// 64 pixels (bf16) / 32 pixels (f32) per step, double-buffered through registers like the forward kernel.  grid.y =
-// tap, grid.z = K-slice (sample, or sample x pixel-chunk).  Output is fp32; slices either own their own GW[z] (per-sample
-// gradients of the modulated conv) or accumulate into one GW with float atomics (shared weights, 128-B runs).
+// 64 pixels (bf16) / 32 pixels (f32) per step, double-buffered through registers like the forward kernel.  The grid
+// is 1-D over (channel tile, tap, K-slice) in an XCD-aware order (see the kernel); a K-slice is a sample or a chunk
+// of one (per-sample weights), or -- shared weights -- a chunk of the pixels of ALL samples concatenated (the batch is
+// folded into K; the chunk count comes from a wave-quantisation cost model in the launcher).  Output is fp32; slices
+// either own their own GW[z] (per-sample gradients of the modulated conv) or accumulate into one GW with float
+// atomics (128-B runs).  On power-of-two maps the staging loads are buffer loads with a constant per-lane offset and
+// an SGPR cursor (UNI, see the kernel); other maps take the generic incremental addressing.
 // pixel_shuffle = 1 is the weight gradient of the generator's 2x2 stride-2 transposed conv: tap (dy,dx) pairs
 // X[b,h,w,:] with GY[b, 2h+dy, 2w+dx, :].
 #include "msg_common.h"

@@ -177,6 +177,13 @@ int msg_modulate_backward(const float* gwk, const float* W, const float* s, cons
 int msg_relayout_weight(const float* w, void* fwd, void* dgrad, float* wsq, int dtype,
                         int O, int I, int T, int Ck, int Ok, int flip, int t_major, float gain, void* stream);
 
+/* Tap gathering for convolutions with very few input channels (the discriminator's first layer, 6 channels):
+ * y[b][h][w][t*C + c] = x[b][h + kh_t - pad][w + kw_t - pad][c] (zero outside the image / beyond taps*C), Ko channels per
+ * output pixel, x with channel pitch Cx.  The kh x kw conv then runs as a 1x1 conv over the gathered map (one K-step
+ * instead of kh*kw mostly-zero ones; the weight gradient reads gy once instead of once per tap). */
+int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, int W, int Cx, int C, int kh, int kw,
+                    int pad, int Ko, void* stream);
+
 /* y = (a + beta*b) * gain over n elements (n multiple of the 16-byte vector, all pointers 16-B aligned): the
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
 int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "msg_modulate_weights": (_I, [_P] * 5 + [_I] * 7 + [_F, _F, _P]),
     "msg_modulate_backward": (_I, [_P] * 6 + [_I] * 6 + [_F, _P]),
     "msg_relayout_weight": (_I, [_P, _P, _P, _P, _I] + [_I] * 7 + [_F, _P]),
+    "msg_gather_taps": (_I, [_P, _P, _I] + [_I] * 9 + [_P]),
     "msg_scaled_add": (_I, [_P, _P, _P, _I, _L, _F, _F, _P]),
     "msg_scaled_add_rows": (_I, [_P, _P, _P, _I, _L, _I, _L, _L, _L, _F, _F, _P]),
     "msg_conv2d_fprop_plan": (_I, [_I] * 11 + [_L]),

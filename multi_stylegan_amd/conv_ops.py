@@ -418,7 +418,45 @@ def _relay_fwd_kind(w, dtype, kind):
     return wk, ck
 
 
+_THIN_INPUT = bool(int(os.environ.get("MSG_THIN_INPUT", "1")))       # 0: no tap gathering for few-channel inputs (A/B)
+
+
+def _thin_ok(dtype, i, g: Geometry) -> bool:
+    """A 'same' kh x kw conv whose (tap, channel) pairs fit ONE 128-byte K run (the discriminator's 6-channel first layer):
+    it runs as a 1x1 conv over the tap-gathered input (msg_gather_taps)."""
+    taps = g.kh * g.kw
+    return _THIN_INPUT and g.kind == "conv" and g.stride == 1 and not g.per_sample and taps > 1 and \
+        2 * g.pad + 1 == g.kh and g.kh == g.kw and i * taps <= 128 // (2 if dtype == torch.bfloat16 else 4)
+
+
+def _gather_taps(x, i, g: Geometry):
+    dev = _lib.require_gpu(x)
+    xv, cx = _nhwc_view(x)
+    b, _, h, w = xv.shape
+    ko = 128 // x.element_size()
+    out = torch.empty((b, h, w, ko), dtype=x.dtype, device=dev)
+    with _lib.on_device(dev):
+        code = _lib.lib().msg_gather_taps(xv.data_ptr(), out.data_ptr(), _lib.dtype_code(x), b, h, w, cx, i, g.kh, g.kw,
+                                          g.pad, ko, _lib.stream_of(dev))
+    _lib.check(code, "msg_gather_taps")
+    return out.permute(0, 3, 1, 2), ko
+
+
+def _relay_thin(w, dtype):
+    """[O, I, kh, kw] -> [O, 1, Ko] with K index (tap * I + channel), zero-padded to one 128-byte run."""
+    o, i, kh, kw = w.shape
+    ko = 128 // (2 if dtype == torch.bfloat16 else 4)
+    out = torch.zeros((o, 1, ko), dtype=dtype, device=w.device)
+    out[:, 0, :kh * kw * i] = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i)
+    return out, ko
+
+
 def _f_raw(x, w, bias, g: Geometry, act=None, residual=None):
+    if w.ndim == 4 and _thin_ok(x.dtype, w.shape[1], g):
+        xc, ko = _gather_taps(x, w.shape[1], g)
+        wk, _ = _cached(w, "thin", x.dtype, g.wscale, lambda: _relay_thin(w, x.dtype))
+        return _launch_fprop(xc, wk, ko, bias, w.shape[0], g.y_hw, 1, 1, 1, 0, 1, False, False,
+                             w.shape[1] * g.kh * g.kw, act=act, residual=residual)
     img = _param_images(w, x.dtype, g.wscale, g.kind) if not g.per_sample else None
     wk, ck = img["f"] if img is not None else \
         _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
@@ -466,6 +504,12 @@ def _d_raw_s2(gy, w, g: Geometry):
 
 
 def _g_raw(gy, x, o, i, g: Geometry):
+    if _thin_ok(x.dtype, i, g):
+        # weight gradient of the tap-gathered 1x1 form: gy is read once (not once per tap), one channel tile
+        xc, ko = _gather_taps(x, i, g)
+        gwp = _launch_wgrad(gy, xc, o, ko, 1, 1, 1, 0, False, False, None, gain=g.wscale)      # [O, Ko, 1, 1]
+        taps = g.kh * g.kw
+        return gwp[:, :taps * i, 0, 0].reshape(o, taps, i).permute(0, 2, 1).reshape(o, i, g.kh, g.kw)
     if g.kind == "up2":
         return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw, gain=g.wscale)
     return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None, gain=g.wscale)

@@ -99,3 +99,56 @@ extern "C" int msg_relayout_weight(const float* w, void* fwd, void* dgrad, float
 #undef RL_LAUNCH
     return MSG_CHECK_LAUNCH();
 }
+
+// ---- tap gathering for convolutions with very few input channels (the discriminator's first layer: 6 channels) -------
+// y[b][h][w][t*C + c] = x[b][h + kh_t - pad][w + kw_t - pad][c]   (zero outside the image and for t*C + c >= taps*C)
+// turns a kh x kw conv over C channels into a 1x1 conv over Ko = one 128-byte run of (tap, channel) pairs: the
+// implicit-GEMM kernels then spend ONE K-step per output tile instead of kh*kw steps that are 90 % zero padding, and
+// the weight gradient reads gy once instead of once per tap.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_taps_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
+                                                          int Cx, int C, int kh, int kw, int pad, int Ko) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    const int vpp = Ko / VEC;                                     // output vectors per pixel
+    const long long total = (long long)B * H * W * vpp;
+    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < total; vi += (long long)gridDim.x * 256) {
+        const int v = (int)(vi % vpp);
+        long long pix = vi / vpp;
+        const int w_ = (int)(pix % W); pix /= W;
+        const int h_ = (int)(pix % H);
+        const int b = (int)(pix / H);
+        T out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int k = v * VEC + e;
+            const int t = k / C, c = k - t * C;
+            const int dy = t / kw, dx = t - dy * kw;
+            const int ih = h_ + dy - pad, iw = w_ + dx - pad;
+            T val = 0;
+            if (t < kh * kw && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                val = x[(((long long)b * H + ih) * W + iw) * Cx + c];
+            out[e] = val;
+        }
+        *reinterpret_cast<uint4*>(y + vi * VEC) = *reinterpret_cast<const uint4*>(out);
+    }
+}
+
+extern "C" int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, int W, int Cx, int C, int kh, int kw,
+                               int pad, int Ko, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!x || !y || B < 0 || H <= 0 || W <= 0 || C <= 0 || Cx < C || kh <= 0 || kw <= 0 || Ko < kh * kw * C) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (Ko % vec || (((uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
+    const long long total = (long long)B * H * W * (Ko / vec);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((gather_taps_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W,
+                           Cx, C, kh, kw, pad, Ko);
+    else
+        hipLaunchKernelGGL((gather_taps_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, Cx,
+                           C, kh, kw, pad, Ko);
+    return MSG_CHECK_LAUNCH();
+}

@@ -64,7 +64,7 @@ class ModelWrapper(object):
                  device: str = "cuda", lr_generator: float = 2e-4, lr_discriminator: float = 6e-4,
                  bucket_bytes: int = 32 << 20, overlap_communication: bool = True,
                  skip_discriminator_weight_grads_in_generator_step: bool = False,
-                 fused_optimizer: Optional[bool] = None) -> None:
+                 fused_optimizer: Optional[bool] = None, batch_discriminator_passes: bool = True) -> None:
         self.device = torch.device(device)
         self.generator = generator.to(self.device)
         self.discriminator = discriminator.to(self.device)
@@ -95,6 +95,9 @@ class ModelWrapper(object):
         self.discriminator_reducer = msg_dist.GradBucketReducer(self.discriminator.parameters(), bucket_bytes,
                                                                 overlap_communication)
         self.skip_d_wgrad = skip_discriminator_weight_grads_in_generator_step
+        # only discriminators that know about minibatch groups (ours) can take the concatenated batch
+        self.batch_discriminator_passes = batch_discriminator_passes and \
+            getattr(discriminator, "supports_minibatch_groups", False)
         self.iteration = 0                       # == progress_bar.n of the reference (1-based when tested, Q12)
         self._log: Dict[str, List[torch.Tensor]] = {}
 
@@ -157,8 +160,15 @@ class ModelWrapper(object):
             z = dr.z_d if dr.z_d is not None else self._noise(batch)
             fake_images = G(input=z, inject_index=dr.inject_d, noise=dr.noise_d)
         self.discriminator_reducer.arm()
-        real_prediction, real_prediction_pixel_wise = D(real_images, is_real=True, is_cut_mix=False)
-        fake_prediction, fake_prediction_pixel_wise = D(fake_images, is_real=False, is_cut_mix=False)
+        if self.batch_discriminator_passes and real_images.shape == fake_images.shape:
+            # D(real) and D(fake) of the reference (:272-275) as ONE batch of 2B with per-half minibatch statistics:
+            # same result, half the launches, better-filled tiles on the low-resolution layers
+            both, both_px = D(torch.cat([real_images, fake_images.to(real_images.dtype)]), minibatch_groups=2)
+            (real_prediction, fake_prediction) = both.split(batch)
+            (real_prediction_pixel_wise, fake_prediction_pixel_wise) = both_px.split(batch)
+        else:
+            real_prediction, real_prediction_pixel_wise = D(real_images, is_real=True, is_cut_mix=False)
+            fake_prediction, fake_prediction_pixel_wise = D(fake_images, is_real=False, is_cut_mix=False)
         loss_real, loss_fake = self.discriminator_loss(real_prediction, fake_prediction)
         loss_real_px, loss_fake_px = self.discriminator_loss(real_prediction_pixel_wise, fake_prediction_pixel_wise)
         (loss_real + loss_fake + loss_real_px + loss_fake_px).backward()

@@ -48,19 +48,27 @@ class Blur(nn.Module):
         return upfirdn2d(input, self.kernel, pad=self.padding)
 
 
+_MBSTD_GROUPS = [1]     # number of independent forward batches concatenated along dim 0 (set by Discriminator.forward)
+
+
 class MinibatchStdDev(nn.Module):
     """Appends one plane holding the mean (over c,h,w) of the per-position std over the batch; statistics in
-    fp32.  The whole per-process batch is one group, as in the reference (:205-217)."""
+    fp32.  The whole batch of ONE forward call is one group, as in the reference (:205-217); when the trainer runs the
+    real and the fake batch through the discriminator as one concatenated batch (Discriminator.forward(...,
+    minibatch_groups=2)) each of them keeps its own statistic."""
 
     def __init__(self, alpha: float = 1e-8) -> None:
         super().__init__()
         self.alpha = alpha
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        x = input.float()
-        var = (x - x.mean(dim=0, keepdim=True)).square().mean(dim=0)
-        stat = torch.sqrt(var.clamp(min=self.alpha)).mean()
-        plane = stat.to(input.dtype).reshape(1, 1, 1, 1).expand(input.shape[0], 1, input.shape[2], input.shape[3])
+        groups = _MBSTD_GROUPS[0]
+        b, _, h, w = input.shape
+        assert b % groups == 0
+        x = input.float().reshape(groups, b // groups, *input.shape[1:])
+        var = (x - x.mean(dim=1, keepdim=True)).square().mean(dim=1)                    # [G, C, H, W]
+        stat = torch.sqrt(var.clamp(min=self.alpha)).mean(dim=(1, 2, 3))                # [G]
+        plane = stat.to(input.dtype).reshape(groups, 1, 1, 1, 1).expand(groups, b // groups, 1, h, w).reshape(b, 1, h, w)
         return conv_ops.cat_channels([input, plane])
 
 
@@ -126,6 +134,8 @@ class NonLocalBlock(nn.Module):
 
 
 class Discriminator(nn.Module):
+    supports_minibatch_groups = True     # forward(..., minibatch_groups=n): n concatenated batches, per-batch statistics
+
     def __init__(self, config: Dict[str, Any], no_rfp: bool = False, no_gfp: bool = False) -> None:
         super().__init__()
         encoder_channels: Tuple[Tuple[int, int], ...] = config["encoder_channels"]
@@ -168,7 +178,17 @@ class Discriminator(nn.Module):
                                             padding=(0, 0), bias=False))
         self.compute_dtype = torch.float32          # MI355X-side knob; default reproduces the reference
 
-    def forward(self, input: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, input: torch.Tensor, minibatch_groups: int = 1, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """minibatch_groups > 1: `input` is that many forward batches concatenated along dim 0 (the real and the fake
+        batch of the discriminator step); everything is per-sample except the minibatch statistic, which is taken per
+        group -- the result equals separate forward calls, at the launch count and tile efficiency of one."""
+        _MBSTD_GROUPS[0] = minibatch_groups
+        try:
+            return self._forward(input)
+        finally:
+            _MBSTD_GROUPS[0] = 1
+
+    def _forward(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         x = input.flatten(start_dim=1, end_dim=2)
         x = conv_ops.to_compute_layout(x, self.compute_dtype)
         skips = []

@@ -78,6 +78,27 @@ def test_tiny_discriminator(golden):
         assert rel_err(params[key[len("tinyD.r1grad."):]].grad, z[key]) < TOL, key
 
 
+def test_discriminator_concatenated_batches_equal_separate_calls(golden):
+    """forward(cat([a, b]), minibatch_groups=2) == (forward(a), forward(b)): everything is per-sample except the
+    minibatch statistic, which is taken per group; gradients of the summed loss agree as well."""
+    z, _, d = _models(golden)
+    torch.manual_seed(3)
+    a, b = torch.rand(3, 2, 3, 32, 32, device=DEV), torch.rand(3, 2, 3, 32, 32, device=DEV)
+    ca, pa = d(a)
+    cb, pb = d(b)
+    (ca.sum() + pa.sum() + 2 * cb.sum() + 2 * pb.sum()).backward()
+    ref = [p.grad.clone() for p in d.parameters()]
+    d.zero_grad()
+    c2, p2 = d(torch.cat([a, b]), minibatch_groups=2)
+    assert rel_err(c2, torch.cat([ca, cb])) < 1e-5 and rel_err(p2, torch.cat([pa, pb])) < 1e-5
+    (c2[:3].sum() + p2[:3].sum() + 2 * c2[3:].sum() + 2 * p2[3:].sum()).backward()
+    for p, r in zip(d.parameters(), ref):
+        assert rel_err(p.grad, r) < 1e-4
+    # one group over the concatenation is a DIFFERENT function (shared statistic)
+    c1, _ = d(torch.cat([a, b]))
+    assert rel_err(c1, torch.cat([ca, cb])) > 1e-6
+
+
 def test_bf16_models_track_fp32(golden):
     """bf16 storage path: same graph, looser documented tolerance (5e-2 of max|ref|)."""
     z, g, d = _models(golden)

@@ -110,24 +110,34 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const T* __restrict__ 
                                                           int Cx, int C, int kh, int kw, int pad, int Ko) {
     using V = Vec16<T>;
     constexpr int VEC = V::N;
-    const int vpp = Ko / VEC;                                     // output vectors per pixel
+    const int vpp = Ko / VEC;                                     // output vectors per pixel (8: divides the grid stride)
     const long long total = (long long)B * H * W * vpp;
-    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < total; vi += (long long)gridDim.x * 256) {
-        const int v = (int)(vi % vpp);
+    const long long first = (long long)blockIdx.x * 256 + threadIdx.x;
+    // the thread's vector slot inside a pixel never changes over its grid-stride loop: its (tap, channel) pairs are
+    // decoded ONCE
+    const int v = (int)(first % vpp);
+    int dy[VEC], dx[VEC], cc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int k = v * VEC + e;
+        const int t = k / C;
+        cc[e] = (t < kh * kw) ? k - t * C : -1;
+        dy[e] = t / kw - pad;
+        dx[e] = t - (t / kw) * kw - pad;
+    }
+    for (long long vi = first; vi < total; vi += (long long)gridDim.x * 256) {
         long long pix = vi / vpp;
         const int w_ = (int)(pix % W); pix /= W;
         const int h_ = (int)(pix % H);
         const int b = (int)(pix / H);
+        const T* xb = x + (long long)b * H * W * Cx;
         T out[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const int k = v * VEC + e;
-            const int t = k / C, c = k - t * C;
-            const int dy = t / kw, dx = t - dy * kw;
-            const int ih = h_ + dy - pad, iw = w_ + dx - pad;
+            const int ih = h_ + dy[e], iw = w_ + dx[e];
             T val = 0;
-            if (t < kh * kw && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-                val = x[(((long long)b * H + ih) * W + iw) * Cx + c];
+            if (cc[e] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                val = xb[((long long)ih * W + iw) * Cx + cc[e]];
             out[e] = val;
         }
         *reinterpret_cast<uint4*>(y + vi * VEC) = *reinterpret_cast<const uint4*>(out);

@@ -190,11 +190,14 @@ class GradBucketReducer:
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self) -> None:
-        """Reduce whatever has not been sent yet, wait for everything, turn sums into means."""
+    def finish(self, average: bool = True) -> float:
+        """Reduce whatever has not been sent yet, wait for everything, turn sums into means.  With average=False the
+        buckets keep the SUM over ranks and the factor that still has to be applied (1 / world) is returned, for a
+        caller that can fold it into a later pass (the trainer folds it into fused Adam's grad_scale and saves one
+        read-modify-write of every gradient per optimiser step)."""
         self._armed = False
         if not self.active:
-            return
+            return 1.0
         while self._next < len(self.buckets):             # whatever is left (incl. buckets with unused parameters)
             self._launch(self.buckets[self._next])
             self._next += 1
@@ -203,7 +206,10 @@ class GradBucketReducer:
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.buckets[0].flat.device).wait_stream(self.comm_stream)
         inv = 1.0 / self.world
+        if not average:
+            return inv
         torch._foreach_mul_([b.flat for b in self.buckets], inv)
+        return 1.0
 
     def grad_norm(self) -> torch.Tensor:
         norms = torch._foreach_norm([b.flat for b in self.buckets])

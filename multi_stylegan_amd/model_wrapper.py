@@ -128,10 +128,10 @@ class ModelWrapper(object):
         """finish the gradient exchange, clip to norm 5 (reference :296,:410), Adam step.  With torch's fused Adam the
         clip factor rides along as its `grad_scale` (the hook GradScaler uses: grad <- grad / grad_scale inside the
         optimizer kernel), which saves a read-modify-write pass over every gradient."""
-        reducer.finish()
         if isinstance(optimizer, torch.optim.Adam) and optimizer.defaults.get("fused"):
-            total = reducer.grad_norm()
-            coef = torch.clamp(5.0 / (total + 1e-6), max=1.0)
+            pending = reducer.finish(average=False)        # buckets hold rank SUMS; `pending` = 1 / world still to apply
+            total = reducer.grad_norm() * pending          # norm of the mean gradient
+            coef = torch.clamp(5.0 / (total + 1e-6), max=1.0) * pending
             optimizer.grad_scale = (1.0 / coef).reshape(()).float()
             optimizer.found_inf = torch.zeros((), dtype=torch.float32, device=total.device)
             try:
@@ -139,6 +139,7 @@ class ModelWrapper(object):
             finally:
                 del optimizer.grad_scale, optimizer.found_inf
         else:
+            reducer.finish()
             reducer.clip_(5.0)
             optimizer.step()
 

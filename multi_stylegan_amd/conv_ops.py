@@ -457,6 +457,13 @@ def _f_raw(x, w, bias, g: Geometry, act=None, residual=None):
         wk, _ = _cached(w, "thin", x.dtype, g.wscale, lambda: _relay_thin(w, x.dtype))
         return _launch_fprop(xc, wk, ko, bias, w.shape[0], g.y_hw, 1, 1, 1, 0, 1, False, False,
                              w.shape[1] * g.kh * g.kw, act=act, residual=residual)
+    if g.kind == "up2" and _oi(w)[0] % _vec(x.dtype):
+        # the pixel-shuffling epilogue stores whole 16-byte channel vectors per output pixel: pad the output channels
+        # with zero filters and drop them again (rare: every up-conv of the models has 512 output channels)
+        o_real = _oi(w)[0]
+        wp = torch.zeros((*w.shape[:-4], _round_up(o_real, _vec(x.dtype)), *w.shape[-3:]), dtype=w.dtype, device=w.device)
+        wp[..., :o_real, :, :, :] = w.detach()
+        return _f_raw(x, wp, bias, g, act=act, residual=residual)[:, :o_real]
     img = _param_images(w, x.dtype, g.wscale, g.kind) if not g.per_sample else None
     wk, ck = img["f"] if img is not None else \
         _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
@@ -480,8 +487,8 @@ def _act_operands(bias, noise, noise_w, y_shape):
 
 
 def _d_raw(gy, w, g: Geometry):
-    if g.kind == "conv" and g.stride == 2 and _S2_PARITY:
-        return _d_raw_s2(gy, w, g)
+    if g.kind == "conv" and g.stride == 2 and _S2_PARITY and _oi(w)[1] % _vec(gy.dtype) == 0:
+        return _d_raw_s2(gy, w, g)          # (the pixel-shuffling epilogue needs whole 16-byte channel vectors)
     i = _oi(w)[1]
     img = _param_images(w, gy.dtype, g.wscale, g.kind) if not g.per_sample else None
     wk, ok = img["d"] if img is not None else \

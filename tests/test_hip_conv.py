@@ -142,6 +142,63 @@ def test_conv_full_size_properties():
     assert rel_err(y.float(), ref) < 2e-2
 
 
+def _random_cases(n=36, seed=20260101):
+    """Random geometries over everything the addressing paths branch on: power-of-two / odd maps, maps smaller and larger
+    than a K-step, few / ragged / multi-tile channel counts, strides, kernel sizes, shared and per-sample weights."""
+    import random
+    rng = random.Random(seed)
+    cases = []
+    while len(cases) < n:
+        kind = rng.choice(["conv", "conv", "conv", "up2"])
+        b = rng.choice([1, 2, 3, 5])
+        i = rng.choice([3, 6, 8, 16, 40, 72, 136])
+        o = rng.choice([1, 3, 8, 24, 72, 136, 264])
+        h = rng.choice([4, 7, 8, 15, 16, 31, 32, 64])
+        w_ = rng.choice([4, 5, 8, 16, 17, 32, 64, 128]) if rng.random() < 0.5 else h
+        if kind == "up2":
+            k, stride, pad = 2, 2, 0
+        else:
+            k = rng.choice([1, 3, 3, 3])
+            stride = rng.choice([1, 1, 1, 2])
+            pad = rng.choice([0, k // 2])
+            if (h + 2 * pad - k) // stride + 1 <= 0 or (w_ + 2 * pad - k) // stride + 1 <= 0:
+                continue
+        if b * max(i, o) * h * w_ > 3_000_000:          # keep the fp64 CPU reference quick
+            continue
+        cases.append((f"r{len(cases)}_{kind}_b{b}_i{i}_o{o}_{h}x{w_}_k{k}s{stride}p{pad}", kind, b, i, o, h, w_, k, stride, pad))
+    return cases
+
+
+RANDOM_CASES = _random_cases()
+
+
+@pytest.mark.parametrize("case", RANDOM_CASES, ids=[c[0] for c in RANDOM_CASES])
+def test_conv_primitives_random_geometries(case):
+    """F / D / G on randomly drawn geometries (bf16 storage, shared and per-sample weights) against the fp64 reference."""
+    from multi_stylegan_amd import conv_ops
+    name, kind, b, i, o, h, w_, k, stride, pad = case
+    dtype, tol = torch.bfloat16, TOLS[torch.bfloat16]
+    g = torch.Generator().manual_seed(sum(ord(ch) for ch in name) * 7 + len(name))
+    for per_sample in (False, True):
+        x = torch.randn(b, i, h, w_, generator=g).to(dtype).double()
+        wshape = (b, o, i, k, k) if per_sample else (o, i, k, k)
+        w = (torch.randn(*wshape, generator=g) / math.sqrt(i * k * k)).to(dtype).double()
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = _reference(kind, xr, wr, stride, pad, per_sample)
+        gy = torch.randn(yr.shape, generator=g).to(dtype).double()
+        gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy)
+        xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd = w.to(DEV, torch.float32).requires_grad_(True)
+        geo = conv_ops.Geometry(kind, k, k, stride if kind == "conv" else 1, pad, (h, w_), per_sample)
+        y = conv_ops._ConvF.apply(xd, wd, None, geo)
+        gyd = gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last) if y.shape[1] > 1 else gy.to(DEV, dtype)
+        gx, gw = torch.autograd.grad(y, (xd, wd), gyd)
+        assert y.shape == yr.shape
+        assert rel_err(y.float(), yr) < tol, ("forward", per_sample)
+        assert rel_err(gx.float(), gxr) < tol, ("data gradient", per_sample)
+        assert rel_err(gw, gwr) < tol, ("weight gradient", per_sample)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 16, 24, 12, 12, 3), (1, 72, 136, 20, 20, 3), (3, 40, 9, 8, 8, 1),
                                    (2, 64, 256, 64, 64, 3)], ids=["small", "multi_tile", "ragged_1x1", "pp_tile"])

@@ -90,7 +90,12 @@ def bench_conv(args):
              ("D 3x3 768->768 32^2 shared", "conv", 768, 768, 32, 3, 1, 1, False),
              ("D 3x3 1024->768 32^2 shared", "conv", 1024, 768, 32, 3, 1, 1, False),
              ("D 1x1 256->128 256^2 shared", "conv", 256, 128, 256, 1, 1, 0, False),
-             ("D 3x3 6->128 256^2 shared", "conv", 6, 128, 256, 3, 1, 1, False)]
+             ("D 3x3 6->128 256^2 shared", "conv", 6, 128, 256, 3, 1, 1, False),
+             ("P 1x1 128->256 256^2 shared", "conv", 128, 256, 256, 1, 1, 0, False),
+             ("P 1x1 256->384 128^2 shared", "conv", 256, 384, 128, 1, 1, 0, False),
+             ("P 1x1 384->256 128^2 shared", "conv", 384, 256, 128, 1, 1, 0, False),
+             ("P 1x1 512->3 256^2 per-sample", "conv", 512, 3, 256, 1, 1, 0, True),
+             ("P 1x1 3->512 256^2 per-sample", "conv", 3, 512, 256, 1, 1, 0, True)]
     for dt in ((torch.bfloat16,) if not args.f32 else (torch.bfloat16, torch.float32)):
         for name, kind, i, o, r, k, s, p, ps in cases:
             if args.only and args.only not in name:

@@ -372,6 +372,60 @@ def test_fused_modulated_conv_matches_composite(kind, dtype):
         assert rel_err(a.float(), c.float()) < tol, name + " vs composite"
 
 
+def _random_mod_cases(n=14, seed=77):
+    import random
+    rng = random.Random(seed)
+    out = []
+    for idx in range(n):
+        up = rng.random() < 0.3
+        k = 2 if up else rng.choice([1, 3])
+        out.append((f"m{idx}", rng.choice([1, 2, 4]), rng.choice([8, 24, 72, 136, 520]), rng.choice([3, 8, 40, 136]),
+                    rng.choice([4, 8, 13, 16, 32]), k, up, rng.random() < 0.7, rng.random() < 0.5))
+    return out
+
+
+RANDOM_MOD_CASES = _random_mod_cases()
+
+
+@pytest.mark.parametrize("case", RANDOM_MOD_CASES, ids=[c[0] for c in RANDOM_MOD_CASES])
+def test_modulated_conv_random_geometries(case):
+    """Fused modulated conv (one-launch weight set, per-sample contraction, fused backward; optionally the activation in
+    the epilogue) against the composite torch-op formulation on random channel counts / taps / map sizes, incl. channel
+    counts beyond the fused backward's limits (I > 512 falls back to the composite inside the op)."""
+    from multi_stylegan_amd import conv_ops
+    from multi_stylegan_amd.op_static import fused_bias_noise_leaky_relu
+    name, b, i, o, h, k, up, demod, with_act = case
+    if up and o % 8:
+        o = 8 * ((o + 7) // 8)
+    dtype, tol = torch.bfloat16, TOLS[torch.bfloat16] * 1.5
+    g = torch.Generator().manual_seed(sum(ord(c) for c in name) + i + o)
+    x = torch.randn(b, i, h, h, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(1, o, i, k, k, generator=g).to(DEV)
+    st = (torch.randn(b, i, generator=g) * 0.3 + 1).to(DEV)
+    oh = 2 * h if up else h
+    gy = torch.randn(b, o, oh, oh, generator=g).to(DEV, dtype)
+    gy = gy.contiguous(memory_format=torch.channels_last) if o > 1 else gy
+    bias, nw = torch.randn(o, generator=g).to(DEV), torch.tensor([0.3], device=DEV)
+    noise = torch.randn(b, 1, oh, oh, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (x, w, st)]
+        xs, ws, ss = leaves
+        if fused:
+            if with_act and not up:
+                y = conv_ops.modulated_conv2d_bias_act(xs, ws, ss, demod, bias, noise, nw, 0.2, 1.0)
+            else:
+                y = conv_ops.modulated_conv2d(xs, ws, ss, demod, up)
+        else:
+            y = conv_ops._modulated_composite(xs, ws, ss, demod, up)
+            if with_act and not up:
+                y = fused_bias_noise_leaky_relu(y, bias, noise, nw, 0.2, 1.0)
+        res.append((y, torch.autograd.grad(y, leaves, gy)))
+    assert rel_err(res[0][0].float(), res[1][0].float()) < tol
+    for a, r, nm in zip(res[0][1], res[1][1], ("gx", "gw", "gs")):
+        assert (a.float() - r.float()).norm() / (r.float().norm() + 1e-12) < tol, nm
+
+
 PP_CASES = [  # shapes that take the 256x256 ping-pong kernel: name, kind, B, I, O, H, W, k, stride, pad, per_sample
     ("pp_3x3_ragged_m", "conv", 5, 64, 256, 15, 15, 3, 1, 1, True),            # per-sample M = 225 (< tile), many z
     ("pp_3x3_shared", "conv", 4, 72, 384, 40, 40, 3, 1, 1, False),              # N tail (384), ragged K (72)

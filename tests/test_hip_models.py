@@ -173,3 +173,23 @@ def test_config1_64px_matches_oracle():
         ws, wp = do(x)
         gs, gp = dd(x.to(DEV))
     assert rel_err(gs, ws) < TOL and rel_err(gp, wp) < TOL
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_train_iteration_odd_batches(golden, batch, dtype):
+    """Batch sizes the tile / group logic could trip over (1: every minibatch statistic degenerates; 3: the path-length
+    half batch is 1, nothing divides anything): two iterations incl. the regularised 16th run and stay finite."""
+    import multi_stylegan_amd as m
+    _, g, d = _models(golden)
+    g.compute_dtype = d.compute_dtype = dtype
+    tr = m.ModelWrapper(g, d, device=DEV)
+    tr.generator_ema.compute_dtype = dtype
+    tr.iteration = 14
+    torch.manual_seed(batch)
+    for _ in range(2):
+        tr.train_iteration(torch.rand(batch, 2, 3, 32, 32, device=DEV))
+    logs = tr.pop_logs()
+    assert {"loss_discriminator_regularization", "path_length", "loss_generator"} <= set(logs)
+    assert all(math.isfinite(v) for vals in logs.values() for v in vals)
+    assert all(torch.isfinite(p).all() for p in list(g.parameters()) + list(d.parameters()))

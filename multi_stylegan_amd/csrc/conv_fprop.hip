@@ -42,13 +42,23 @@ __device__ __attribute__((aligned(256))) unsigned int g_zero_page[16384];   // 6
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, bool DMA>
-__global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict__ x, const T* __restrict__ w,
+// LEAN (short K sweeps, n_iters <= ~2: the 1x1 convs on <= 128 channels and the gathered 6-channel input conv, whose
+// time is the OUTPUT write, not the contraction): one LDS stage instead of two (32 KiB) and <= 128 VGPRs, so four
+// workgroups share a CU and one workgroup's store burst overlaps the others' loads -- latency is hidden by occupancy
+// instead of by the in-workgroup double buffer a two-step sweep cannot fill anyway.  LEAN = workgroups per CU the
+// register budget is set for (3: 168 VGPRs, 17 spilled outside the loop; 4: 128 VGPRs spills 114 and is slower).
+// Measured (bf16, B=16, same box): 1x1 3->512 @256^2 474 -> 390 us, 1x1 128->256 @256^2 346 -> 331 us, 1x1 256->128
+// @256^2 255 -> 237 us; whole training step -1 ms.  What these launches still pay (ablations on 1x1 128->256: full 322
+// us, no global stores 246, no epilogue 172): the accumulator -> LDS -> 16-B-store epilogue is NOT hidden by the other
+// workgroups of the CU (de-phasing them with a start-up delay changed nothing, non-temporal stores neither).
+template <typename T, bool DMA, int LEAN = 0>
+__global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                             T* __restrict__ y, const float* __restrict__ bias,
                                                             ConvParams p) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int BKE = ROWB / sizeof(T);
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    static_assert(!LEAN || (!DMA && sizeof(T) == 2), "lean variant: bf16, register staging");
+    __shared__ __attribute__((aligned(16))) char smem[(LEAN ? 1 : 2) * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -88,7 +98,10 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
         a_ih0[j] = oh * p.stride - p.pad;
         a_iw0[j] = ow * p.stride - p.pad;
-        a_boff[j] = ((long long)b * p.x_bstride + slot_j * VEC) * (long long)sizeof(T);
+        // byte offset of tap (0,0) of this row's pixel (may point in front of the image for halo rows: it is only
+        // dereferenced for taps that land inside); every other tap is this plus ONE wave-uniform term
+        a_boff[j] = ((long long)b * p.x_bstride + slot_j * VEC +
+                     ((long long)a_ih0[j] * p.IW + a_iw0[j]) * p.Cx) * (long long)sizeof(T);
         a_slot[j] = slot_j;
     }
     const int taps = p.kh * p.kw;
@@ -109,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     }
     const bool ragged = (p.Cx % BKE) != 0;          // channel stride not a whole number of 128-B runs
     int ld_tap = -1, ld_chunk = p.n_chunks - 1;     // cursor of the NEXT K-step to load (advanced before each load)
+    int kh_ = 0, kw_ = -1;                          // (kh, kw) of ld_tap, advanced without a division
     int st_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) st_off[j] = swz(row_of[j], a_slot[j]);
@@ -127,18 +141,25 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         if (++ld_chunk == p.n_chunks) {         // next tap: one pointer per row (or the zero page)
             ld_chunk = 0;
             ++ld_tap;
-            const int kh_ = ld_tap / p.kw, kw_ = ld_tap - kh_ * p.kw;
+            if (++kw_ == p.kw) { kw_ = 0; ++kh_; }
+            if (p.in_up == 1) {                 // ~6 vector instructions per row: range test, 64-bit add, select
+                const long long tap_off = ((long long)kh_ * p.IW + kw_) * p.Cx * (long long)sizeof(T);   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int ih = a_ih0[j] + kh_, iw = a_iw0[j] + kw_;
-                bool ok = a_ok[j] & (ih >= 0) & (iw >= 0);
-                if (p.in_up > 1) {
-                    ok = ok & (ih % p.in_up == 0) & (iw % p.in_up == 0);
-                    ih /= p.in_up; iw /= p.in_up;
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = a_ok[j] & ((unsigned)(a_ih0[j] + kh_) < (unsigned)p.IH) &
+                                    ((unsigned)(a_iw0[j] + kw_) < (unsigned)p.IW);
+                    pa[j] = (ok ? xbase : zbase) + (ok ? a_boff[j] + tap_off : zoff);
                 }
-                ok = ok & (ih < p.IH) & (iw < p.IW);
-                const long long off = ok ? a_boff[j] + ((long long)ih * p.IW + iw) * p.Cx * (long long)sizeof(T) : zoff;
-                pa[j] = (ok ? xbase : zbase) + off;
+            } else {                            // transposed strided conv as a gather with parity holes
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ih = a_ih0[j] + kh_, iw = a_iw0[j] + kw_;
+                    bool ok = a_ok[j] & (ih >= 0) & (iw >= 0) & (ih % p.in_up == 0) & (iw % p.in_up == 0);
+                    const int ihs = ih / p.in_up, iws = iw / p.in_up;
+                    ok = ok & (ihs < p.IH) & (iws < p.IW);
+                    const long long off = a_boff[j] + ((long long)(ihs - a_ih0[j]) * p.IW + (iws - a_iw0[j])) * p.Cx * (long long)sizeof(T);
+                    pa[j] = (ok ? xbase : zbase) + (ok ? off : zoff);
+                }
             }
         }
 #pragma unroll
@@ -168,77 +189,89 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             *reinterpret_cast<u32x4*>(sb + st_off[j]) = rb[j];
         }
     };
-    // Software pipeline, ONE barrier per K-step, writes placed AFTER it: at step `it` the registers hold step it+1
-    // (loaded during step it-1); they are parked in the other LDS stage right after the barrier, the loads of step
-    // it+2 are issued, and only then the MFMAs of step `it` run -- LDS writes and global loads both fly under them.
-    if constexpr (DMA) {
-        dma_stage = 0;
-        load_next();                                // step 0 -> stage 0, asynchronously
-    } else {
-        load_next();
-        park(0);
-        if (p.n_iters > 1) load_next();
-    }
-    for (int it = 0; it < p.n_iters; ++it) {
-        __syncthreads();                            // (DMA: the barrier's vmcnt(0) is what retires step `it`'s DMA)
-        if constexpr (DMA) {
-            if (it + 1 < p.n_iters) { dma_stage = (it + 1) & 1; load_next(); }   // lands while the MFMAs below run
-        } else {
-            if (it + 1 < p.n_iters) park((it + 1) & 1);
-            if (it + 2 < p.n_iters) load_next();
-        }
-        {
-            const char* sa = smem + (it & 1) * STAGE_BYTES;
-            const char* sb = sa + BM * ROWB;
-            if constexpr (sizeof(T) == 2) {
-                // 4 k-steps of 16; the fragments of step kk+1 are requested before the MFMAs of step kk are issued,
-                // and the order is pinned (DS x8, then [MFMA x4, DS x4] ...) so LDS latency hides under the matrix pipe
-                bf16v8 fa[2][2], fb[2][2];
+    // the MFMAs of one staged K-step (stage base `sa`: 128 A rows, then 128 B rows)
+    auto mma_step = [&](const char* sa) __attribute__((always_inline)) {
+        const char* sb = sa + BM * ROWB;
+        if constexpr (sizeof(T) == 2) {
+            // 4 k-steps of 16; the fragments of step kk+1 are requested before the MFMAs of step kk are issued,
+            // and the order is pinned (DS x8, then [MFMA x4, DS x4] ...) so LDS latency hides under the matrix pipe
+            bf16v8 fa[2][2], fb[2][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    fa[0][t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, lh));
-                    fb[0][t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, lh));
+            for (int t = 0; t < 2; ++t) {
+                fa[0][t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, lh));
+                fb[0][t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, lh));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        fa[(kk + 1) & 1][t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, 2 * (kk + 1) + lh));
+                        fb[(kk + 1) & 1][t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, 2 * (kk + 1) + lh));
+                    }
                 }
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (kk + 1 < 4) {
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            fa[(kk + 1) & 1][t] = *reinterpret_cast<const bf16v8*>(sa + swz(wm * 64 + t * 32 + lr, 2 * (kk + 1) + lh));
-                            fb[(kk + 1) & 1][t] = *reinterpret_cast<const bf16v8*>(sb + swz(wn * 64 + t * 32 + lr, 2 * (kk + 1) + lh));
-                        }
-                    }
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // DS read x8 (steps 0 and 1)
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 0)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 2)
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 1)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 3)
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // MFMA x8   (steps 2, 3)
+        } else {
+            // lane half h owns k = 16h .. 16h+15 of the 32-float run (any k order is fine as long as A and B agree)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 fa[2], fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[t] = *reinterpret_cast<const f32x4*>(sa + swz(wm * 64 + t * 32 + lr, 4 * lh + q));
+                    fb[t] = *reinterpret_cast<const f32x4*>(sb + swz(wn * 64 + t * 32 + lr, 4 * lh + q));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // DS read x8 (steps 0 and 1)
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 0)
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 2)
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 1)
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 3)
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // MFMA x8   (steps 2, 3)
-            } else {
-                // lane half h owns k = 16h .. 16h+15 of the 32-float run (any k order is fine as long as A and B agree)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 fa[2], fb[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        fa[t] = *reinterpret_cast<const f32x4*>(sa + swz(wm * 64 + t * 32 + lr, 4 * lh + q));
-                        fb[t] = *reinterpret_cast<const f32x4*>(sb + swz(wn * 64 + t * 32 + lr, 4 * lh + q));
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-                }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
             }
+        }
+    };
+    if constexpr (LEAN) {
+        load_next();
+        for (int it = 0; it < p.n_iters; ++it) {
+            if (it) __syncthreads();                    // everyone done reading the single stage
+            park(0);
+            if (it + 1 < p.n_iters) load_next();        // flies under the MFMAs below
+            __syncthreads();
+            mma_step(smem);
+        }
+    } else {
+        // Software pipeline, ONE barrier per K-step, writes placed AFTER it: at step `it` the registers hold step it+1
+        // (loaded during step it-1); they are parked in the other LDS stage right after the barrier, the loads of step
+        // it+2 are issued, and only then the MFMAs of step `it` run -- LDS writes and global loads both fly under them.
+        if constexpr (DMA) {
+            dma_stage = 0;
+            load_next();                                // step 0 -> stage 0, asynchronously
+        } else {
+            load_next();
+            park(0);
+            if (p.n_iters > 1) load_next();
+        }
+        for (int it = 0; it < p.n_iters; ++it) {
+            __syncthreads();                            // (DMA: the barrier's vmcnt(0) is what retires step `it`'s DMA)
+            if constexpr (DMA) {
+                if (it + 1 < p.n_iters) { dma_stage = (it + 1) & 1; load_next(); }   // lands while the MFMAs below run
+            } else {
+                if (it + 1 < p.n_iters) park((it + 1) & 1);
+                if (it + 2 < p.n_iters) load_next();
+            }
+            mma_step(smem + (it & 1) * STAGE_BYTES);
         }
     }
     __syncthreads();                                 // everyone done with the staging buffers: the epilogue reuses them
@@ -428,8 +461,11 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     // staging: LDS-DMA (global_load_lds) for long K sweeps, register staging (two steps in flight) for short ones;
     // MSG_CONV_VARIANT=1 / 2 forces DMA / registers (A/B measurements)
     const bool dma = variant == 1 || (variant == 0 && p.n_iters >= 12);
+    static int lean_max = -1;                       // MSG_CONV_LEAN=<n>: lean variant for n_iters <= n (0 = never)
+    if (lean_max < 0) { const char* e = getenv("MSG_CONV_LEAN"); lean_max = e ? atoi(e) : 4; }
     if (dtype == MSG_BF16) {
-        if (dma) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
+        if (!dma && p.n_iters <= lean_max) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
+        else if (dma) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
         else hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
     } else {
         if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);

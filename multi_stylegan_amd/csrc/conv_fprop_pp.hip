@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[h * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[h * 2 + i][j], 0, 0, 0);
+                    acc[h * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[i][ks], acc[h * 2 + i][j], 0, 0, 0);   // D^T: see epilogue
             if (dma) issue_one(2 + (ks >> 1), (ks & 1) != 0, stage);
         }
     };
@@ -273,76 +273,106 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     }
     if (grp == 0) PP_BARRIER();
 
-    // ---- epilogue: wave-private 128 x 64 bf16 patch in LDS (16 KiB per wave = all 128 KiB), then 16-B stores
+    // ---- epilogue: wave-private 128 x 64 bf16 patch in LDS (16 KiB per wave = all 128 KiB), then 16-B stores.
+    // The MFMAs were issued with the operands swapped, so an accumulator block holds the TRANSPOSED product: lane
+    // (lr, lh) owns pixel 32 i + lr and, per group g = e >> 2, the four CONSECUTIVE channels 32 j + 8 g + 4 lh + (0..3).
+    // They go to LDS as one packed 8-byte write (32 ds_write_b64 per wave instead of 128 ds_write_b16); 8-byte unit u
+    // of row r lives at unit u ^ (r & 15), which spreads the 16 rows of a lane group over all banks.
     constexpr int PITCH = 64 * ESZ;
     char* ep = smem + wid * (128 * PITCH);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j * 32 + lr;
-            const int n = n0 + wn * 64 + col;
-            const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const int unit = 8 * j + 2 * g + lh;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                const int nb = n0 + wn * 64 + 4 * unit;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                reinterpret_cast<bf16_t*>(ep + row * PITCH)[col] = f2bf(acc[i][j][e] + bv);
+                for (int e = 0; e < 4; ++e) bv[e] = nb + e < p.N ? bias[nb + e] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 32 + lr;
+                uint2 pk;
+                pk.x = (unsigned)f2bf(acc[i][j][4 * g + 0] + bv[0]) | ((unsigned)f2bf(acc[i][j][4 * g + 1] + bv[1]) << 16);
+                pk.y = (unsigned)f2bf(acc[i][j][4 * g + 2] + bv[2]) | ((unsigned)f2bf(acc[i][j][4 * g + 3] + bv[3]) << 16);
+                *reinterpret_cast<uint2*>(ep + row * PITCH + ((unit ^ (row & 15)) << 3)) = pk;
             }
         }
     const int er = lane >> 3, ec = (lane & 7) * VEC;          // 8 lanes per 64-channel row, 8 rows per pass
-    // fused activation stage: bias vector and per-row noise values are fetched before the barrier (latency hidden)
+    const int n = n0 + wn * 64 + ec;
+    int nn = n, q = 0;
+    if (p.pixel_shuffle) { const int oc = p.N >> 2; q = n / oc; nn = n - q * oc; }
+    const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;  // valid elements left in this channel run
+    const bool n_ok = n < p.N;
+    // Row coordinates (sample, oh, ow) of this lane's row of pass 0 by division ONCE; every later pass is 8 pixels
+    // further along and is reached by stepping.  gp[pass] = index of the OUTPUT pixel the row is stored to (sample-
+    // major, pixel-shuffled where asked), -1 for rows past M; the fused stage's bias vector and per-row noise values
+    // are fetched in the same sweep, before the barrier.
+    int gp[16];
     float a_bias[VEC], a_noise[16];
-    if (p.act.enabled == 1) {
-        const int n = n0 + wn * 64 + ec;
+    {
+        const int m_first = min(m0 + grp * 128 + er, p.Mtot - 1);
+        int b = p.per_sample ? bz : m_first / ohw;
+        const int pix0 = p.per_sample ? m_first : m_first - b * ohw;
+        int oh = pix0 / p.OW, ow = pix0 - oh * p.OW;
+        const bool want_noise = p.act.enabled == 1 && p.act.noise;
+        const float nw = want_noise ? p.act.noise_w[0] : 0.f;
+        if (p.act.enabled == 1) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
-        const float nw = p.act.noise ? p.act.noise_w[0] : 0.f;
+            for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
+        }
 #pragma unroll
         for (int pass = 0; pass < 16; ++pass) {
-            const int m = m0 + grp * 128 + pass * 8 + er;
-            float nz = 0.f;
-            if (p.act.noise && m < p.Mtot) {
-                const int b = p.per_sample ? bz : m / ohw;
-                const int pix = p.per_sample ? m : m - b * ohw;
-                nz = nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix];
-            }
-            a_noise[pass] = nz;
+            const bool ok = m0 + grp * 128 + pass * 8 + er < p.Mtot;
+            const int pix = oh * p.OW + ow;
+            const int g = p.pixel_shuffle ? ((b * 2 * p.OH + 2 * oh + (q >> 1)) * (2 * p.OW) + 2 * ow + (q & 1))
+                                          : b * ohw + pix;
+            gp[pass] = ok ? g : -1;
+            a_noise[pass] = (want_noise && ok) ? nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix] : 0.f;
+            ow += 8;
+            while (ow >= p.OW) { ow -= p.OW; ++oh; }
+            if (!p.per_sample) while (oh >= p.OH) { oh -= p.OH; ++b; }
         }
     }
     __syncthreads();
+    // All 16 patch rows are read (and, for the residual merge, all 16 residual vectors requested) BEFORE any of them is
+    // used: one LDS / HBM latency per tile instead of one per pass.  16-byte unit (lane & 7) of a row = 8-byte units
+    // 2 (lane & 7), +1, stored at (unit ^ (row & 15)): one aligned 16-byte read, halves swapped when the row is odd.
+    u32x4 v[16];
 #pragma unroll
     for (int pass = 0; pass < 16; ++pass) {
         const int row = pass * 8 + er;
-        const int m = m0 + grp * 128 + row;
-        const int n = n0 + wn * 64 + ec;
-        if (m >= p.Mtot || n >= p.N) continue;
-        const int b = p.per_sample ? bz : m / ohw;
-        const int pix = p.per_sample ? m : m - b * ohw;
-        const int oh = pix / p.OW, ow = pix - oh * p.OW;
-        bf16_t* dst;
-        int nn = n;
-        if (p.pixel_shuffle) {
-            const int oc = p.N >> 2, q = n / oc;
-            nn = n - q * oc;
-            dst = y + (long long)b * p.y_bstride + ((long long)(2 * oh + (q >> 1)) * (2 * p.OW) + (2 * ow + (q & 1))) * p.ldy + nn;
-        } else {
-            dst = y + (long long)b * p.y_bstride + ((long long)oh * p.OW + ow) * p.ldy + n;
-        }
-        const bf16_t* src = reinterpret_cast<const bf16_t*>(ep + row * PITCH) + ec;
-        const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;
-        u32x4 v = *reinterpret_cast<const u32x4*>(src);
-        if (p.act.enabled == 1) v = act_epilogue_apply<bf16_t>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
-        else if (p.act.enabled == 2) {                       // residual merge (never with pixel_shuffle)
-            const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.act.residual) +
-                            ((long long)b * ohw + pix) * p.act.res_ld + n;
-            v = residual_epilogue_apply<bf16_t>(v, *reinterpret_cast<const u32x4*>(rp), p.act.res_gain);
-        }
-        if (lim >= VEC) {
-            *reinterpret_cast<u32x4*>(dst) = v;
-        } else {
-            bf16_t tmp[VEC];
-            *reinterpret_cast<u32x4*>(tmp) = v;
-            for (int e = 0; e < lim; ++e) dst[e] = tmp[e];
+        v[pass] = *reinterpret_cast<const u32x4*>(ep + row * PITCH + (((lane & 7) ^ ((row & 15) >> 1)) << 4));
+    }
+    if (er & 1) {
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) v[pass] = u32x4{v[pass][2], v[pass][3], v[pass][0], v[pass][1]};
+    }
+    if (p.act.enabled == 1) {
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) v[pass] = act_epilogue_apply<bf16_t>(v[pass], a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+    } else if (p.act.enabled == 2) {                          // residual merge (never with pixel_shuffle)
+        const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.act.residual) + (n_ok ? n : 0);
+        u32x4 r[16];
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass)
+            r[pass] = *reinterpret_cast<const u32x4*>(rbase + (long long)max(gp[pass], 0) * p.act.res_ld);
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) v[pass] = residual_epilogue_apply<bf16_t>(v[pass], r[pass], p.act.res_gain);
+    }
+    bf16_t* ybase = y + (p.pixel_shuffle ? nn : n);
+    if (n_ok && lim >= VEC) {
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass)
+            if (gp[pass] >= 0) *reinterpret_cast<u32x4*>(ybase + (long long)gp[pass] * p.ldy) = v[pass];
+    } else if (n_ok) {                                        // ragged channel tail: element stores
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            if (gp[pass] < 0) continue;
+            bf16_t* dst = ybase + (long long)gp[pass] * p.ldy;
+            for (int e = 0; e < lim; ++e) dst[e] = (bf16_t)(v[pass][e >> 1] >> (16 * (e & 1)));
         }
     }
 }

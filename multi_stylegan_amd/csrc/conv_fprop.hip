@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);   // D^T: see epilogue
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // DS read x8 (steps 0 and 1)
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 0)
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][e], fa[i][e], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -276,79 +276,121 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
     }
     __syncthreads();                                 // everyone done with the staging buffers: the epilogue reuses them
 
-    // ---- epilogue: accumulators -> LDS (wave-private 64x64 patch) -> 16-B stores
+    // ---- epilogue: accumulators -> LDS (wave-private 64x64 patch) -> 16-B stores.
+    // The MFMAs ran with the operands swapped, so an accumulator block is the TRANSPOSED product: lane (lr, lh) owns
+    // pixel 32 i + lr and, per group g = e >> 2, the four CONSECUTIVE channels 32 j + 8 g + 4 lh + (0..3).  They go to
+    // LDS as ONE packed write (8 B bf16 / 16 B f32); 4-channel unit u of row r lives at unit u ^ (r & 15), which spreads
+    // the 16 rows a lane group writes over all banks.
     constexpr int PITCH = 64 * sizeof(T);     // f32: 4 waves x 64 rows x 256 B = exactly the 64 KiB of staging LDS
+    constexpr int UNITB = 4 * sizeof(T);
     char* ep = smem + wid * (64 * PITCH);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j * 32 + lr;
-            const int n = n0 + wn * 64 + col;
-            const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const int unit = 8 * j + 2 * g + lh;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                const int nb = n0 + wn * 64 + 4 * unit;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                store_from_f32(reinterpret_cast<T*>(ep + row * PITCH) + col, acc[i][j][e] + bv);
+                for (int e = 0; e < 4; ++e) bv[e] = nb + e < p.N ? bias[nb + e] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = i * 32 + lr;
+                char* dstl = ep + row * PITCH + ((unit ^ (row & 15)) * UNITB);
+                if constexpr (sizeof(T) == 2) {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(acc[i][j][4 * g + 0] + bv[0]) | ((unsigned)f2bf(acc[i][j][4 * g + 1] + bv[1]) << 16);
+                    pk.y = (unsigned)f2bf(acc[i][j][4 * g + 2] + bv[2]) | ((unsigned)f2bf(acc[i][j][4 * g + 3] + bv[3]) << 16);
+                    *reinterpret_cast<uint2*>(dstl) = pk;
+                } else {
+                    *reinterpret_cast<f32x4*>(dstl) = f32x4{acc[i][j][4 * g + 0] + bv[0], acc[i][j][4 * g + 1] + bv[1],
+                                                            acc[i][j][4 * g + 2] + bv[2], acc[i][j][4 * g + 3] + bv[3]};
+                }
             }
         }
     constexpr int LPR = 64 / VEC;                                  // lanes per 64-element row
     constexpr int RPP = 64 / LPR;                                  // rows per pass
+    constexpr int NPASS = 64 / RPP;
     const int er = lane / LPR, ec = (lane % LPR) * VEC;
-    // fused activation stage: this lane's bias vector and the noise value of each of its rows are fetched HERE, before
-    // the barrier, so their latency hides behind it instead of sitting in front of every store
-    float a_bias[VEC], a_noise[64 / RPP];
-    if (p.act.enabled == 1) {
-        const int n = n0 + wn * 64 + ec;
+    const int n = n0 + wn * 64 + ec;
+    int nn = n, q = 0;
+    if (p.pixel_shuffle) { const int oc = p.N >> 2; q = n / oc; nn = n - q * oc; }
+    const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;  // valid elements left in this channel run
+    const bool n_ok = n < p.N;
+    // Row coordinates (sample, oh, ow) of this lane's row of pass 0 by division ONCE; later passes are RPP pixels further
+    // along and are reached by stepping.  gp[pass] = index of the OUTPUT pixel the row is stored to (sample-major,
+    // pixel-shuffled where asked), -1 for rows past M; the fused stage's bias vector and per-row noise values are
+    // fetched in the same sweep, before the barrier.
+    int gp[NPASS];
+    float a_bias[VEC], a_noise[NPASS];
+    {
+        const int m_first = min(m0 + wm * 64 + er, p.Mtot - 1);
+        int b = p.per_sample ? bz : m_first / ohw;
+        const int pix0 = p.per_sample ? m_first : m_first - b * ohw;
+        int oh = pix0 / p.OW, ow = pix0 - oh * p.OW;
+        const bool want_noise = p.act.enabled == 1 && p.act.noise;
+        const float nw = want_noise ? p.act.noise_w[0] : 0.f;
+        if (p.act.enabled == 1) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
-        const float nw = p.act.noise ? p.act.noise_w[0] : 0.f;
+            for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
+        }
 #pragma unroll
-        for (int pass = 0; pass < 64 / RPP; ++pass) {
-            const int m = m0 + wm * 64 + pass * RPP + er;
-            float nz = 0.f;
-            if (p.act.noise && m < p.Mtot) {
-                const int b = p.per_sample ? bz : m / ohw;
-                const int pix = p.per_sample ? m : m - b * ohw;
-                nz = nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix];
-            }
-            a_noise[pass] = nz;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const bool ok = m0 + wm * 64 + pass * RPP + er < p.Mtot;
+            const int pix = oh * p.OW + ow;
+            const int g = p.pixel_shuffle ? ((b * 2 * p.OH + 2 * oh + (q >> 1)) * (2 * p.OW) + 2 * ow + (q & 1))
+                                          : b * ohw + pix;
+            gp[pass] = ok ? g : -1;
+            a_noise[pass] = (want_noise && ok) ? nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix] : 0.f;
+            ow += RPP;
+            while (ow >= p.OW) { ow -= p.OW; ++oh; }
+            if (!p.per_sample) while (oh >= p.OH) { oh -= p.OH; ++b; }
         }
     }
     __syncthreads();
+    // All patch rows are read (and, for the residual merge, all residual vectors requested) BEFORE any is used: one LDS
+    // / HBM latency per tile instead of one per pass.
+    u32x4 v[NPASS];
 #pragma unroll
-    for (int pass = 0; pass < 64 / RPP; ++pass) {                  // (fully unrolled: a_noise[pass] lives in registers)
+    for (int pass = 0; pass < NPASS; ++pass) {
         const int row = pass * RPP + er;
-        const int m = m0 + wm * 64 + row;
-        const int n = n0 + wn * 64 + ec;
-        if (m >= p.Mtot || n >= p.N) continue;
-        const int b = p.per_sample ? bz : m / ohw;
-        const int pix = p.per_sample ? m : m - b * ohw;
-        const int oh = pix / p.OW, ow = pix - oh * p.OW;
-        T* dst;
-        int nn = n;
-        if (p.pixel_shuffle) {
-            const int oc = p.N >> 2, q = n / oc;
-            nn = n - q * oc;
-            dst = y + (long long)b * p.y_bstride +
-                  ((long long)(2 * oh + (q >> 1)) * (2 * p.OW) + (2 * ow + (q & 1))) * p.ldy + nn;
-        } else {
-            dst = y + (long long)b * p.y_bstride + ((long long)oh * p.OW + ow) * p.ldy + n;
+        if constexpr (sizeof(T) == 2)      // 16-B unit = two 8-B units stored at (unit ^ (row & 15)): halves swap on odd rows
+            v[pass] = *reinterpret_cast<const u32x4*>(ep + row * PITCH + (((lane & 7) ^ ((row & 15) >> 1)) << 4));
+        else
+            v[pass] = *reinterpret_cast<const u32x4*>(ep + row * PITCH + (((lane & 15) ^ (row & 15)) << 4));
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (er & 1) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) v[pass] = u32x4{v[pass][2], v[pass][3], v[pass][0], v[pass][1]};
         }
-        const T* src = reinterpret_cast<const T*>(ep + row * PITCH) + ec;
-        const int lim = p.pixel_shuffle ? (p.N >> 2) - nn : p.N - n;  // valid elements left in this channel run
-        u32x4 v = *reinterpret_cast<const u32x4*>(src);
-        if (p.act.enabled == 1) v = act_epilogue_apply<T>(v, a_bias, a_noise[pass], p.act.alpha, p.act.scale);
-        else if (p.act.enabled == 2) {                       // residual merge (never with pixel_shuffle)
-            const T* rp = reinterpret_cast<const T*>(p.act.residual) +
-                            ((long long)b * ohw + pix) * p.act.res_ld + n;
-            v = residual_epilogue_apply<T>(v, *reinterpret_cast<const u32x4*>(rp), p.act.res_gain);
-        }
-        if (lim >= VEC) {
-            *reinterpret_cast<u32x4*>(dst) = v;
-        } else {
+    }
+    if (p.act.enabled == 1) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) v[pass] = act_epilogue_apply<T>(v[pass], a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+    } else if (p.act.enabled == 2) {                          // residual merge (never with pixel_shuffle)
+        const T* rbase = reinterpret_cast<const T*>(p.act.residual) + (n_ok ? n : 0);
+        u32x4 r[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass)
+            r[pass] = *reinterpret_cast<const u32x4*>(rbase + (long long)max(gp[pass], 0) * p.act.res_ld);
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) v[pass] = residual_epilogue_apply<T>(v[pass], r[pass], p.act.res_gain);
+    }
+    T* ybase = y + (p.pixel_shuffle ? nn : n);
+    if (n_ok && lim >= VEC) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass)
+            if (gp[pass] >= 0) *reinterpret_cast<u32x4*>(ybase + (long long)gp[pass] * p.ldy) = v[pass];
+    } else if (n_ok) {                                        // ragged channel tail: element stores
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (gp[pass] < 0) continue;
             T tmp[VEC];
-            *reinterpret_cast<u32x4*>(tmp) = v;
+            *reinterpret_cast<u32x4*>(tmp) = v[pass];
+            T* dst = ybase + (long long)gp[pass] * p.ldy;
             for (int e = 0; e < lim; ++e) dst[e] = tmp[e];
         }
     }

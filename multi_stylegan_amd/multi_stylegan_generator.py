@@ -23,6 +23,9 @@ import torch.nn as nn
 from . import conv_ops, equalized_layer
 from .op_static import FusedLeakyReLU, blur_bias_act, fused_bias_noise_leaky_relu, upfirdn2d
 
+# 0: the two RGB heads of a level as two modulated convs (A/B; same result up to the rounding of one bf16 add)
+PAIR_OUTPUT_HEADS = bool(int(os.environ.get("MSG_PAIR_HEADS", "1")))
+
 
 def _fir2d(taps, gain=1.0):
     t = torch.tensor(list(taps), dtype=torch.float32)
@@ -267,6 +270,30 @@ class Generator(nn.Module):
                               styles[1].unsqueeze(1).repeat(1, n - inject_index, 1)], dim=1)
         return self.style_mapping(input).unsqueeze(1).repeat(1, n, 1)
 
+    @staticmethod
+    def _paired_heads(head1: "OutputBlock", head2: "OutputBlock", features: torch.Tensor, latent_w: torch.Tensor,
+                      skip1: torch.Tensor, skip2: torch.Tensor):
+        """output_blocks_1[i](features, w) and output_blocks_2[i](features, style_1): the reference's second head
+        reads stream 1's features with stream 1's modulated style (multi_stylegan_generator.py:184-189), and neither
+        head demodulates, so the two 1x1 modulated convs are ONE contraction with the weights stacked along the output
+        channels -- the 512-channel map is read once instead of twice, and backward gets its gradient from one
+        6-channel data-gradient conv instead of two 3-channel ones plus an add over the whole map."""
+        mc1, mc2 = head1.modulated_convolution, head2.modulated_convolution
+        if not (PAIR_OUTPUT_HEADS and features.is_cuda and mc1.modulation_mapping is not None
+                and mc2.modulation_mapping is None and not mc1.demodulate and not mc2.demodulate):
+            skip1, style = head1(features, latent_w, skip=skip1)
+            return skip1, head2(features, style, skip=skip2), style
+        bsz, o1 = features.shape[0], mc1.out_channels
+        style = mc1.modulation_mapping(latent_w).view(bsz, 1, mc1.in_channels, 1, 1)
+        both = conv_ops.modulated_conv2d(features, torch.cat([mc1.weight, mc2.weight], dim=1),
+                                         style.reshape(bsz, mc1.in_channels), demodulate=False, upsample=False)
+        rgb1 = both[:, :o1].float().contiguous() + head1.bias
+        rgb2 = both[:, o1:].float().contiguous() + head2.bias
+        if skip1 is not None:
+            rgb1 = rgb1 + head1.upsampling(skip1)
+            rgb2 = rgb2 + head2.upsampling(skip2)
+        return rgb1, rgb2, style
+
     def forward(self, input: Union[List[torch.Tensor], torch.Tensor], return_main_style_vectors: bool = False,
                 noise: Optional[List[torch.Tensor]] = None, randomize_noise: bool = True,
                 inject_index: Optional[int] = None, input_is_latent: bool = False,
@@ -297,8 +324,8 @@ class Generator(nn.Module):
                                                                noise=layer_noise[2 * i + 1])
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i + 1](out2, style, noise=layer_noise[2 * i + 1])
-            skip1, style = self.output_blocks_1[i](out1, latent[:, 2 * i + 3], skip=skip1)
-            skip2 = self.output_blocks_2[i](out1, style, skip=skip2)     # reads stream 1, as the reference does
+            skip1, skip2, style = self._paired_heads(self.output_blocks_1[i], self.output_blocks_2[i], out1,
+                                                     latent[:, 2 * i + 3], skip1, skip2)
         image = torch.stack([skip1, skip2], dim=1)
         if return_path_length_grads:
             if path_length_noise is None:

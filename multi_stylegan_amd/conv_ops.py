@@ -486,7 +486,10 @@ def _act_operands(bias, noise, noise_w, y_shape):
     return b32, nz, nw
 
 
-def _d_raw(gy, w, g: Geometry):
+def _d_raw(gy, w, g: Geometry, residual=None):
+    """Data gradient; residual = (map shaped like the result, gain): (dgrad + map) * gain in the epilogue (plain
+    stride-1 convs only -- the caller checks)."""
+    assert residual is None or (g.kind == "conv" and g.stride == 1)
     if g.kind == "conv" and g.stride == 2 and _S2_PARITY and _oi(w)[1] % _vec(gy.dtype) == 0:
         return _d_raw_s2(gy, w, g)          # (the pixel-shuffling epilogue needs whole 16-byte channel vectors)
     i = _oi(w)[1]
@@ -497,7 +500,8 @@ def _d_raw(gy, w, g: Geometry):
         return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample, _oi(w)[0])
     pad = g.kh - 1 - g.pad
     assert g.kh == g.kw
-    return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample, _oi(w)[0])
+    return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample, _oi(w)[0],
+                         residual=residual)
 
 
 def _d_raw_s2(gy, w, g: Geometry):
@@ -580,10 +584,11 @@ class _ConvActF(Function):
     D / G contractions), so first- and second-order gradients are those of conv followed by FusedLeakyReLU."""
 
     @staticmethod
-    def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale):
+    def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale, slot=None):
         o = _oi(w)[0]
         b32, nz, nw = _act_operands(act_bias, noise, noise_w, (x.shape[0], o, *g.y_hw))
         y = _f_raw(x, w, None, g, act=(b32, nz, nw, alpha, scale))
+        ctx.slot = slot
         ctx.g, ctx.cfg = g, (alpha, scale, act_bias is not None, noise is not None)
         ctx.nw_shape = None if noise_w is None else noise_w.shape
         ctx.save_for_backward(x, w, y, noise)
@@ -596,10 +601,20 @@ class _ConvActF(Function):
         alpha, scale, has_bias, has_noise = ctx.cfg
         g = ctx.g
         gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha, scale)
-        gx = _ConvD.apply(gpre, w, g) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            other = ctx.slot.g if ctx.slot is not None else None
+            if other is not None and not torch.is_grad_enabled() and g.kind == "conv" and g.stride == 1 and \
+                    other.shape == x.shape and other.dtype == gpre.dtype:
+                # the block input's OTHER gradient (from the 1x1 residual conv, computed just before) is added in this
+                # data-gradient conv's epilogue: no separate accumulation pass over the input map
+                gx = _d_raw(gpre, w, g, residual=(other, 1.0))
+                ctx.slot.merged = True
+            else:
+                gx = _ConvD.apply(gpre, w, g)
         gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
-            (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None
+            (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None
 
 
 class _ConvResidualF(Function):
@@ -608,8 +623,9 @@ class _ConvResidualF(Function):
     rescaled gradient goes to `main` as it is and through the D / G contractions to x and w."""
 
     @staticmethod
-    def forward(ctx, x, w, main, g, gain, fork):
+    def forward(ctx, x, w, main, g, gain, fork, slot=None):
         y = _f_raw(x, w, None, g, residual=(main, gain))
+        ctx.slot = slot
         ctx.g, ctx.gain, ctx.fork = g, float(gain), fork
         ctx.save_for_backward(x, w)
         return (y, y.view_as(y)) if fork else y
@@ -627,25 +643,63 @@ class _ConvResidualF(Function):
         else:
             gs = (g1 + g2) * ctx.gain
         gx = _ConvD.apply(gs, w, ctx.g) if ctx.needs_input_grad[0] else None
+        if ctx.slot is not None and gx is not None and not torch.is_grad_enabled():
+            ctx.slot.g = gx                  # the main branch's first conv adds it in its data-gradient epilogue
         gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g) if ctx.needs_input_grad[1] else None
-        return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None
+        return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None
 
 
-def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, fork=False):
+class GradSlot:
+    """Hand-over point between the two consumers of a block input (see fork_input)."""
+    __slots__ = ("g", "merged")
+
+    def __init__(self):
+        self.g, self.merged = None, False
+
+
+class _ForkInput(Function):
+    """x -> two aliases for a discriminator block input read by the main branch's first conv AND by the 1x1 residual
+    conv.  In backward the residual conv runs first (it is the last node of the block), leaves its input gradient in
+    the slot, and the main branch's first conv -- the last node of the block to run -- adds it in the epilogue of its
+    data-gradient conv; this node then passes that sum on instead of adding two maps in a separate pass.  Whenever
+    the hand-over did not happen (second-order graphs, other shapes, another order) it adds them itself."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_main, g_res):
+        slot = ctx.slot
+        merged, slot.g, slot.merged = slot.merged, None, False
+        if merged or g_res is None:
+            return g_main, None
+        if g_main is None:
+            return g_res, None
+        return g_main + g_res, None
+
+
+def fork_input(x, slot: GradSlot):
+    return _ForkInput.apply(x, slot)
+
+
+def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, fork=False, grad_slot=None):
     """(conv(x, wscale * weight) + main) * gain; with fork=True two aliases of the result (see scaled_add_fork)."""
     s = stride if isinstance(stride, int) else stride[0]
     p = padding if isinstance(padding, int) else padding[0]
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
-    return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork))
+    return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork), grad_slot)
 
 
 # ------------------------------------------------------------------------------------------------- public entry
-def conv2d_bias_act(x, weight, act_bias, stride=1, padding=0, wscale=1.0, negative_slope=0.2, scale=1.0):
+def conv2d_bias_act(x, weight, act_bias, stride=1, padding=0, wscale=1.0, negative_slope=0.2, scale=1.0,
+                    grad_slot=None):
     """leaky_relu(conv(x, wscale * weight) + act_bias) * scale in one launch (EqualizedConv2d -> FusedLeakyReLU)."""
     s = stride if isinstance(stride, int) else stride[0]
     p = padding if isinstance(padding, int) else padding[0]
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
-    return _ConvActF.apply(x, weight, act_bias, None, None, g, float(negative_slope), float(scale))
+    return _ConvActF.apply(x, weight, act_bias, None, None, g, float(negative_slope), float(scale), grad_slot)
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):

@@ -16,6 +16,7 @@ from .op_static import FusedLeakyReLU, scaled_add, scaled_add_fork, upfirdn2d
 
 FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
 COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
+FUSE_INPUT_FORK = bool(int(os.environ.get("MSG_FUSE_INPUT_FORK", "1")))     # 0: autograd adds a block input's two gradients (A/B)
 
 
 def _fir2d(taps, gain=1.0):
@@ -97,14 +98,22 @@ class ResNetBlock(nn.Module):
 
     def _merge(self, input: torch.Tensor, merge):
         conv1, act1, conv2, act2 = self.main_mapping            # conv -> bias + leaky ReLU fused per pair
-        output = conv2.forward_activated(conv1.forward_activated(self.mini_batch_std_dev(input), act1), act2)
         res = self.residual_mapping
-        if FUSE_RESIDUAL and isinstance(res, equalized_layer.EqualizedConv2d) and res.bias is None and \
-                input.is_cuda and output.dtype == input.dtype:
+        fuse_res = FUSE_RESIDUAL and isinstance(res, equalized_layer.EqualizedConv2d) and res.bias is None and \
+            input.is_cuda
+        slot, x_main, x_res = None, self.mini_batch_std_dev(input), input
+        if fuse_res and FUSE_INPUT_FORK and conv_ops.FUSE_ACTIVATION and input.requires_grad and x_main is input \
+                and conv1.bias is None:
+            # the input's two gradients (main 3x3 conv, 1x1 residual conv) meet in the 3x3 conv's data-gradient epilogue
+            slot = conv_ops.GradSlot()
+            x_main, x_res = conv_ops.fork_input(input, slot)
+        output = conv2.forward_activated(conv1.forward_activated(x_main, act1, grad_slot=slot), act2)
+        if fuse_res and output.dtype == input.dtype:
             # (main + conv1x1(input)) / sqrt(2) in the epilogue of the 1x1 conv: no separate merge pass
-            return conv_ops.conv2d_add_residual(input, res.weight, output, 1.0 / math.sqrt(2), stride=res.stride,
-                                                padding=res.padding, wscale=res.scale, fork=merge is scaled_add_fork)
-        return merge(output, res(input), 1.0 / math.sqrt(2))
+            return conv_ops.conv2d_add_residual(x_res, res.weight, output, 1.0 / math.sqrt(2), stride=res.stride,
+                                                padding=res.padding, wscale=res.scale, fork=merge is scaled_add_fork,
+                                                grad_slot=slot)
+        return merge(output, res(x_res), 1.0 / math.sqrt(2))
 
 
 class NonLocalBlock(nn.Module):

@@ -193,3 +193,50 @@ def test_train_iteration_odd_batches(golden, batch, dtype):
     assert {"loss_discriminator_regularization", "path_length", "loss_generator"} <= set(logs)
     assert all(math.isfinite(v) for vals in logs.values() for v in vals)
     assert all(torch.isfinite(p).all() for p in list(g.parameters()) + list(d.parameters()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_input_gradient_merge(dtype):
+    """A ResNet block's input feeds the main 3x3 conv and the 1x1 residual conv; first-order backward hands the
+    residual conv's input gradient to the 3x3 conv's data-gradient epilogue (conv_ops.fork_input).  Same gradients as
+    autograd's own accumulation, the hand-over really happens, and second-order graphs (R1) fall back to the plain add."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd import conv_ops, u_net_2d_discriminator as U
+    torch.manual_seed(5)
+    block = U.ResNetBlock(64, 32).to(DEV)
+    x0 = conv_ops.to_compute_layout(torch.randn(3, 64, 24, 20, device=DEV), dtype)
+    gy = conv_ops.to_compute_layout(torch.randn(3, 32, 24, 20, device=DEV), dtype)
+    calls = []
+    orig = conv_ops._d_raw
+    def spy(gy_, w_, g_, residual=None):
+        calls.append(residual is not None)
+        return orig(gy_, w_, g_, residual=residual)
+    grads = {}
+    for flag in (False, True):
+        U.FUSE_INPUT_FORK = flag
+        calls.clear()
+        conv_ops._d_raw = spy
+        try:
+            x = x0.clone().requires_grad_(True)
+            block.zero_grad()
+            block(x).backward(gy)
+        finally:
+            conv_ops._d_raw = orig
+        grads[flag] = (x.grad.float(), [p.grad.clone() for p in block.parameters()])
+        assert any(calls) == flag, "the merged data-gradient epilogue must run exactly when the fork is enabled"
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(grads[True][0], grads[False][0]) < tol
+    for a, b in zip(grads[True][1], grads[False][1]):
+        assert rel_err(a, b) < tol
+    # second order: grad of |dy/dx|^2 wrt the weights, merged path must step aside
+    U.FUSE_INPUT_FORK = True
+    outs = {}
+    for flag in (False, True):
+        U.FUSE_INPUT_FORK = flag
+        x = x0.clone().requires_grad_(True)
+        gx, = torch.autograd.grad(block(x).float().sum(), x, create_graph=True)
+        pen = gx.float().square().sum()
+        outs[flag] = torch.autograd.grad(pen, list(block.parameters()))
+    U.FUSE_INPUT_FORK = True
+    for a, b in zip(outs[True], outs[False]):
+        assert rel_err(a, b) < (1e-4 if dtype == torch.float32 else 5e-2)

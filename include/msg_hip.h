@@ -192,6 +192,15 @@ int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n
 int msg_scaled_add_rows(const void* a, const void* b, void* y, int dtype, long long rows, int cols,
                         long long lda, long long ldb, long long ldy, float beta, float gain, void* stream);
 
+/* Row softmax of the non-local block's attention map and its backward (u_net_2d_discriminator.py:378:
+ * F.softmax(torch.bmm(theta^T, phi), -1)): x, y [rows][cols] contiguous in the storage type, fp32 arithmetic,
+ *   y = softmax(x) along cols;   gx = y * (gy - sum_c gy[c] * y[c]).
+ * One wave keeps a row in registers (read once, written once): cols a multiple of the 16-byte vector and at most 4096;
+ * larger rows: MSG_EUNSUPPORTED. */
+int msg_softmax_rows(const void* x, void* y, int dtype, long long rows, int cols, void* stream);
+int msg_softmax_rows_backward(const void* y, const void* gy, void* gx, int dtype, long long rows, int cols,
+                              void* stream);
+
 /* msg_conv2d_fprop with the activation stage of the layer fused into the epilogue:
  *   y = leaky_relu(conv(x, w) + noise_weight[0] * noise[b or 0, pixel] + act_bias[n], alpha) * scale
  * i.e. EqualizedConv2d -> FusedLeakyReLU (u_net_2d_discriminator.py:160-171) and ModulatedConv2d -> NoiseInjection ->

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "msg_gather_taps": (_I, [_P, _P, _I] + [_I] * 9 + [_P]),
     "msg_scaled_add": (_I, [_P, _P, _P, _I, _L, _F, _F, _P]),
     "msg_scaled_add_rows": (_I, [_P, _P, _P, _I, _L, _I, _L, _L, _L, _F, _F, _P]),
+    "msg_softmax_rows": (_I, [_P, _P, _I, _L, _I, _P]),
+    "msg_softmax_rows_backward": (_I, [_P, _P, _P, _I, _L, _I, _P]),
     "msg_conv2d_fprop_plan": (_I, [_I] * 11 + [_L]),
     "msg_linear_fprop": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "msg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),

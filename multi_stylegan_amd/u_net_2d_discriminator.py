@@ -11,11 +11,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv_ops, equalized_layer
-from .op_static import FusedLeakyReLU, scaled_add, scaled_add_fork, upfirdn2d
+from .op_static import FusedLeakyReLU, scaled_add, scaled_add_fork, softmax_rows, upfirdn2d
 
 
 FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
 COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
+NATIVE_SOFTMAX = bool(int(os.environ.get("MSG_NATIVE_SOFTMAX", "1")))       # 0: ROCm library softmax in the non-local blocks (A/B)
 FUSE_INPUT_FORK = bool(int(os.environ.get("MSG_FUSE_INPUT_FORK", "1")))     # 0: autograd adds a block input's two gradients (A/B)
 
 
@@ -136,7 +137,8 @@ class NonLocalBlock(nn.Module):
         key = F.max_pool2d(self.phi(input), kernel_size=2, stride=2).flatten(start_dim=2)               # [B, C/8, HW/4]
         value = F.max_pool2d(self.g(input), kernel_size=2, stride=2).flatten(start_dim=2).transpose(1, 2)  # [B, HW/4, C/2]
         # softmax accumulates in fp32 whatever the storage type: no fp32 copy of the [B, HW, HW/4] map is made
-        beta = torch.softmax(torch.bmm(query, key), dim=-1)
+        scores = torch.bmm(query, key)
+        beta = softmax_rows(scores) if input.is_cuda and NATIVE_SOFTMAX else torch.softmax(scores, dim=-1)
         attended = torch.bmm(beta, value).view(bsz, height, width, -1).permute(0, 3, 1, 2)
         output = self.o(conv_ops.to_compute_layout(attended))
         return scaled_add(self.gamma.to(input.dtype) * output, self.residual_mapping(input), 1.0 / math.sqrt(2))

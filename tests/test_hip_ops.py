@@ -279,3 +279,28 @@ def test_fused_act_full_size_properties():
     want_gx = gy.float() * torch.where(y.float() > 0, 1.0, 0.2)
     assert rel_err(gx.float(), want_gx) < TOL16
     assert rel_err(gb, gx.float().sum(dim=(0, 2, 3))) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 17, 8), (2, 33, 1000), (2, 64, 1024), (1, 9, 4096), (5, 520)])
+def test_softmax_rows(dtype, shape):
+    """Attention softmax (u_net_2d_discriminator.py:378) against the CPU fp32 softmax on the same (rounded) input:
+    value, gradient, and the second-order terms R1 needs."""
+    from multi_stylegan_amd.op_static import softmax_rows
+    torch.manual_seed(11)
+    x_cpu = (3.0 * torch.randn(*shape)).to(dtype).float()
+    gy_cpu = torch.randn(*shape).to(dtype).float()
+    v_cpu = torch.randn(*shape).to(dtype).float()
+    def run(x, gy, v, fn):
+        x = x.clone().requires_grad_(True)
+        gy = gy.clone().requires_grad_(True)
+        y = fn(x)
+        gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+        ggy, gx2 = torch.autograd.grad(gx, (gy, x), v)
+        return [t.detach().float().cpu() for t in (y, gx, ggy, gx2)]
+    ref = run(x_cpu, gy_cpu, v_cpu, lambda t: torch.softmax(t, dim=-1))
+    got = run(x_cpu.to(DEV, dtype), gy_cpu.to(DEV, dtype), v_cpu.to(DEV, dtype), softmax_rows)
+    tol = 2e-6 if dtype == torch.float32 else 1.5e-2
+    for name, a, b in zip(("y", "gx", "d/dgy", "d/dx"), got, ref):
+        assert rel_err(a, b) < tol, (name, rel_err(a, b))
+    assert abs(got[0].sum(dim=-1) - 1).max() < (1e-5 if dtype == torch.float32 else 2e-2)

@@ -11,6 +11,7 @@
 //                          derivative of the demodulation norm:  with u = scale*W*s, w = d*u,
 //                          g_u = d*g_w - d^3 * u * <g_w, u>_{i,t}
 #include "msg_common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
     v = wave_sum(v);
@@ -351,6 +352,151 @@ __global__ __launch_bounds__(256) void modulate_backward_kernel(const float* __r
     }
 }
 
+// The same fold for I % 4 == 0 and T in {1, 4, 9} (every modulated conv of the generator), restructured around the
+// only large operand, the per-sample weight gradients g_w [B][O][T][ldg] (151 MB for a 512x512 3x3 layer at B = 16):
+//  * everything the fold needs from g_w is LINEAR in it -- g_u = d g_w - d^3 u <g_w,u> gives
+//        gW[o,i,t]  = scale * ( sum_b d_b s_bi g_w  -  scale W_oit sum_b d_b^3 T_b s_bi^2 ),
+//        gs[b,i]   += scale * ( d_b sum_t W_oit g_w  -  d_b^3 T_b scale s_bi sum_t W_oit^2 ),   T_b = scale <g_w, W s_b>
+//    so g_w is read ONCE (the old kernel read it for T_b and again for the sums), with no load depending on a
+//    reduction: all of a thread's loads for an output channel are in flight together;
+//  * a thread owns FOUR consecutive input channels: 16-byte loads of g_w, s and W, 16-byte stores of gW, gs;
+//  * the two halves of the workgroup take the even / the odd samples and meet in LDS for gW.
+template <bool DEMOD, int T>
+__global__ __launch_bounds__(256) void modulate_backward_v4_kernel(const float* __restrict__ gwk, const float* __restrict__ W,
+                                                                   const float* __restrict__ s, const float* __restrict__ d,
+                                                                   float* __restrict__ gW, float* __restrict__ gs_part,
+                                                                   int B, int O, int I, int ldg, int OG, float scale) {
+    constexpr int NB = MB_BMAX / 4;                   // samples per half (B <= 16)
+    __shared__ float red[4][NB];
+    __shared__ float Tsh[2][NB];
+    __shared__ __attribute__((aligned(16))) float xch[128][4 * T + 4];
+    const int og = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = tid >> 7, i = (tid & 127) * 4;
+    const bool live = i < I;
+    float gs_acc[NB][4];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gs_acc[q][e] = 0.f;
+
+    for (int oo = 0; oo < OG; ++oo) {
+        const int o = og * OG + oo;
+        if (o >= O) break;
+        float wv[4][T], gl[4][T], p1[NB][4], w2[4], c2[4];
+        {
+            float flat[4 * T];
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const f32x4 v = live ? *reinterpret_cast<const f32x4*>(W + ((size_t)o * I + i) * T + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) flat[4 * j + e] = v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w2[e] = 0.f; c2[e] = 0.f;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    wv[e][t] = flat[e * T + t];
+                    gl[e][t] = 0.f;
+                    w2[e] = fmaf(wv[e][t], wv[e][t], w2[e]);
+                }
+            }
+        }
+        float part[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int b = 2 * q + half;
+            part[q] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p1[q][e] = 0.f;
+            if (b >= B || !live) continue;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s + (size_t)b * I + i);
+            const float dv = DEMOD ? d[(size_t)b * O + o] : 1.f;
+            const float* g = gwk + (((size_t)b * O + o) * T) * ldg + i;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (size_t)t * ldg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p1[q][e] = fmaf(wv[e][t], gv[e], p1[q][e]);
+                    gl[e][t] = fmaf(dv * sv[e], gv[e], gl[e][t]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[q] = fmaf(sv[e], p1[q][e], part[q]);
+        }
+        if (DEMOD) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const float tot = wave_sum(part[q]);
+                if (lane == 0) red[wid][q] = tot;
+            }
+            __syncthreads();
+            if (tid < 2 * NB) Tsh[tid / NB][tid % NB] = scale * (red[2 * (tid / NB)][tid % NB] + red[2 * (tid / NB) + 1][tid % NB]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int b = 2 * q + half;
+            if (b >= B || !live) continue;
+            const float dv = DEMOD ? d[(size_t)b * O + o] : 1.f;
+            const float corr = DEMOD ? dv * dv * dv * Tsh[half][q] : 0.f;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s + (size_t)b * I + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gs_acc[q][e] += dv * p1[q][e] - corr * scale * sv[e] * w2[e];
+                c2[e] = fmaf(corr * sv[e], sv[e], c2[e]);
+            }
+        }
+        // gW = scale * (gl - scale * W * c2), both halves added
+        if (half == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < T; ++t) xch[tid & 127][e * T + t] = gl[e][t] - scale * wv[e][t] * c2[e];
+        }
+        __syncthreads();
+        if (half == 0 && live) {
+            float outv[4 * T];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    outv[e * T + t] = scale * (gl[e][t] - scale * wv[e][t] * c2[e] + xch[tid][e * T + t]);
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                *reinterpret_cast<f32x4*>(gW + ((size_t)o * I + i) * T + 4 * j) =
+                    f32x4{outv[4 * j], outv[4 * j + 1], outv[4 * j + 2], outv[4 * j + 3]};
+        }
+        __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int b = 2 * q + half;
+            if (b >= B) continue;
+            *reinterpret_cast<f32x4*>(gs_part + ((size_t)og * B + b) * I + i) =
+                f32x4{scale * gs_acc[q][0], scale * gs_acc[q][1], scale * gs_acc[q][2], scale * gs_acc[q][3]};
+        }
+    }
+}
+
+template <bool DEMOD>
+static bool modulate_backward_v4_launch(const float* gwk, const float* W, const float* s, const float* d, float* gW,
+                                        float* gs_part, int B, int O, int I, int taps, int ldg, int o_group, float scale,
+                                        int groups, hipStream_t st) {
+#define MB_V4(T_) hipLaunchKernelGGL((modulate_backward_v4_kernel<DEMOD, T_>), dim3(groups), dim3(256), 0, st, gwk, W, s, d, \
+                                     gW, gs_part, B, O, I, ldg, o_group, scale); return true;
+    switch (taps) {
+        case 1: MB_V4(1)
+        case 4: MB_V4(4)
+        case 9: MB_V4(9)
+        default: return false;
+    }
+#undef MB_V4
+}
+
 extern "C" int msg_modulate_backward(const float* gwk, const float* W, const float* s, const float* d, float* gW,
                                      float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
                                      float scale, void* stream) {
@@ -360,6 +506,13 @@ extern "C" int msg_modulate_backward(const float* gwk, const float* W, const flo
     if (I > 256 * MB_SLOTS || taps > MB_TAPS || B > MB_BMAX / 2) return MSG_EUNSUPPORTED;
     const int groups = (O + o_group - 1) / o_group;
     hipStream_t st = (hipStream_t)stream;
+    static int v4 = -1;
+    if (v4 < 0) { const char* e = getenv("MSG_MODBWD_V4"); v4 = e ? atoi(e) : 1; }
+    if (v4 && I % 4 == 0 && ldg % 4 == 0 && !(((uintptr_t)gwk | (uintptr_t)W | (uintptr_t)s | (uintptr_t)gW | (uintptr_t)gs_part) & 15u)) {
+        const bool ok = d ? modulate_backward_v4_launch<true>(gwk, W, s, d, gW, gs_part, B, O, I, taps, ldg, o_group, scale, groups, st)
+                          : modulate_backward_v4_launch<false>(gwk, W, s, d, gW, gs_part, B, O, I, taps, ldg, o_group, scale, groups, st);
+        if (ok) return MSG_CHECK_LAUNCH();
+    }
     if (d)
         hipLaunchKernelGGL((modulate_backward_kernel<true>), dim3(groups), dim3(256), 0, st, gwk, W, s, d, gW, gs_part,
                            B, O, I, taps, ldg, o_group, scale);

@@ -237,6 +237,18 @@ int msg_linear_dgrad(const float* gy, const float* w, float* gx, int M, int N, i
 int msg_linear_wgrad(const float* gy, const float* x, float* gw, float* gb, int M, int N, int K,
                      float gain, float bias_gain, void* stream);
 
+/* G layers of the same shape in ONE launch (the generator's style affines, multi_stylegan_generator.py:379-382: every
+ * ModulatedConv2d's modulation_mapping applied to its slot of the latent [M][L][K], all known before the first conv):
+ * group g reads rows x + slot[g]*K (row pitch L*K), its own weight w[g] ([N][K]) / bias[g] (device pointer tables;
+ * `bias` itself may be NULL), and writes the g-th slab of the [G][M][N] (fprop), [G][M][K] (dgrad), [G][N][K] / [G][N]
+ * (wgrad) outputs.  Same arithmetic per group as msg_linear_fprop / _dgrad / _wgrad. */
+int msg_linear_grouped_fprop(const float* x, const int* slot, const float* const* w, const float* const* bias, float* y,
+                             int G, int M, int N, int K, int L, float gain, float bias_gain, void* stream);
+int msg_linear_grouped_dgrad(const float* gy, const float* const* w, float* gx, int G, int M, int N, int K, float gain,
+                             void* stream);
+int msg_linear_grouped_wgrad(const float* gy, const float* x, const int* slot, float* gw, float* gb, int G, int M, int N,
+                             int K, int L, float gain, float bias_gain, void* stream);
+
 /* Which kernel msg_conv2d_fprop launches for a problem (no launch): 2 = 256x256 ping-pong, 1 = 128x128 with LDS-DMA
  * staging, 0 = 128x128 with register staging.  Used by bench.py to label per-kernel timings. */
 int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,

@@ -822,6 +822,107 @@ def linear(x, weight, bias=None, wscale=1.0, bias_scale=1.0):
     return y.permute(0, 2, 3, 1).reshape(b, o)
 
 
+_PTR_TABLES: dict = {}
+
+
+def _ptr_table(tensors, dev):
+    """Device int64 table of the tensors' addresses (cached: parameters keep their storage between steps)."""
+    key = (dev.index, tuple(t.data_ptr() for t in tensors))
+    hit = _PTR_TABLES.get(key)
+    if hit is None:
+        if len(_PTR_TABLES) > 64:
+            _PTR_TABLES.clear()
+        hit = _PTR_TABLES[key] = torch.tensor(key[1], dtype=torch.int64, device=dev)
+    return hit
+
+
+class _GroupedLinear(Function):
+    """out[g] = wscale * latent[:, slot[g]] @ W_g^T + bias_scale * b_g for G same-shaped layers in ONE launch (and two
+    in backward) -- see msg_linear_grouped_fprop.  Inputs: latent [B,L,K], slot (tuple), then G weights and G biases.
+    Higher-order requests differentiate the per-layer composite instead."""
+
+    @staticmethod
+    def forward(ctx, latent, slot, wscale, bias_scale, *wb):
+        g = len(slot)
+        ws, bs = wb[:g], wb[g:]
+        dev = _lib.require_gpu(latent, *ws, *bs)
+        (lat,) = _dense32(latent)
+        b, l, k = lat.shape
+        n = ws[0].shape[0]
+        for w, bb in zip(ws, bs):
+            if w.shape != (n, k) or bb.shape != (n,) or w.dtype != torch.float32 or bb.dtype != torch.float32 \
+                    or not w.is_contiguous():
+                raise _lib.MsgHipError("grouped linear: layers must be fp32, contiguous and of one shape")
+        slot_t = _ptr_table_ints(slot, dev)
+        y = torch.empty((g, b, n), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev), _lib.kernel_clock.span("linear_grouped_fprop/f32", 2.0 * g * b * n * k):
+            code = _lib.lib().msg_linear_grouped_fprop(lat.data_ptr(), slot_t.data_ptr(), _ptr_table(ws, dev).data_ptr(),
+                                                       _ptr_table(bs, dev).data_ptr(), y.data_ptr(), g, b, n, k, l,
+                                                       float(wscale), float(bias_scale), _lib.stream_of(dev))
+        _lib.check(code, "msg_linear_grouped_fprop")
+        ctx.save_for_backward(latent, *ws, *bs)
+        ctx.cfg = (tuple(slot), float(wscale), float(bias_scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        slot, wscale, bias_scale = ctx.cfg
+        g = len(slot)
+        lat, ws, bs = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + g], ctx.saved_tensors[1 + g:]
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                ins = [t for t, nd in zip((lat, *ws, *bs), (need[0], *need[4:])) if nd]
+                out = torch.stack([linear(lat[:, slot[j]], ws[j], bs[j], wscale, bias_scale) for j in range(g)])
+                grads = list(torch.autograd.grad(out, ins, gy, create_graph=True, allow_unused=True))
+            res = [grads.pop(0) if nd else None for nd in (need[0], *need[4:])]
+            return (res[0], None, None, None, *res[1:])
+        dev = lat.device
+        gy, lat = _dense32(gy, lat)
+        b, l, k = lat.shape
+        n = ws[0].shape[0]
+        slot_t = _ptr_table_ints(slot, dev)
+        glat = None
+        if need[0]:
+            gx = torch.empty((g, b, k), dtype=torch.float32, device=dev)
+            with _lib.on_device(dev):
+                code = _lib.lib().msg_linear_grouped_dgrad(gy.data_ptr(), _ptr_table(ws, dev).data_ptr(), gx.data_ptr(),
+                                                           g, b, n, k, wscale, _lib.stream_of(dev))
+            _lib.check(code, "msg_linear_grouped_dgrad")
+            glat = torch.zeros((b, l, k), dtype=torch.float32, device=dev)
+            glat.index_add_(1, slot_t.long(), gx.transpose(0, 1))
+        gw = gb = None
+        if any(need[4:]):
+            gw = torch.empty((g, n, k), dtype=torch.float32, device=dev)
+            gb = torch.empty((g, n), dtype=torch.float32, device=dev)
+            with _lib.on_device(dev):
+                code = _lib.lib().msg_linear_grouped_wgrad(gy.data_ptr(), lat.data_ptr(), slot_t.data_ptr(), gw.data_ptr(),
+                                                           gb.data_ptr(), g, b, n, k, l, wscale, bias_scale,
+                                                           _lib.stream_of(dev))
+            _lib.check(code, "msg_linear_grouped_wgrad")
+        grads_w = [gw[j] if need[4 + j] else None for j in range(g)]
+        grads_b = [gb[j] if need[4 + g + j] else None for j in range(g)]
+        return (glat, None, None, None, *grads_w, *grads_b)
+
+
+_INT_TABLES: dict = {}
+
+
+def _ptr_table_ints(values, dev):
+    key = (dev.index, tuple(int(v) for v in values))
+    hit = _INT_TABLES.get(key)
+    if hit is None:
+        if len(_INT_TABLES) > 64:
+            _INT_TABLES.clear()
+        hit = _INT_TABLES[key] = torch.tensor(key[1], dtype=torch.int32, device=dev)
+    return hit
+
+
+def grouped_linear(latent, slots, weights, biases, wscale, bias_scale):
+    """[G, B, N]: layer j applied to latent[:, slots[j]] -- all G style affines of the generator in one launch."""
+    return _GroupedLinear.apply(latent, tuple(int(v) for v in slots), float(wscale), float(bias_scale), *weights, *biases)
+
+
 def demod_coefficients(weight, style, scale):
     """d[b,o] = rsqrt(scale^2 * sum_i s[b,i]^2 * sum_k W[o,i,k]^2 + 1e-8)   (generator.py:384-388, refactored)."""
     wsq = weight[0].square().sum(dim=(2, 3))

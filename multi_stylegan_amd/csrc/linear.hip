@@ -21,9 +21,9 @@ constexpr int LIN_KC = 1024;       // K elements whose weights one wave keeps in
 
 // (Measured alternative: 4 output columns per wave to cut the L1/L2 re-reads of x by 4 -- 2x SLOWER at M=16, N=K=512:
 //  the kernel is bound by the latency chain of one wave, not by traffic, so more, lighter waves win.)
-__global__ __launch_bounds__(256) void linear_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                           int M, int N, int K, float gain, float bias_gain) {
+__device__ __forceinline__ void linear_fprop_body(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                  int M, int N, int K, float gain, float bias_gain) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (n >= N) return;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void linear_fprop_kernel(const float* __restri
             for (int mm = 0; mm < LIN_MB; ++mm) {
                 const int m = m0 + mm;
                 if (m >= M) break;
-                const float* xm = x + (size_t)m * K;
+                const float* xm = x + (size_t)m * ldx;
                 float a = 0.f;
 #pragma unroll
                 for (int j = 0; j < LIN_KC / 64; ++j) {
@@ -64,14 +64,32 @@ __global__ __launch_bounds__(256) void linear_fprop_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void linear_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int M, int N, int K, float gain, float bias_gain) {
+    linear_fprop_body(x, K, w, bias, y, M, N, K, gain, bias_gain);
+}
+
+// GROUPED variants (blockIdx.y = group): G independent layers of the same shape in one launch -- the generator's 20 style
+// affines all read the latent [M][L][K] (group g reads slot slot[g], rows L*K apart) and are known before the first
+// convolution runs, so they cost one launch forward and two backward instead of 20 + 40 (each ~12 us of an otherwise
+// idle chip).  w / bias come from pointer tables (the layers keep their own parameters); outputs are [G][...] stacks.
+__global__ __launch_bounds__(256) void linear_grouped_fprop_kernel(const float* __restrict__ x, const int* __restrict__ slot,
+                                                                   const float* const* __restrict__ w, const float* const* __restrict__ bias,
+                                                                   float* __restrict__ y, int M, int N, int K, int L,
+                                                                   float gain, float bias_gain) {
+    const int g = blockIdx.y;
+    linear_fprop_body(x + (size_t)slot[g] * K, (long long)L * K, w[g], bias ? bias[g] : nullptr, y + (size_t)g * M * N,
+                      M, N, K, gain, bias_gain);
+}
+
 // One workgroup of 16 waves per 64 output columns k.  The batch rows' gy values are staged TRANSPOSED in LDS
 // ([n][16 rows], so one ds_read_b128 broadcast hands a wave 4 rows' factors); wave q walks its 1/16 of the rows n of W
 // (each row segment is one coalesced 256-B load) with 16 batch rows in registers, then the 16 partial sums meet in the
 // same LDS where thread (m, k) adds them in a fixed order (deterministic, no atomics).
 constexpr int LIN_NCH = 1024;      // rows of W per staged chunk: 1024 x 16 floats = 64 KiB of LDS
-__global__ __launch_bounds__(1024) void linear_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
-                                                            float* __restrict__ gx, int M, int N, int K, float gain) {
-    __shared__ __attribute__((aligned(16))) float sh[LIN_NCH * LIN_MB];      // gyT[n][m], later red[q][m][lane]
+__device__ __forceinline__ void linear_dgrad_body(float* __restrict__ sh, const float* __restrict__ gy, const float* __restrict__ w,
+                                                  float* __restrict__ gx, int M, int N, int K, float gain) {
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = blockIdx.x * 64 + lane;
@@ -119,14 +137,27 @@ __global__ __launch_bounds__(1024) void linear_dgrad_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                           float* __restrict__ gw, float* __restrict__ gb,
-                                                           int M, int N, int K, float gain, float bias_gain) {
+__global__ __launch_bounds__(1024) void linear_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                            float* __restrict__ gx, int M, int N, int K, float gain) {
+    __shared__ __attribute__((aligned(16))) float sh[LIN_NCH * LIN_MB];      // gyT[n][m], later red[q][m][lane]
+    linear_dgrad_body(sh, gy, w, gx, M, N, K, gain);
+}
+
+__global__ __launch_bounds__(1024) void linear_grouped_dgrad_kernel(const float* __restrict__ gy, const float* const* __restrict__ w,
+                                                                    float* __restrict__ gx, int M, int N, int K, float gain) {
+    __shared__ __attribute__((aligned(16))) float sh[LIN_NCH * LIN_MB];
+    const int g = blockIdx.y;
+    linear_dgrad_body(sh, gy + (size_t)g * M * N, w[g], gx + (size_t)g * M * K, M, N, K, gain);
+}
+
+__device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ gy, const float* __restrict__ x, long long ldx,
+                                                  float* __restrict__ gw, float* __restrict__ gb,
+                                                  int M, int N, int K, float gain, float bias_gain) {
     const int n = blockIdx.x;
     const float* gn = gy + n;                       // gy[m][n] = gn[m * N]: block-uniform
     for (int k = threadIdx.x; k < K; k += 256) {
         float a = 0.f;
-        for (int m = 0; m < M; ++m) a = fmaf(gn[(size_t)m * N], x[(size_t)m * K + k], a);
+        for (int m = 0; m < M; ++m) a = fmaf(gn[(size_t)m * N], x[(size_t)m * ldx + k], a);
         gw[(size_t)n * K + k] = gain * a;
     }
     if (gb && threadIdx.x == 0) {
@@ -134,6 +165,21 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
         for (int m = 0; m < M; ++m) s += gn[(size_t)m * N];
         gb[n] = bias_gain * s;
     }
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                           float* __restrict__ gw, float* __restrict__ gb,
+                                                           int M, int N, int K, float gain, float bias_gain) {
+    linear_wgrad_body(gy, x, K, gw, gb, M, N, K, gain, bias_gain);
+}
+
+__global__ __launch_bounds__(256) void linear_grouped_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                   const int* __restrict__ slot, float* __restrict__ gw,
+                                                                   float* __restrict__ gb, int M, int N, int K, int L,
+                                                                   float gain, float bias_gain) {
+    const int g = blockIdx.y;
+    linear_wgrad_body(gy + (size_t)g * M * N, x + (size_t)slot[g] * K, (long long)L * K, gw + (size_t)g * N * K,
+                      gb ? gb + (size_t)g * N : nullptr, M, N, K, gain, bias_gain);
 }
 
 static bool lin_bad(const void* a, const void* b, const void* c, int M, int N, int K) {
@@ -168,5 +214,34 @@ extern "C" int msg_linear_wgrad(const float* gy, const float* x, float* gw, floa
     if (lin_bad(gy, x, gw, M, N, K)) return MSG_EINVAL;
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, gy, x, gw, gb, M, N, K, gain,
                        bias_gain);
+    return MSG_CHECK_LAUNCH();
+}
+
+// ---- grouped entry points (see linear_grouped_fprop_kernel)
+extern "C" int msg_linear_grouped_fprop(const float* x, const int* slot, const float* const* w, const float* const* bias,
+                                        float* y, int G, int M, int N, int K, int L, float gain, float bias_gain,
+                                        void* stream) {
+    if (M == 0 || G == 0) return MSG_OK;
+    if (lin_bad(x, w, y, M, N, K) || !slot || G < 0 || L <= 0 || G > 65535) return MSG_EINVAL;
+    hipLaunchKernelGGL(linear_grouped_fprop_kernel, dim3((N + 3) / 4, G), dim3(256), 0, (hipStream_t)stream, x, slot, w,
+                       bias, y, M, N, K, L, gain, bias_gain);
+    return MSG_CHECK_LAUNCH();
+}
+
+extern "C" int msg_linear_grouped_dgrad(const float* gy, const float* const* w, float* gx, int G, int M, int N, int K,
+                                        float gain, void* stream) {
+    if (M == 0 || G == 0) return MSG_OK;
+    if (lin_bad(gy, w, gx, M, N, K) || G < 0 || G > 65535) return MSG_EINVAL;
+    hipLaunchKernelGGL(linear_grouped_dgrad_kernel, dim3((K + 63) / 64, G), dim3(1024), 0, (hipStream_t)stream, gy, w, gx,
+                       M, N, K, gain);
+    return MSG_CHECK_LAUNCH();
+}
+
+extern "C" int msg_linear_grouped_wgrad(const float* gy, const float* x, const int* slot, float* gw, float* gb, int G,
+                                        int M, int N, int K, int L, float gain, float bias_gain, void* stream) {
+    if (G == 0) return MSG_OK;
+    if (M <= 0 || lin_bad(gy, x, gw, M, N, K) || !slot || G < 0 || L <= 0 || G > 65535) return MSG_EINVAL;
+    hipLaunchKernelGGL(linear_grouped_wgrad_kernel, dim3(N, G), dim3(256), 0, (hipStream_t)stream, gy, x, slot, gw, gb,
+                       M, N, K, L, gain, bias_gain);
     return MSG_CHECK_LAUNCH();
 }

@@ -125,11 +125,15 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const T* __restrict__ 
         dy[e] = t / kw - pad;
         dx[e] = t - (t / kw) * kw - pad;
     }
-    for (long long vi = first; vi < total; vi += (long long)gridDim.x * 256) {
-        long long pix = vi / vpp;
-        const int w_ = (int)(pix % W); pix /= W;
-        const int h_ = (int)(pix % H);
-        const int b = (int)(pix / H);
+    // vpp divides the grid stride (host), so the thread walks PIXELS with a constant stride: one 64-bit division up
+    // front, 32-bit ones in the loop
+    const unsigned npix = (unsigned)(total / vpp), pstep = (unsigned)((long long)gridDim.x * 256 / vpp);
+    for (unsigned pix = (unsigned)(first / vpp); pix < npix; pix += pstep) {
+        const long long vi = (long long)pix * vpp + v;
+        const unsigned row = pix / (unsigned)W;
+        const int w_ = (int)(pix - row * (unsigned)W);
+        const int b = (int)(row / (unsigned)H);
+        const int h_ = (int)(row - (unsigned)b * (unsigned)H);
         const T* xb = x + (long long)b * H * W * Cx;
         T out[VEC];
 #pragma unroll
@@ -150,7 +154,8 @@ extern "C" int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, 
     if (!x || !y || B < 0 || H <= 0 || W <= 0 || C <= 0 || Cx < C || kh <= 0 || kw <= 0 || Ko < kh * kw * C) return MSG_EINVAL;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int vec = dtype == MSG_BF16 ? 8 : 4;
-    if (Ko % vec || (((uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
+    if (Ko % vec || 256 % (Ko / vec) || (((uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
+    if ((long long)B * H * W >= (1ll << 31)) return MSG_EUNSUPPORTED;
     const long long total = (long long)B * H * W * (Ko / vec);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipStream_t s = (hipStream_t)stream;

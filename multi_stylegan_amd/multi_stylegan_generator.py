@@ -25,6 +25,8 @@ from .op_static import FusedLeakyReLU, blur_bias_act, fused_bias_noise_leaky_rel
 
 # 0: the two RGB heads of a level as two modulated convs (A/B; same result up to the rounding of one bf16 add)
 PAIR_OUTPUT_HEADS = bool(int(os.environ.get("MSG_PAIR_HEADS", "1")))
+# 0: every styled layer runs its own modulation_mapping launch (A/B; identical arithmetic per layer)
+GROUP_STYLE_AFFINES = bool(int(os.environ.get("MSG_GROUP_AFFINES", "1")))
 
 
 def _fir2d(taps, gain=1.0):
@@ -87,6 +89,23 @@ class NoiseInjection(nn.Module):
         return input + (self.weight * noise).to(input.dtype)
 
 
+class _Premodulated:
+    """A style that already went through the layer's modulation_mapping (Generator.forward computes all of them in one
+    grouped launch, conv_ops.grouped_linear)."""
+    __slots__ = ("value",)
+
+    def __init__(self, value: torch.Tensor) -> None:
+        self.value = value
+
+
+def _modulated_style(mc: "ModulatedConv2d", style, bsz: int) -> torch.Tensor:
+    if isinstance(style, _Premodulated):
+        return style.value.view(bsz, 1, mc.in_channels, 1, 1)
+    if mc.modulation_mapping is not None:
+        return mc.modulation_mapping(style).view(bsz, 1, mc.in_channels, 1, 1)
+    return style
+
+
 class ModulatedConv2d(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, style_dimension: int,
                  kernel_size: Union[int, Tuple[int, int]] = (3, 3), demodulate: bool = True, upsampling: bool = True,
@@ -111,10 +130,7 @@ class ModulatedConv2d(nn.Module):
     def forward(self, input: torch.Tensor, style: torch.Tensor, skip_blur: bool = False):
         bsz, feats = input.shape[:2]
         assert feats == self.in_channels, f"Expect input feature shape of {self.in_channels} but get {feats}."
-        if self.modulation_mapping is not None:
-            modulated_style = self.modulation_mapping(style).view(bsz, 1, self.in_channels, 1, 1)
-        else:
-            modulated_style = style
+        modulated_style = _modulated_style(self, style, bsz)
         output = conv_ops.modulated_conv2d(input, self.weight, modulated_style.reshape(bsz, self.in_channels),
                                            demodulate=self.demodulate, upsample=self.upsampling)
         if self.upsampling and not skip_blur:
@@ -140,8 +156,7 @@ class StyledConv2d(nn.Module):
         if not mc.upsampling and conv_ops.FUSE_ACTIVATION and input.is_cuda:
             # conv -> noise -> bias -> leaky ReLU in one launch (the upsampling layers blur in between: two passes)
             bsz = input.shape[0]
-            style_out = mc.modulation_mapping(style).view(bsz, 1, mc.in_channels, 1, 1) \
-                if mc.modulation_mapping is not None else style
+            style_out = _modulated_style(mc, style, bsz)
             if noise is None:
                 noise = torch.randn(bsz, 1, input.shape[2], input.shape[3], device=input.device, dtype=torch.float32)
             output = conv_ops.modulated_conv2d_bias_act(
@@ -270,6 +285,30 @@ class Generator(nn.Module):
                               styles[1].unsqueeze(1).repeat(1, n - inject_index, 1)], dim=1)
         return self.style_mapping(input).unsqueeze(1).repeat(1, n, 1)
 
+    def _style_groups(self):
+        """(modulated conv, latent slot) of every layer that owns a modulation_mapping, in execution order."""
+        groups = [(self.starting_convolution_1.modulated_convolution, 0),
+                  (self.starting_output_block_1.modulated_convolution, 1)]
+        for i in range(len(self.main_convolutions_1) // 2):
+            groups += [(self.main_convolutions_1[2 * i].modulated_convolution, 2 * i + 1),
+                       (self.main_convolutions_1[2 * i + 1].modulated_convolution, 2 * i + 2),
+                       (self.output_blocks_1[i].modulated_convolution, 2 * i + 3)]
+        return groups
+
+    def _all_styles(self, latent: torch.Tensor):
+        """All style affines (multi_stylegan_generator.py:379-382, one EqualizedLinear per styled layer) in ONE grouped
+        launch: they only depend on the latent.  None when the layers are not uniform (then each layer maps its own)."""
+        if not (GROUP_STYLE_AFFINES and latent.is_cuda and latent.dtype == torch.float32):
+            return None
+        groups = self._style_groups()
+        maps = [mc.modulation_mapping for mc, _ in groups]
+        first = maps[0]
+        if any(m is None or m.bias is None or m.weight.shape != first.weight.shape for m in maps):
+            return None
+        out = conv_ops.grouped_linear(latent, [slot for _, slot in groups], [m.weight for m in maps],
+                                      [m.bias for m in maps], first.scale, first.scale_bias)
+        return out.unbind(0)
+
     @staticmethod
     def _paired_heads(head1: "OutputBlock", head2: "OutputBlock", features: torch.Tensor, latent_w: torch.Tensor,
                       skip1: torch.Tensor, skip2: torch.Tensor):
@@ -284,7 +323,7 @@ class Generator(nn.Module):
             skip1, style = head1(features, latent_w, skip=skip1)
             return skip1, head2(features, style, skip=skip2), style
         bsz, o1 = features.shape[0], mc1.out_channels
-        style = mc1.modulation_mapping(latent_w).view(bsz, 1, mc1.in_channels, 1, 1)
+        style = _modulated_style(mc1, latent_w, bsz)
         both = conv_ops.modulated_conv2d(features, torch.cat([mc1.weight, mc2.weight], dim=1),
                                          style.reshape(bsz, mc1.in_channels), demodulate=False, upsample=False)
         rgb1 = both[:, :o1].float().contiguous() + head1.bias
@@ -309,23 +348,27 @@ class Generator(nn.Module):
         else:
             noise_start, layer_noise = noise[0], list(noise[1:])
         dt = self.compute_dtype
+        pre = self._all_styles(latent) if not return_path_length_grads else None
+        w_of = (lambda group, slot: _Premodulated(pre[group])) if pre is not None else \
+            (lambda group, slot: latent[:, slot])
         out1 = conv_ops.to_compute_layout(self.constant_input_1(latent), dt)
         out2 = conv_ops.to_compute_layout(self.constant_input_2(latent), dt)
-        out1, style = self.starting_convolution_1(out1, latent[:, 0], noise=noise_start)
+        out1, style = self.starting_convolution_1(out1, w_of(0, 0), noise=noise_start)
         out2 = self.starting_convolution_2(out2, style, noise=noise_start)
-        skip1, style = self.starting_output_block_1(out1, latent[:, 1])
+        skip1, style = self.starting_output_block_1(out1, w_of(1, 1))
         skip2 = self.starting_output_block_2(out2, style)
         run_stream2 = not self.elide_dead_branch
         for i in range(n_main // 2):
-            out1, style = self.main_convolutions_1[2 * i](out1, latent[:, 2 * i + 1], noise=layer_noise[2 * i])
+            out1, style = self.main_convolutions_1[2 * i](out1, w_of(2 + 3 * i, 2 * i + 1),
+                                                           noise=layer_noise[2 * i])
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i](out2, style, noise=layer_noise[2 * i])
-            out1, style = self.main_convolutions_1[2 * i + 1](out1, latent[:, 2 * i + 2],
+            out1, style = self.main_convolutions_1[2 * i + 1](out1, w_of(3 + 3 * i, 2 * i + 2),
                                                                noise=layer_noise[2 * i + 1])
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i + 1](out2, style, noise=layer_noise[2 * i + 1])
             skip1, skip2, style = self._paired_heads(self.output_blocks_1[i], self.output_blocks_2[i], out1,
-                                                     latent[:, 2 * i + 3], skip1, skip2)
+                                                     w_of(4 + 3 * i, 2 * i + 3), skip1, skip2)
         image = torch.stack([skip1, skip2], dim=1)
         if return_path_length_grads:
             if path_length_noise is None:

@@ -455,3 +455,35 @@ def test_pingpong_kernel_shapes(case):
     gx, = torch.autograd.grad(y, xd, gy.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
     assert rel_err(y.float(), yr) < 2e-2, "forward"
     assert rel_err(gx.float(), gxr) < 2e-2, "data gradient"
+
+
+@pytest.mark.parametrize("g,b,l,n,k", [(5, 16, 14, 512, 512), (3, 3, 4, 40, 24), (1, 1, 1, 8, 8)])
+def test_grouped_linear_matches_per_layer(g, b, l, n, k):
+    """conv_ops.grouped_linear (all style affines in one launch) == the per-layer EqualizedLinear path: values,
+    first-order gradients (latent slots shared by several layers accumulate), and the second-order fallback."""
+    from multi_stylegan_amd import conv_ops
+    torch.manual_seed(3)
+    latent = torch.randn(b, l, k, device=DEV, requires_grad=True)
+    slots = [int(v) for v in torch.randint(0, l, (g,))]
+    ws = [torch.randn(n, k, device=DEV, requires_grad=True) for _ in range(g)]
+    bs = [torch.randn(n, device=DEV, requires_grad=True) for _ in range(g)]
+    gy = torch.randn(g, b, n, device=DEV)
+    wscale, bscale = 0.37, 1.3
+
+    def per_layer():
+        return torch.stack([conv_ops.linear(latent[:, slots[j]], ws[j], bs[j], wscale, bscale) for j in range(g)])
+
+    out_g = conv_ops.grouped_linear(latent, slots, ws, bs, wscale, bscale)
+    out_p = per_layer()
+    assert rel_err(out_g, out_p) < 1e-6
+    grads_g = torch.autograd.grad(out_g, [latent, *ws, *bs], gy)
+    grads_p = torch.autograd.grad(out_p, [latent, *ws, *bs], gy)
+    for a, c in zip(grads_g, grads_p):
+        assert rel_err(a, c) < 1e-5
+    # second order (path-length style): d/dW of |d out / d latent|^2
+    def second(fn):
+        o = fn()
+        gl, = torch.autograd.grad(o, latent, gy, create_graph=True)
+        return torch.autograd.grad(gl.square().sum(), ws)
+    for a, c in zip(second(lambda: conv_ops.grouped_linear(latent, slots, ws, bs, wscale, bscale)), second(per_layer)):
+        assert rel_err(a, c) < 1e-5

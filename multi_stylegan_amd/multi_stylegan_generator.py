@@ -278,7 +278,11 @@ class Generator(nn.Module):
                 return input.repeat(1, n, 1)
             return input
         if isinstance(input, (list, tuple)):
-            styles = [self.style_mapping(z) for z in input]
+            if len(input) > 1 and all(z.shape == input[0].shape for z in input):
+                # the mapping network is row-wise: both latent draws of a style-mixing pair go through it as one batch
+                styles = self.style_mapping(torch.cat(list(input), dim=0)).chunk(len(input), dim=0)
+            else:
+                styles = [self.style_mapping(z) for z in input]
             if inject_index is None:
                 inject_index = np.random.randint(1, n - 1)
             return torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
@@ -309,29 +313,35 @@ class Generator(nn.Module):
                                       [m.bias for m in maps], first.scale, first.scale_bias)
         return out.unbind(0)
 
+    def _heads_pairable(self, features: torch.Tensor) -> bool:
+        if not (PAIR_OUTPUT_HEADS and features.is_cuda):
+            return False
+        for h1, h2 in zip(self.output_blocks_1, self.output_blocks_2):
+            m1, m2 = h1.modulated_convolution, h2.modulated_convolution
+            if m1.modulation_mapping is None or m2.modulation_mapping is not None or m1.demodulate or m2.demodulate \
+                    or m1.weight.shape != m2.weight.shape:
+                return False
+        return True
+
     @staticmethod
-    def _paired_heads(head1: "OutputBlock", head2: "OutputBlock", features: torch.Tensor, latent_w: torch.Tensor,
-                      skip1: torch.Tensor, skip2: torch.Tensor):
-        """output_blocks_1[i](features, w) and output_blocks_2[i](features, style_1): the reference's second head
-        reads stream 1's features with stream 1's modulated style (multi_stylegan_generator.py:184-189), and neither
-        head demodulates, so the two 1x1 modulated convs are ONE contraction with the weights stacked along the output
-        channels -- the 512-channel map is read once instead of twice, and backward gets its gradient from one
-        6-channel data-gradient conv instead of two 3-channel ones plus an add over the whole map."""
+    def _paired_heads(head1: "OutputBlock", head2: "OutputBlock", features: torch.Tensor, latent_w, skip: torch.Tensor):
+        """output_blocks_1[i](features, w) and output_blocks_2[i](features, style_1) as ONE block on a 2 x 3-channel
+        map: the reference's second head reads stream 1's features with stream 1's modulated style
+        (multi_stylegan_generator.py:184-189) and neither head demodulates, so the two 1x1 modulated convs are one
+        contraction with the weights stacked along the output channels -- the 512-channel map is read once, and
+        backward gets its gradient from one 6-channel data-gradient conv instead of two 3-channel ones plus an add over
+        the whole map.  The skip path (bias, FIR upsampling of the previous level, sum) runs once on the stacked map
+        too; `skip` is [B, 2*3, h, w], heads stacked along the channels."""
         mc1, mc2 = head1.modulated_convolution, head2.modulated_convolution
-        if not (PAIR_OUTPUT_HEADS and features.is_cuda and mc1.modulation_mapping is not None
-                and mc2.modulation_mapping is None and not mc1.demodulate and not mc2.demodulate):
-            skip1, style = head1(features, latent_w, skip=skip1)
-            return skip1, head2(features, style, skip=skip2), style
-        bsz, o1 = features.shape[0], mc1.out_channels
+        bsz, o1, o2 = features.shape[0], mc1.out_channels, mc2.out_channels
         style = _modulated_style(mc1, latent_w, bsz)
         both = conv_ops.modulated_conv2d(features, torch.cat([mc1.weight, mc2.weight], dim=1),
                                          style.reshape(bsz, mc1.in_channels), demodulate=False, upsample=False)
-        rgb1 = both[:, :o1].float().contiguous() + head1.bias
-        rgb2 = both[:, o1:].float().contiguous() + head2.bias
-        if skip1 is not None:
-            rgb1 = rgb1 + head1.upsampling(skip1)
-            rgb2 = rgb2 + head2.upsampling(skip2)
-        return rgb1, rgb2, style
+        bias = torch.cat([head1.bias.expand(1, o1, 1, 1), head2.bias.expand(1, o2, 1, 1)], dim=1)
+        rgb = both.float().contiguous() + bias
+        if skip is not None:
+            rgb = rgb + head1.upsampling(skip)
+        return rgb, style
 
     def forward(self, input: Union[List[torch.Tensor], torch.Tensor], return_main_style_vectors: bool = False,
                 noise: Optional[List[torch.Tensor]] = None, randomize_noise: bool = True,
@@ -358,6 +368,8 @@ class Generator(nn.Module):
         skip1, style = self.starting_output_block_1(out1, w_of(1, 1))
         skip2 = self.starting_output_block_2(out2, style)
         run_stream2 = not self.elide_dead_branch
+        paired = n_main >= 2 and skip1.shape == skip2.shape and self._heads_pairable(out1)
+        skip = torch.cat([skip1, skip2], dim=1) if paired else None
         for i in range(n_main // 2):
             out1, style = self.main_convolutions_1[2 * i](out1, w_of(2 + 3 * i, 2 * i + 1),
                                                            noise=layer_noise[2 * i])
@@ -367,9 +379,16 @@ class Generator(nn.Module):
                                                                noise=layer_noise[2 * i + 1])
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i + 1](out2, style, noise=layer_noise[2 * i + 1])
-            skip1, skip2, style = self._paired_heads(self.output_blocks_1[i], self.output_blocks_2[i], out1,
-                                                     w_of(4 + 3 * i, 2 * i + 3), skip1, skip2)
-        image = torch.stack([skip1, skip2], dim=1)
+            if paired:
+                skip, style = self._paired_heads(self.output_blocks_1[i], self.output_blocks_2[i], out1,
+                                                 w_of(4 + 3 * i, 2 * i + 3), skip)
+            else:
+                skip1, style = self.output_blocks_1[i](out1, w_of(4 + 3 * i, 2 * i + 3), skip=skip1)
+                skip2 = self.output_blocks_2[i](out1, style, skip=skip2)     # reads stream 1, as the reference does
+        if paired:      # [B, 2*3, H, W] -> [B, 2, 3, H, W]: a view
+            image = skip.view(skip.shape[0], 2, skip.shape[1] // 2, *skip.shape[2:])
+        else:
+            image = torch.stack([skip1, skip2], dim=1)
         if return_path_length_grads:
             if path_length_noise is None:
                 path_length_noise = torch.randn(image.shape, device=image.device, dtype=torch.float32)

@@ -108,3 +108,34 @@ def test_linear_and_modulation_entries(lib):
                                     1.0, 1e-8, s) == EINVAL                                               # R % O != 0
     assert lib.msg_scale_rows_cols(a.data_ptr(), None, None, d.data_ptr(), F32, 2, 8, 1, 8, 4, 1.0, s) == EINVAL  # Ck < C
     torch.cuda.synchronize()
+
+
+def test_softmax_and_grouped_linear_entries(lib):
+    a, b, c = _buf(1 << 16), _buf(1 << 16), _buf(1 << 16)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.msg_softmax_rows(a.data_ptr(), b.data_ptr(), F32, 4, 1024, s) == OK
+    assert lib.msg_softmax_rows(a.data_ptr(), b.data_ptr(), F32, 0, 1024, s) == OK                  # no rows: no-op
+    assert lib.msg_softmax_rows(a.data_ptr(), b.data_ptr(), F32, 4, 8192, s) == EUNSUPPORTED        # row > one wave's registers
+    assert lib.msg_softmax_rows(a.data_ptr(), b.data_ptr(), F32, 4, 1022, s) == EUNSUPPORTED        # not whole 16-byte vectors
+    assert lib.msg_softmax_rows(a.data_ptr(), b.data_ptr(), F64, 4, 1024, s) == EUNSUPPORTED
+    assert lib.msg_softmax_rows(None, b.data_ptr(), F32, 4, 1024, s) == EINVAL
+    assert lib.msg_softmax_rows(a.data_ptr() + 4, b.data_ptr(), F32, 4, 1024, s) == EUNSUPPORTED    # misaligned
+    assert lib.msg_softmax_rows_backward(a.data_ptr(), b.data_ptr(), None, F32, 4, 1024, s) == EINVAL
+    assert lib.msg_softmax_rows_backward(a.data_ptr(), b.data_ptr(), c.data_ptr(), BF16, 4, 4096, s) == OK
+    torch.cuda.synchronize()
+    assert abs(float(b[:1024].sum()) - 1.0) < 1e-5                                                   # softmax of zeros
+    # grouped linear: pointer tables on the device
+    w = [_buf(64) for _ in range(3)]
+    wt = torch.tensor([t.data_ptr() for t in w], dtype=torch.int64, device=DEV)
+    slot = torch.tensor([0, 1, 1], dtype=torch.int32, device=DEV)
+    x, y = _buf(2 * 2 * 8), _buf(3 * 2 * 8)
+    args = (x.data_ptr(), slot.data_ptr(), wt.data_ptr(), None, y.data_ptr())
+    assert lib.msg_linear_grouped_fprop(*args, 3, 2, 8, 8, 2, 1.0, 1.0, s) == OK
+    assert lib.msg_linear_grouped_fprop(*args, 0, 2, 8, 8, 2, 1.0, 1.0, s) == OK                     # no groups: no-op
+    assert lib.msg_linear_grouped_fprop(*args, 3, 2, 8, 8, 0, 1.0, 1.0, s) == EINVAL                 # latent slots per row
+    assert lib.msg_linear_grouped_fprop(x.data_ptr(), None, wt.data_ptr(), None, y.data_ptr(), 3, 2, 8, 8, 2, 1.0, 1.0,
+                                        s) == EINVAL
+    assert lib.msg_linear_grouped_dgrad(y.data_ptr(), None, x.data_ptr(), 3, 2, 8, 8, 1.0, s) == EINVAL
+    assert lib.msg_linear_grouped_wgrad(y.data_ptr(), x.data_ptr(), slot.data_ptr(), None, None, 3, 2, 8, 8, 2, 1.0, 1.0,
+                                        s) == EINVAL
+    torch.cuda.synchronize()

@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
         }
 }
 
+extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* gw, int dtype,
+                                         int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
+                                         int kh, int kw, int stride, int pad, int pixel_shuffle,
+                                         int per_sample, int k_chunks, int oi_major, float gain, void* stream);
+
 extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
                                 int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
                                 int kh, int kw, int stride, int pad, int pixel_shuffle,
@@ -369,6 +374,9 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz;
     if (Cx % vec || ldgy % vec || (((uintptr_t)gy | (uintptr_t)x) & 15u)) return MSG_EUNSUPPORTED;
+    if (msg_conv2d_wgrad_row3_try(gy, x, gw, dtype, B, IH, IW, Cx, I, OH, OW, ldgy, O, ldgw, kh, kw, stride, pad,
+                                  pixel_shuffle, per_sample, k_chunks, oi_major, gain, stream))
+        return MSG_CHECK_LAUNCH();                 // kh x 3 'same' convs on wide maps: three taps per workgroup
     WgradParams p{};
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.I = I; p.OH = OH; p.OW = OW; p.ldgy = ldgy; p.O = O;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.pixel_shuffle = pixel_shuffle;

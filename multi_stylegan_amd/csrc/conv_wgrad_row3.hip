@@ -1,0 +1,304 @@
+// a3/a4: weight gradient of the kh x 3 'same' convolutions on maps at least 64 pixels wide -- all three horizontal taps
+// of a kernel row in ONE workgroup (bf16; the 256^2 / 128^2 / 64^2 layers, where most of the weight-gradient time is).
+//
+//   GW[(z)][o][kh*3 + kw][i] (+)= sum_{b,oh,ow} GY[b, oh, ow, o] * X[b, oh + kh - pad, ow + kw - 1, i],   kw = 0, 1, 2
+//
+// conv_wgrad.hip gives every tap its own workgroup, so the 64-pixel GY tile and the (shifted) X tile of a K-step are
+// staged nine times; global -> LDS staging is what bounds these kernels ("where the conv kernels stand").
+// Here a K-step is a 64-pixel segment of ONE image row (the map width is a multiple of 64): the three horizontal taps
+// read the same X pixels shifted by one, so the workgroup stages the GY segment once and 66 X pixels (the segment plus
+// one neighbour on each side, zeros at the image border) once, and the transposing fragment reads of tap kw simply
+// start kw rows further down the LDS tile.  Per MFMA: a third of the staging traffic, two thirds of the LDS reads
+// (the GY fragments are shared by the three taps).  Three accumulator sets (3 x 64 registers) mean one workgroup of four
+// waves per CU, in the unified VGPR/AGPR file -- the regime of conv_fprop_big.hip, with a third of its staging per MFMA.
+//
+// Same LDS image as conv_wgrad.hip ([pixel][128 channels], rows rotated by 64 B * (pixel & 3), ds_read_b64_tr_b16),
+// same buffer-load addressing (per-thread constant offset + wave-uniform SGPR cursor, out-of-range rows read zeros),
+// same fp32 epilogue (stores or float atomics into GW[o][tap][i]).
+#include "msg_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct Row3Params {
+    int B, H, W, Cx, I, ldgy, O, ldgw;
+    int kh, pad;                                      // kernel rows and vertical padding (kw = 3, horizontal padding 1)
+    int per_sample, steps_per_chunk, chunks_per_sample, nz, atomic;
+    int o_tiles, i_tiles, oi_major;
+    float gain;
+    long long gw_zstride;
+};
+
+constexpr int R3_ROW = 256;                           // bytes of one pixel row of a 128-channel tile
+constexpr int R3_KP = 64;                             // pixels per K-step
+constexpr int R3_TA = R3_KP * R3_ROW;                 // 16 KiB: GY segment
+constexpr int R3_TB = (R3_KP + 4) * R3_ROW;           // 17 KiB: X segment + neighbours (66 rows used)
+constexpr int R3_STAGE = R3_TA + R3_TB;
+constexpr int R3_OOB = (int)0x80000000;
+
+__device__ __forceinline__ int r3_off(int r, int ch) { return r * R3_ROW + (((ch << 4) + ((r & 3) << 6)) & (R3_ROW - 1)); }
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
+                                                                 float* __restrict__ gw, Row3Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * R3_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int G = tiles * p.kh;
+    // tile index fastest, then kernel row, then K-slice (8 | tiles: an XCD keeps its channel tiles for every slice)
+    int z = blockIdx.x / G;
+    const int rem_ = blockIdx.x - z * G;
+    int khi = rem_ / tiles;
+    int tile = rem_ - khi * tiles;
+    z = __builtin_amdgcn_readfirstlane(z);
+    khi = __builtin_amdgcn_readfirstlane(khi);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (z >= p.nz) return;
+    const int o0 = __builtin_amdgcn_readfirstlane((tile / p.i_tiles) * 128), i0 = __builtin_amdgcn_readfirstlane((tile % p.i_tiles) * 128);
+    const int segs = p.W / R3_KP;
+    const int steps_per_sample = p.H * segs;
+    int b = 0, s0, s1;
+    if (p.per_sample) {
+        b = z / p.chunks_per_sample;
+        const int chunk = z - b * p.chunks_per_sample;
+        s0 = chunk * p.steps_per_chunk;
+        s1 = min(steps_per_sample, s0 + p.steps_per_chunk);
+    } else {
+        s0 = z * p.steps_per_chunk;
+        s1 = min(p.B * steps_per_sample, s0 + p.steps_per_chunk);
+    }
+    // (integer divisions run on the vector ALU: pin the wave-uniform results back into SGPRs, otherwise the buffer
+    //  descriptors derived from them count as divergent and every load becomes a waterfall loop)
+    b = __builtin_amdgcn_readfirstlane(b);
+    s0 = __builtin_amdgcn_readfirstlane(s0);
+    s1 = __builtin_amdgcn_readfirstlane(s1);
+    const int n_iters = s1 - s0;
+    // cursor of the next K-step to load: (sample, row, column) -- wave-uniform
+    int b_s = s0 / steps_per_sample;
+    int row_s = (s0 - b_s * steps_per_sample) / segs;
+    int col_s = (s0 - b_s * steps_per_sample - row_s * segs) * R3_KP;
+    b_s = __builtin_amdgcn_readfirstlane(b_s);
+    row_s = __builtin_amdgcn_readfirstlane(row_s);
+    col_s = __builtin_amdgcn_readfirstlane(col_s);
+
+    // ---- staging: thread moves 16-B chunk `ch` of pixel rows r0 + 16 j (j = 0..3) of both operands; threads 0..31 also
+    // move X rows 64, 65 (the right neighbour and one spare).  X row r' holds image column col - 1 + r'.
+    const int r0 = tid >> 4, ch = tid & 15;
+    const int oc = o0 + ch * 8, ic = i0 + ch * 8;
+    const bool oc_ok = oc + 8 <= p.ldgy, ic_ok = ic + 8 <= p.Cx;
+    const int u_L = p.ldgy * 2, u_C = p.Cx * 2;
+    int voff_gy[4], voff_x[5], xw_c[5], st_a[4], st_b[5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 16 * j;
+        voff_gy[j] = oc_ok ? r * u_L + oc * 2 : R3_OOB;
+        voff_x[j] = ic_ok ? r * u_C + ic * 2 : R3_OOB;
+        xw_c[j] = r - 1;
+        st_a[j] = r3_off(r, ch);
+        st_b[j] = r3_off(r, ch);
+    }
+    {
+        const int r = 64 + r0;                        // (tid < 32: r0 is 0 or 1)
+        voff_x[4] = (ic_ok && tid < 32) ? r * u_C + ic * 2 : R3_OOB;
+        xw_c[4] = r - 1;
+        st_b[4] = r3_off(r, ch);
+    }
+    const long long sample_gy = (long long)p.H * p.W * u_L, sample_x = (long long)p.H * p.W * u_C;
+    const char* gbase = (const char*)gy + (p.per_sample ? (long long)b * sample_gy : 0);
+    const char* xbase = (const char*)x + (p.per_sample ? (long long)b * sample_x : 0) +
+                        ((long long)(khi - p.pad) * p.W - 1) * u_C;       // tap (khi, 0) of pixel (0, 0): may precede the tensor
+    const __amdgpu_buffer_rsrc_t rs_gy = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, R3_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, R3_OOB, 0x00020000);
+
+    f32x16 acc[3][2][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[k][i][j][e] = 0.f;
+
+    u32x4 ra[4], rb[5];
+    auto load_next = [&]() __attribute__((always_inline)) {
+        const unsigned pixel = ((unsigned)b_s * (unsigned)p.H + (unsigned)row_s) * (unsigned)p.W + (unsigned)col_s;
+        const int so_gy = (int)(pixel * (unsigned)u_L), so_x = (int)(pixel * (unsigned)u_C);
+        const bool row_ok = (unsigned)(row_s + khi - p.pad) < (unsigned)p.H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool xok = row_ok & ((unsigned)(col_s + xw_c[j]) < (unsigned)p.W);
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gy, voff_gy[j], so_gy, 0);
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[j] : R3_OOB, so_x, 0);
+        }
+        {
+            const bool xok = row_ok & ((unsigned)(col_s + xw_c[4]) < (unsigned)p.W);
+            rb[4] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[4] : R3_OOB, so_x, 0);
+        }
+        col_s += R3_KP;
+        if (col_s == p.W) { col_s = 0; ++row_s; }
+        if (row_s == p.H) { row_s = 0; ++b_s; }
+    };
+    auto park = [&](int stage) __attribute__((always_inline)) {
+        char* sa = smem + stage * R3_STAGE;
+        char* sb = sa + R3_TA;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<u32x4*>(sa + st_a[j]) = ra[j];
+            *reinterpret_cast<u32x4*>(sb + st_b[j]) = rb[j];
+        }
+        if (tid < 32) *reinterpret_cast<u32x4*>(sb + st_b[4]) = rb[4];
+    };
+    if (n_iters > 0) {
+        load_next();
+        park(0);
+        if (n_iters > 1) load_next();
+    }
+    // transposed fragment: lane = 16 g + 4 q + pq supplies the address of pixel row (kb + q), channels cb + 4 pq ..+3;
+    // it receives channel (cb + lane % 16) of pixel rows kb .. kb + 3 (see conv_wgrad.hip).  The row a lane addresses is
+    // (multiple of 4) + q + tap shift, so the 64-B rotation of its row only depends on (q + shift) & 3: every address is
+    // a per-lane constant (one per operand / tap / 32-channel block) plus a compile-time row offset.
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int kb = 8 * (g4 >> 1), cb = 16 * (g4 & 1);
+    int cA[2], cB[3][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        cA[t] = (kb + q) * R3_ROW + ((((wm * 64 + t * 32 + cb + 4 * pq) * 2) + ((q & 3) << 6)) & (R3_ROW - 1));
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            cB[k][t] = R3_TA + (kb + q) * R3_ROW + ((((wn * 64 + t * 32 + cb + 4 * pq) * 2) + (((q + k) & 3) << 6)) & (R3_ROW - 1));
+    }
+    auto frag = [&](const char* stage_base, int c, int rows) __attribute__((always_inline)) {
+        s16x4 part[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(stage_base + c + (rows + 4 * half) * R3_ROW));
+        return __builtin_bit_cast(bf16v8, (s16x8)__builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    for (int it = 0; it < n_iters; ++it) {
+        __syncthreads();
+        if (it + 1 < n_iters) park((it + 1) & 1);
+        if (it + 2 < n_iters) load_next();
+        const char* sa = smem + (it & 1) * R3_STAGE;
+        bf16v8 fa[2][2], fb[2][3][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[0][t] = frag(sa, cA[t], 0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fb[0][k][t] = frag(sa, cB[k][t], k);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                          // k-steps of 16 pixels, fragments one step ahead
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[(ks + 1) & 1][t] = frag(sa, cA[t], (ks + 1) * 16);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fb[(ks + 1) & 1][k][t] = frag(sa, cB[k][t], (ks + 1) * 16 + k);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[k][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][k][j], acc[k][i][j], 0, 0, 0);
+        }
+        // order: the 16 fragment reads of k-step 0, then per k-step [3 MFMAs, 4 reads of the next k-step] x 4
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    }
+
+    // ---- epilogue: fp32, lanes 0..31 = 32 consecutive input channels (128-B runs), one pass per horizontal tap
+    const int lr = lane & 31, lh = lane >> 5;
+    const int taps = p.kh * 3;
+    float* gz = gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int tap = khi * 3 + k;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int icn = i0 + wn * 64 + j * 32 + lr;
+                if (icn >= p.ldgw) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int o = o0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (o >= p.O) continue;
+                    float* dst = p.oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
+                                            : gz + ((long long)o * taps + tap) * p.ldgw + icn;
+                    if (p.oi_major && icn >= p.I) continue;
+                    const float v = acc[k][i][j][e] * p.gain;
+                    if (p.atomic) atomicAdd(dst, v);
+                    else *dst = v;
+                }
+            }
+    }
+}
+
+// Called by msg_conv2d_wgrad (conv_wgrad.hip) after its argument checks; returns 1 if it launched.
+extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* gw, int dtype,
+                                         int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
+                                         int kh, int kw, int stride, int pad, int pixel_shuffle,
+                                         int per_sample, int k_chunks, int oi_major, float gain, void* stream) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("MSG_WGRAD_ROW3"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || dtype != MSG_BF16 || kw != 3 || stride != 1 || pixel_shuffle || OW % R3_KP || IH != OH || IW != OW ||
+        pad != 1 || kh > 3)
+        return 0;
+    // (the 'same' geometry: horizontal padding 1 is what the shifted-row trick assumes; vertical padding is free)
+    const long long gy_bytes = (long long)OH * OW * ldgy * 2, x_bytes = (long long)IH * IW * Cx * 2;
+    const long long nb = per_sample ? 1 : B;
+    if (nb * gy_bytes >= (1ll << 32) || nb * x_bytes >= (1ll << 32) || gy_bytes >= (1ll << 31) || x_bytes >= (1ll << 31)) return 0;
+    Row3Params p{};
+    p.B = B; p.H = OH; p.W = OW; p.Cx = Cx; p.I = I; p.ldgy = ldgy; p.O = O; p.ldgw = ldgw;
+    p.kh = kh; p.pad = pad;
+    p.per_sample = per_sample;
+    p.o_tiles = (O + 127) / 128;
+    p.i_tiles = (I + 127) / 128;
+    p.oi_major = oi_major;
+    p.gain = gain;
+    p.gw_zstride = oi_major ? (long long)O * I * kh * 3 : (long long)O * kh * 3 * ldgw;
+    const long long steps_per_sample = (long long)OH * (OW / R3_KP);
+    const long long tiles = (long long)p.o_tiles * p.i_tiles * kh;
+    long long zs;
+    if (per_sample) {
+        // the caller chose k_chunks (and zero-filled GW iff k_chunks > 1)
+        p.chunks_per_sample = k_chunks;
+        p.steps_per_chunk = (int)((steps_per_sample + k_chunks - 1) / k_chunks);
+        p.atomic = k_chunks > 1;
+        zs = (long long)B * k_chunks;
+    } else {
+        // shared weights: the batch is folded into K; K split by the wave-quantisation cost model of conv_wgrad.hip
+        // with ONE workgroup per CU (rounds of 256) and ~3 steps of fixed cost per workgroup
+        const long long steps = (long long)B * steps_per_sample;
+        long long chunks = 1, best = -1;
+        const long long cmax = steps / 4 < 4096 ? steps / 4 : 4096;
+        for (long long c = 1; c <= cmax; ++c) {
+            const long long rounds = (tiles * c + 255) / 256;
+            const long long cost = rounds * ((steps + c - 1) / c + 3);
+            if (best < 0 || cost < best) { best = cost; chunks = c; }
+            if (tiles * c > 4096) break;
+        }
+        p.steps_per_chunk = (int)((steps + chunks - 1) / chunks);
+        zs = (steps + p.steps_per_chunk - 1) / p.steps_per_chunk;
+        p.chunks_per_sample = (int)zs;
+        p.atomic = zs > 1;
+    }
+    p.nz = (int)zs;
+    const long long nblk = zs * tiles;
+    if (zs > (1 << 24) || nblk >= (1ll << 31)) return 0;
+    hipLaunchKernelGGL(conv_wgrad_row3_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+    return 1;
+}

@@ -32,6 +32,10 @@ CASES = [  # name, kind, B, I, O, H, W, k, stride, pad
     ("pow2_128w_1x1", "conv", 2, 16, 8, 4, 128, 1, 1, 0),
     ("pow2_s2_to_16", "conv", 2, 8, 8, 33, 33, 3, 2, 0),
     ("pow2_up2_8x8", "up2", 3, 8, 16, 8, 8, 2, 2, 0),
+    # maps >= 64 wide: the three-taps-per-workgroup weight-gradient kernel (conv_wgrad_row3.hip), several segments per
+    # row, ragged channel tiles, several K chunks
+    ("row3_128w_ragged", "conv", 3, 72, 136, 5, 128, 3, 1, 1),
+    ("row3_64w_tall", "conv", 2, 24, 40, 70, 64, 3, 1, 1),
 ]
 
 

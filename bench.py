@@ -129,7 +129,7 @@ def main():
         note(f"warm-up iteration {i + 1} done")
     trainer.pop_logs()
     clock_all = args.clock_all or bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))
-    roofline_keys = ("conv_fprop_pp" if args.dtype == "bf16" else "conv_fprop_dma", "upfirdn2d")
+    roofline_keys = (("conv_fprop_row3", "conv_fprop_pp") if args.dtype == "bf16" else ("conv_fprop_dma",)) + ("upfirdn2d",)
     _lib.kernel_clock.reset(enabled=not args.no_kernel_clock, only=None if clock_all else roofline_keys)
     barrier()
     t0 = time.perf_counter()
@@ -170,8 +170,13 @@ def main():
                     "launches": c["launches"],
                     "avg_us": round(c["avg_us"], 2), "algorithmic_work_per_launch": round(c["work"] / c["launches"])}
         mf = args.dtype == "bf16"
-        roof = leg(f"conv_fprop_pp/{args.dtype}", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
-                   "conv_fprop_pp_kernel (implicit-GEMM conv fwd + data-grad, 256x256 ping-pong tile, MFMA 32x32x16 bf16)") \
+        # (bf16: whichever of the two large-tile conv kernels spent more time in the timed region is the dominant one)
+        names = {"conv_fprop_row3": "conv_fprop_row3_kernel (implicit-GEMM 3x3 conv fwd + data-grad, 256x256 tile, activation "
+                                    "tile shared by the three horizontal taps, MFMA 32x32x16 bf16)",
+                 "conv_fprop_pp": "conv_fprop_pp_kernel (implicit-GEMM conv fwd + data-grad, 256x256 ping-pong tile, MFMA "
+                                  "32x32x16 bf16)"}
+        dom = max(names, key=lambda k: clock.get(f"{k}/{args.dtype}", {}).get("total_ms", 0.0))
+        roof = leg(f"{dom}/{args.dtype}", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", names[dom]) \
             if mf else leg(f"conv_fprop_dma/{args.dtype}", "mfma", MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                            "conv_fprop_kernel<float, true> (implicit-GEMM conv, MFMA 32x32x2 f32)")
         # the FIR launches that carry the bytes: the blur behind every upsampling styled conv, which also applies that

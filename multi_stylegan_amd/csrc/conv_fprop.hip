@@ -403,15 +403,23 @@ extern "C" int msg_conv2d_fprop_pp_try(const void* x, const void* w, const float
 
 extern "C" int msg_conv2d_fprop_pp_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                             int kh, int kw, long long w_batch_stride);
+extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const float* bias, void* y,
+                                         int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                         int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                         long long w_batch_stride, const ActEpilogue* act, void* stream);
 extern "C" int msg_conv2d_fprop_big_try(const void* x, const void* w, const float* bias, void* y,
                                         int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                         int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
                                         long long w_batch_stride, const ActEpilogue* act, void* stream);
 
-// Which kernel msg_conv2d_fprop would launch for this problem: 2 = conv_fprop_pp_kernel (256x256 ping-pong),
+extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
+                                              int kh, int kw, long long w_batch_stride);
+// Which kernel msg_conv2d_fprop would launch for this problem: 3 = conv_fprop_row3_kernel (3x3 'same' convs on wide maps,
+// activation tile shared by the horizontal taps), 2 = conv_fprop_pp_kernel (256x256 ping-pong),
 // 1 = conv_fprop_kernel<T, true> (128x128, LDS-DMA staging), 0 = conv_fprop_kernel<T, false> (register staging).
 extern "C" int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                      int kh, int kw, long long w_batch_stride) {
+    if (dtype == MSG_BF16 && msg_conv2d_fprop_row3_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 3;
     if (dtype == MSG_BF16 && msg_conv2d_fprop_pp_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 2;
     const int esz = dtype == MSG_BF16 ? 2 : 4;
     const int n_iters = kh * kw * (Ck / (128 / esz));
@@ -470,6 +478,10 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     if (pixel_shuffle && (N % 4 || (N / 4) % vec || ldy % vec)) return MSG_EUNSUPPORTED;
     if (!pixel_shuffle && ldy % vec) return MSG_EUNSUPPORTED;
     if (in_up > 1 && stride != 1) return MSG_EUNSUPPORTED;
+    if (dtype == MSG_BF16 &&
+        msg_conv2d_fprop_row3_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
+                                  pixel_shuffle, w_batch_stride, &act, stream))
+        return MSG_CHECK_LAUNCH();                 // 3x3 'same' convs on wide maps: activation tile shared by the three horizontal taps
     if (dtype == MSG_BF16 &&
         msg_conv2d_fprop_big_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
                                  pixel_shuffle, w_batch_stride, &act, stream))

@@ -436,6 +436,12 @@ PP_CASES = [  # shapes that take the 256x256 ping-pong kernel: name, kind, B, I,
     ("pp_1x1_shared", "conv", 8, 256, 256, 48, 48, 1, 1, 0, False),
     ("pp_up2", "up2", 3, 64, 128, 36, 36, 2, 2, 0, True),                        # 4*O = 512 columns, pixel shuffle
     ("pp_s2_dgrad", "conv", 4, 256, 256, 65, 65, 3, 2, 0, False),               # its data gradient uses in_up = 2
+    # 3x3 'same' convs on maps 64 / 128 / 256 wide: conv_fprop_row3.hip (activation tile shared by the horizontal taps);
+    # several image-row segments per tile, ragged K, N tail, shared and per-sample weights, many / few rows
+    ("row3_64w", "conv", 2, 72, 256, 40, 64, 3, 1, 1, False),
+    ("row3_128w_ps", "conv", 2, 64, 512, 10, 128, 3, 1, 1, True),
+    ("row3_256w", "conv", 1, 128, 288, 5, 256, 3, 1, 1, False),
+    ("row3_64w_ps_ragged_n", "conv", 3, 136, 264, 64, 64, 3, 1, 1, True),
 ]
 
 

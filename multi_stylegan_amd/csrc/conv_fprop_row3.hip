@@ -33,15 +33,19 @@ struct ConvParamsR3 {
     ActEpilogue act;
 };
 
-constexpr int HM = 256, HN = 256, HROW = 128;
+constexpr int HM = 256, HROW = 128;
 constexpr int HA = 264 * HROW;                     // activation buffer: 33 pieces of 8 rows
-constexpr int HB = HN * HROW;
 constexpr int H_OOB = (int)0x80000000;
 
+// NCOLB = 32-column blocks per wave: 4 -> 256-column tile (128 x 128 wave tiles), 2 -> 128-column tile (128 x 64 wave tiles,
+// for layers with 128 / 384 output channels)
+template <int NCOLB>
 __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                                  bf16_t* __restrict__ y, const float* __restrict__ bias,
                                                                  ConvParamsR3 p) {
     constexpr int VEC = 8, BKE = 64, ESZ = 2;
+    constexpr int HN = 64 * NCOLB, HB = HN * HROW, WN = 32 * NCOLB;      // tile columns, weight buffer bytes, wave-tile columns
+    constexpr int NBP = 2 * NCOLB;                                    // weight pieces (8 rows) per wave and K-step
     __shared__ __attribute__((aligned(16))) char smem[2 * HA + 2 * HB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     const char* wb = (const char*)w + (p.per_sample ? (long long)bz * p.w_bstride * ESZ : 0);
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, 0x7ffffff0, 0x00020000);
-    int a_ih0[9], a_b32[9], a_sl[9], va[9], vb[8];
+    int a_ih0[9], a_b32[9], a_sl[9], va[9], vb[NBP];
     unsigned a_okmask = 0;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -88,10 +92,11 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
         // offset of kernel row 0 (may be "negative" for the top image row: only used when that row is in range)
         a_b32[j] = (int)(((long long)b * p.x_bstride + sl * VEC) * ESZ) + ((oh - 1) * p.IW + iw) * p.Cx * ESZ;
         va[j] = H_OOB;
-        if (j < 8) {
-            const int wrow = wid * 64 + 8 * j + (lane >> 3);
+        if (j < NBP) {
+            const int wrow = wid * (WN / 2) + 8 * j + (lane >> 3);
             const int n = n0 + wrow;
-            vb[j] = n < p.N ? (int)(((long long)n * 9 * p.Ck + sl * VEC) * ESZ) : H_OOB;
+            const int slb = slot_phys ^ ((wrow >> 1) & 7);
+            vb[j] = n < p.N ? (int)(((long long)n * 9 * p.Ck + slb * VEC) * ESZ) : H_OOB;
         }
     }
     const bool ragged = (p.Cx % BKE) != 0;
@@ -108,19 +113,23 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
         if (j == 8 && wid_u != 0) return;
         const bool a_zero = !live | (ragged & (chunk * BKE + a_sl[j] * VEC + VEC > p.Cx));
         lds_t la = (lds_t)(smem + abuf * HA + (j < 8 ? wid_u * 64 + 8 * j : 256) * HROW);
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass instantiates this template too: it must not see the device builtin)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, la, 16, a_zero ? H_OOB : va[j], chunk * HROW, 0, 0);
+#endif
     };
     // weight piece j of K-step (tap, chunk) into weight buffer `bbuf`
     auto dma_b = [&](int j, int bbuf, int tap, int chunk, bool live) __attribute__((always_inline)) {
-        lds_t la = (lds_t)(smem + 2 * HA + bbuf * HB + (wid_u * 64 + 8 * j) * HROW);
+        lds_t la = (lds_t)(smem + 2 * HA + bbuf * HB + (wid_u * (WN / 2) + 8 * j) * HROW);
+#if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, la, 16, live ? vb[j] : H_OOB, (tap * p.n_chunks + chunk) * HROW, 0, 0);
+#endif
     };
 
-    f32x16 acc[4][4];
+    f32x16 acc[4][NCOLB];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NCOLB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
 #pragma unroll
     for (int j = 0; j < 9; ++j) dma_a(j, 0, 0, true);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_b(j, 0, 0, 0, true);
+    for (int j = 0; j < NBP; ++j) dma_b(j, 0, 0, 0, true);
 
     // cursors: current K-step = (kh, chunk, kw); the group being loaded = (kh_l, chunk_l)
     int kh = 0, chunk = 0, kw = 0;
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) seg_of[i] = (wm * 128 + i * 32) / seg;
     const int sxb = (lr >> 1) & 7;
-    const int fb_base = 2 * HA + (wn * 128 + lr) * HROW;
+    const int fb_base = 2 * HA + (wn * WN + lr) * HROW;
 
     for (int it = 0; it < p.n_iters; ++it) {
         __syncthreads();      // its vmcnt(0) retires this wave's DMA for step `it`; all reads of the other buffers are done
@@ -166,29 +175,29 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
             a_row[i] = r * HROW;
             a_sx[i] = (r >> 1) & 7;
         }
-        bf16v8 fa[2][4], fb[2][4];
+        bf16v8 fa[2][4], fb[2][NCOLB];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             fa[0][t] = *reinterpret_cast<const bf16v8*>(sA + a_row[t] + ((lh ^ a_sx[t]) << 4));
-            fb[0][t] = *reinterpret_cast<const bf16v8*>(sB + fb_base + t * 32 * HROW + ((lh ^ sxb) << 4));
+            if (t < NCOLB) fb[0][t] = *reinterpret_cast<const bf16v8*>(sB + fb_base + t * 32 * HROW + ((lh ^ sxb) << 4));
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)      // operands swapped: transposed accumulators (see the epilogue)
+                for (int j = 0; j < NCOLB; ++j)     // operands swapped: transposed accumulators (see the epilogue)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
                 if (kk + 1 < 4) {
                     const int s2 = 2 * (kk + 1) + lh;
                     fa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sA + a_row[i] + ((s2 ^ a_sx[i]) << 4));
-                    fb[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sB + fb_base + i * 32 * HROW + ((s2 ^ sxb) << 4));
+                    if (i < NCOLB) fb[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sB + fb_base + i * 32 * HROW + ((s2 ^ sxb) << 4));
                 }
                 // one staging instruction per group of four MFMAs: slots 0..15 of the K-step.  Even slots: weight piece
                 // slot/2 of the next K-step; odd slots: an activation piece of the next group (three per K-step).
                 const int slot = kk * 4 + i;
                 if ((slot & 1) == 0) {
-                    dma_b(slot >> 1, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
+                    if ((slot >> 1) < NBP) dma_b(slot >> 1, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
                 } else {
                     const int a = slot >> 1;                     // 0..7
                     if (a < 3) dma_a(kw * 3 + a, abuf ^ 1, chunk_l, more_a);
@@ -200,19 +209,19 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     }
     __syncthreads();
 
-    // ---- epilogue: wave-private 128 x 128 bf16 patch in LDS (32 KiB per wave), then 16-B stores.  Transposed
-    // accumulators: lane (lr, lh) owns pixel 32 i + lr and, per group g = e >> 2, the four CONSECUTIVE channels
-    // 32 j + 8 g + 4 lh + (0..3): one packed 8-byte LDS write each; 8-byte unit u of row r lives at unit u ^ (r & 15).
-    constexpr int PITCH = 128 * ESZ;
+    // ---- epilogue: wave-private 128 x WN bf16 patch in LDS, then 16-B stores.  Transposed accumulators: lane (lr, lh)
+    // owns pixel 32 i + lr and, per group g = e >> 2, the four CONSECUTIVE channels 32 j + 8 g + 4 lh + (0..3): one packed
+    // 8-byte LDS write each; 8-byte unit u of row r lives at unit u ^ (r & 15).
+    constexpr int PITCH = WN * ESZ;
     char* ep = smem + wid * (128 * PITCH);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NCOLB; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int unit = 8 * j + 2 * g + lh;                // 0..31
+            const int unit = 8 * j + 2 * g + lh;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (bias) {
-                const int nb = n0 + wn * 128 + 4 * unit;
+                const int nb = n0 + wn * WN + 4 * unit;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[e] = nb + e < p.N ? bias[nb + e] : 0.f;
             }
@@ -225,16 +234,19 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
                 *reinterpret_cast<uint2*>(ep + row * PITCH + ((unit ^ (row & 15)) << 3)) = pk;
             }
         }
-    const int er = lane >> 4, ec = (lane & 15) * VEC;          // 16 lanes per 128-channel row, 4 rows per pass
-    const int n = n0 + wn * 128 + ec;
+    constexpr int LPR = WN / VEC;                               // lanes per patch row: 16 / 8
+    constexpr int RPP = 64 / LPR;                               // rows per pass: 4 / 8
+    constexpr int NP = 64 / RPP;                                // passes per half patch (64 rows): 16 / 8
+    const int er = lane / LPR, u16 = lane % LPR, ec = u16 * VEC;
+    const int n = n0 + wn * WN + ec;
     const bool n_ok = n < p.N;
     const int lim = p.N - n;
-    // two half-patches of 16 passes each (64 rows): row coordinates stepped, all rows / residual vectors of a half
-    // requested before any is used
+    // two half-patches of 64 rows: row coordinates stepped, all rows / residual vectors of a half requested before any
+    // is used
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        int gp[16];
-        float a_bias[VEC], a_noise[16];
+        int gp[NP];
+        float a_bias[VEC], a_noise[NP];
         {
             const int m_first = min(m0 + wm * 128 + half * 64 + er, p.Mtot - 1);
             int b = p.per_sample ? bz : m_first / ohw;
@@ -247,49 +259,49 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
                 for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
             }
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass) {
-                const bool ok = m0 + wm * 128 + half * 64 + pass * 4 + er < p.Mtot;
+            for (int pass = 0; pass < NP; ++pass) {
+                const bool ok = m0 + wm * 128 + half * 64 + pass * RPP + er < p.Mtot;
                 const int pix = oh * p.OW + ow;
                 gp[pass] = ok ? b * ohw + pix : -1;
                 a_noise[pass] = (want_noise && ok) ? nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix] : 0.f;
-                ow += 4;
+                ow += RPP;
                 while (ow >= p.OW) { ow -= p.OW; ++oh; }
                 if (!p.per_sample) while (oh >= p.OH) { oh -= p.OH; ++b; }
             }
         }
         if (half == 0) __syncthreads();
-        u32x4 v[16];
+        u32x4 v[NP];
 #pragma unroll
-        for (int pass = 0; pass < 16; ++pass) {
-            const int row = half * 64 + pass * 4 + er;
-            v[pass] = *reinterpret_cast<const u32x4*>(ep + row * PITCH + (((lane & 15) ^ ((row & 15) >> 1)) << 4));
+        for (int pass = 0; pass < NP; ++pass) {
+            const int row = half * 64 + pass * RPP + er;
+            v[pass] = *reinterpret_cast<const u32x4*>(ep + row * PITCH + ((u16 ^ ((row & 15) >> 1)) << 4));
         }
         if (er & 1) {
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass) v[pass] = u32x4{v[pass][2], v[pass][3], v[pass][0], v[pass][1]};
+            for (int pass = 0; pass < NP; ++pass) v[pass] = u32x4{v[pass][2], v[pass][3], v[pass][0], v[pass][1]};
         }
         if (p.act.enabled == 1) {
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass) v[pass] = act_epilogue_apply<bf16_t>(v[pass], a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+            for (int pass = 0; pass < NP; ++pass) v[pass] = act_epilogue_apply<bf16_t>(v[pass], a_bias, a_noise[pass], p.act.alpha, p.act.scale);
         } else if (p.act.enabled == 2) {
             const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.act.residual) + (n_ok ? n : 0);
-            u32x4 r[16];
+            u32x4 r[NP];
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass)
+            for (int pass = 0; pass < NP; ++pass)
                 r[pass] = *reinterpret_cast<const u32x4*>(rbase + (long long)max(gp[pass], 0) * p.act.res_ld);
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass) v[pass] = residual_epilogue_apply<bf16_t>(v[pass], r[pass], p.act.res_gain);
+            for (int pass = 0; pass < NP; ++pass) v[pass] = residual_epilogue_apply<bf16_t>(v[pass], r[pass], p.act.res_gain);
         }
         bf16_t* ybase = y + (p.per_sample ? (long long)bz * p.y_bstride : 0) + n;
         if (n_ok && lim >= VEC) {
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass) {
+            for (int pass = 0; pass < NP; ++pass) {
                 const long long g = p.per_sample ? (long long)(gp[pass] - bz * ohw) : (long long)gp[pass];
                 if (gp[pass] >= 0) *reinterpret_cast<u32x4*>(ybase + g * p.ldy) = v[pass];
             }
         } else if (n_ok) {
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass) {
+            for (int pass = 0; pass < NP; ++pass) {
                 if (gp[pass] < 0) continue;
                 const long long g = p.per_sample ? (long long)(gp[pass] - bz * ohw) : (long long)gp[pass];
                 bf16_t* dst = ybase + g * p.ldy;
@@ -299,23 +311,37 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     }
 }
 
+// Tile width for N output channels: 256 columns unless that leaves a mostly empty last tile (N = 128, 384), then 128
+// columns; 0 = neither fits (the 15 % padding rule of the pp kernel).
+static int row3_tile_columns(int N) {
+    if (N >= 256 && (long long)((N + 255) / 256) * 256 * 100 <= (long long)N * 115) return 256;
+    if (N >= 128 && (long long)((N + 127) / 128) * 128 * 100 <= (long long)N * 115) return 128;
+    return 0;
+}
+
 // Which problems take this kernel (shared by the launcher below and by msg_conv2d_fprop_plan): a 3x3 convolution whose
 // output map equals its input map is the stride-1, pad-1, no-zero-insertion 'same' convolution.
 extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                               int kh, int kw, long long w_batch_stride) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("MSG_CONV_ROW3"); enabled = e ? atoi(e) : 1; }
-    if (!enabled || kh != 3 || kw != 3 || IH != OH || IW != OW) return 0;
+    if (!enabled || kh != 3 || kw != 3 || IH != OH || IW != OW || Ck % 64) return 0;
     if (!(OW == 64 || OW == 128 || OW % 256 == 0)) return 0;
     const bool per_sample = w_batch_stride != 0;
     const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;
-    if (N < 256 || mtot < 1024 || mtot >= (1ll << 31) || mtot % 256) return 0;
-    if ((long long)((N + HN - 1) / HN) * HN * 100 > (long long)N * 115) return 0;       // (same padding rule as the pp kernel)
+    // The 128-column variant (layers with 128 / 384 output channels) is opt-in, MSG_CONV_ROW3_NARROW=1: with 128 x 64
+    // wave tiles a wave has only 32 MFMAs between two workgroup barriers and one workgroup per CU cannot hide them --
+    // measured equal to or slower than the 128x128 kernel with its two workgroups per CU (3x3 128->128 @256^2 524 vs 510
+    // us, 256->128 @256^2 858 vs 865, 384->384 @64^2 232 vs 214).
+    static int narrow = -1;
+    if (narrow < 0) { const char* e = getenv("MSG_CONV_ROW3_NARROW"); narrow = e ? atoi(e) : 0; }
+    const int hn = row3_tile_columns(N);
+    if (!hn || (hn == 128 && !narrow) || mtot < 1024 || mtot >= (1ll << 31) || mtot % 256) return 0;
     const long long x_bytes = (long long)(per_sample ? 1 : B) * IH * IW * Cx * 2;
     const long long w_bytes = (long long)N * 9 * Ck * 2;
     if (x_bytes >= 0x7ffffff0ll || w_bytes >= 0x7ffffff0ll) return 0;                   // 31-bit buffer offsets
     if ((long long)9 * (Ck / 64) * HROW >= (1ll << 24)) return 0;
-    const long long blocks = (mtot / HM) * ((N + HN - 1) / HN);
+    const long long blocks = (mtot / HM) * ((N + hn - 1) / hn);
     if (blocks * (per_sample ? B : 1) < 224 || blocks >= (1ll << 31)) return 0;
     return 1;
 }
@@ -344,10 +370,15 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     p.n_chunks = n_chunks;
     p.n_iters = 9 * n_chunks;
     p.m_tiles = (int)((mtot + HM - 1) / HM);
-    p.n_tiles = (N + HN - 1) / HN;
+    const int hn = row3_tile_columns(N);
+    p.n_tiles = (N + hn - 1) / hn;
     const long long blocks = (long long)p.m_tiles * p.n_tiles;
     dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);
-    hipLaunchKernelGGL(conv_fprop_row3_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                       (const bf16_t*)w, (bf16_t*)y, bias, p);
+    if (hn == 256)
+        hipLaunchKernelGGL(conv_fprop_row3_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)w, (bf16_t*)y, bias, p);
+    else
+        hipLaunchKernelGGL(conv_fprop_row3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)w, (bf16_t*)y, bias, p);
     return 1;
 }

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             if (p.n_iters > 1) load_next();
         }
         for (int it = 0; it < p.n_iters; ++it) {
-            __syncthreads();                            // (DMA: the barrier's vmcnt(0) is what retires step `it`'s DMA)
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step `it`'s LDS-DMA has landed (explicit: the compiler's own wait is alias-based)
+            __syncthreads();
             if constexpr (DMA) {
                 if (it + 1 < p.n_iters) { dma_stage = (it + 1) & 1; load_next(); }   // lands while the MFMAs below run
             } else {
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             mma_step(smem + (it & 1) * STAGE_BYTES);
         }
     }
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                 // everyone done with the staging buffers: the epilogue reuses them
 
     // ---- epilogue: accumulators -> LDS (wave-private 64x64 patch) -> 16-B stores.

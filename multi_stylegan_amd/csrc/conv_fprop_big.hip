@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_big_kernel(const bf16_t* __
     const int fa_base = (wm * 128 + lr) * GROW, fb_base = GM * GROW + (wn * 128 + lr) * GROW;
 
     for (int it = 0; it < p.n_iters; ++it) {
-        if constexpr (ABL != 3 && ABL != 4) __syncthreads();   // its vmcnt(0) retires this wave's DMA of step `it`; all reads of the other stage are done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of step `it` has landed (explicit: the compiler's own wait is alias-based)
+        if constexpr (ABL != 3 && ABL != 4) __syncthreads();   // all reads of the other stage are done
         const bool more = it + 1 < p.n_iters;
         const int nstage = (it + 1) & 1;
         if (more && ++ld_chunk == p.n_chunks) next_tap();
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_big_kernel(const bf16_t* __
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ---- epilogue: wave-private 128 x 128 bf16 patch in LDS (32 KiB per wave = all 128 KiB), then 16-B stores

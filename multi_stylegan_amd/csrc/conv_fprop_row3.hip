@@ -151,7 +151,11 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     const int fb_base = 2 * HA + (wn * WN + lr) * HROW;
 
     for (int it = 0; it < p.n_iters; ++it) {
-        __syncthreads();      // its vmcnt(0) retires this wave's DMA for step `it`; all reads of the other buffers are done
+        // This wave's LDS-DMA for step `it` must have LANDED before the barrier: say so explicitly.  (The compiler's own
+        // wait in front of __syncthreads() is derived from alias analysis of the DMA destinations and was vmcnt(2) here --
+        // the last two pieces could still be in flight: a race that showed up as sporadically wrong output channels.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // all reads of the other buffers are done
         const bool more = it + 1 < p.n_iters;
         // next K-step's coordinates
         int kw_n = kw + 1, chunk_n = chunk, kh_n = kh;
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
         }
         kw = kw_n; chunk = chunk_n; kh = kh_n;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the dummy pieces of the last step write zeros: they must land first)
     __syncthreads();
 
     // ---- epilogue: wave-private 128 x WN bf16 patch in LDS, then 16-B stores.  Transposed accumulators: lane (lr, lh)

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
         }
     }
     for (int it = 0; it < n_iters; ++it) {
-        __syncthreads();                            // (DMA: its vmcnt(0) retires the DMA of step `it`)
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA of step `it` has landed
+        __syncthreads();
         if constexpr (DMA) {
             if (it + 1 < n_iters) { dma_stage = (it + 1) & 1; load_next(); }
         } else {

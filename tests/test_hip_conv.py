@@ -36,6 +36,7 @@ CASES = [  # name, kind, B, I, O, H, W, k, stride, pad
     # row, ragged channel tiles, several K chunks
     ("row3_128w_ragged", "conv", 3, 72, 136, 5, 128, 3, 1, 1),
     ("row3_64w_tall", "conv", 2, 24, 40, 70, 64, 3, 1, 1),
+    ("row3_512w", "conv", 2, 16, 24, 3, 512, 3, 1, 1),
 ]
 
 
@@ -442,6 +443,7 @@ PP_CASES = [  # shapes that take the 256x256 ping-pong kernel: name, kind, B, I,
     ("row3_128w_ps", "conv", 2, 64, 512, 10, 128, 3, 1, 1, True),
     ("row3_256w", "conv", 1, 128, 288, 5, 256, 3, 1, 1, False),
     ("row3_64w_ps_ragged_n", "conv", 3, 136, 264, 64, 64, 3, 1, 1, True),
+    ("row3_512w_ps", "conv", 8, 64, 256, 16, 512, 3, 1, 1, True),                # tiles start mid-row: live left / right neighbours
 ]
 
 

@@ -499,3 +499,22 @@ def test_grouped_linear_matches_per_layer(g, b, l, n, k):
         return torch.autograd.grad(gl.square().sum(), ws)
     for a, c in zip(second(lambda: conv_ops.grouped_linear(latent, slots, ws, bs, wscale, bscale)), second(per_layer)):
         assert rel_err(a, c) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(4, 512, 512, 64, 64, 3, True), (2, 256, 256, 128, 128, 3, False),
+                                    (2, 128, 512, 32, 256, 3, True), (4, 256, 256, 48, 48, 1, False),
+                                    (2, 128, 128, 128, 128, 3, False), (8, 64, 256, 16, 512, 3, True)])
+def test_conv_kernels_are_race_free(shape):
+    """The forward kernels have no atomics: repeated launches on the same operands must agree bit for bit, and a
+    staging race (an LDS-DMA piece still in flight when another wave reads it) shows up as a difference.  Shapes of the
+    row-sharing kernel, the ping-pong kernel and the 128x128 LDS-DMA kernel, at sizes that fill the chip."""
+    from multi_stylegan_amd import conv_ops
+    b, i, o, h, w_, k, per_sample = shape
+    torch.manual_seed(b * 1000 + i)
+    x = conv_ops.to_compute_layout(torch.randn(b, i, h, w_, device=DEV), torch.bfloat16)
+    w = torch.randn((b, o, i, k, k) if per_sample else (o, i, k, k), device=DEV) / math.sqrt(i * k * k)
+    geo = conv_ops.Geometry("conv", k, k, 1, k // 2, (h, w_), per_sample)
+    first = conv_ops._f_raw(x, w, None, geo).clone()
+    for _ in range(12):
+        again = conv_ops._f_raw(x, w, None, geo)
+        assert torch.equal(first, again)

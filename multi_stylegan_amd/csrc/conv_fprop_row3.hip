@@ -200,11 +200,39 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
                 // one staging instruction per group of four MFMAs: slots 0..15 of the K-step.  Even slots: weight piece
                 // slot/2 of the next K-step; odd slots: an activation piece of the next group (three per K-step).
                 const int slot = kk * 4 + i;
-                if ((slot & 1) == 0) {
-                    if ((slot >> 1) < NBP) dma_b(slot >> 1, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                } else {
-                    const int a = slot >> 1;                     // 0..7
-                    if (a < 3) dma_a(kw * 3 + a, abuf ^ 1, chunk_l, more_a);
+                // Placement of the K-step's 11 staging instructions among its 16 groups of four MFMAs (-DR3_DMA_ORDER=n).
+                // Measured on 3x3 512->512 @256^2: spread over the whole step (0) 4290 us, one per group from the start
+                // (1) 4180, two per group from the start (2, the default) 4040; 3..11 per group: no further gain.
+#ifndef R3_DMA_ORDER
+#define R3_DMA_ORDER 2
+#endif
+                if constexpr (R3_DMA_ORDER == 0) {               // spread: even slots weights, first odd slots activations
+                    if ((slot & 1) == 0) {
+                        if ((slot >> 1) < NBP) dma_b(slot >> 1, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
+                    } else {
+                        const int a = slot >> 1;                 // 0..7
+                        if (a < 3) dma_a(kw * 3 + a, abuf ^ 1, chunk_l, more_a);
+                    }
+                } else if constexpr (R3_DMA_ORDER == 1) {        // front-loaded, one per slot
+                    if (slot < NBP) dma_b(slot, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
+                    else if (slot < NBP + 3) dma_a(kw * 3 + slot - NBP, abuf ^ 1, chunk_l, more_a);
+                } else if constexpr (R3_DMA_ORDER >= 3) {        // front-loaded, R3_DMA_ORDER per slot
+                    constexpr int PER = R3_DMA_ORDER;
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int d = slot * PER + q;            // 0 .. NBP + 2
+                        if (d < NBP) dma_b(d, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
+                        else if (d < NBP + 3) dma_a(kw * 3 + d - NBP, abuf ^ 1, chunk_l, more_a);
+                    }
+                } else {                                         // front-loaded, two per slot
+                    if (2 * slot < NBP) {
+                        dma_b(2 * slot, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
+                        dma_b(2 * slot + 1, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
+                    } else if (2 * slot < NBP + 4) {
+                        const int a = 2 * slot - NBP;
+                        dma_a(kw * 3 + a, abuf ^ 1, chunk_l, more_a);
+                        if (a + 1 < 3) dma_a(kw * 3 + a + 1, abuf ^ 1, chunk_l, more_a);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -416,12 +416,15 @@ extern "C" int msg_conv2d_fprop_big_try(const void* x, const void* w, const floa
 
 extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                               int kh, int kw, long long w_batch_stride);
-// Which kernel msg_conv2d_fprop would launch for this problem: 3 = conv_fprop_row3_kernel (3x3 'same' convs on wide maps,
-// activation tile shared by the horizontal taps), 2 = conv_fprop_pp_kernel (256x256 ping-pong),
+// Which kernel msg_conv2d_fprop would launch for this problem: 3 / 4 = conv_fprop_row3_kernel<4,4> / <2,2> (3x3 'same' convs
+// on wide maps, activation tile shared by the horizontal taps; 256x256 / 128x128 tile), 2 = conv_fprop_pp_kernel (256x256 ping-pong),
 // 1 = conv_fprop_kernel<T, true> (128x128, LDS-DMA staging), 0 = conv_fprop_kernel<T, false> (register staging).
 extern "C" int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                      int kh, int kw, long long w_batch_stride) {
-    if (dtype == MSG_BF16 && msg_conv2d_fprop_row3_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 3;
+    if (dtype == MSG_BF16) {
+        const int r3 = msg_conv2d_fprop_row3_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride);
+        if (r3) return r3 == 1 ? 3 : 4;
+    }
     if (dtype == MSG_BF16 && msg_conv2d_fprop_pp_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 2;
     const int esz = dtype == MSG_BF16 ? 2 : 4;
     const int n_iters = kh * kw * (Ck / (128 / esz));

@@ -33,19 +33,23 @@ struct ConvParamsR3 {
     ActEpilogue act;
 };
 
-constexpr int HM = 256, HROW = 128;
-constexpr int HA = 264 * HROW;                     // activation buffer: 33 pieces of 8 rows
+constexpr int HROW = 128;
 constexpr int H_OOB = (int)0x80000000;
 
-// NCOLB = 32-column blocks per wave: 4 -> 256-column tile (128 x 128 wave tiles), 2 -> 128-column tile (128 x 64 wave tiles,
-// for layers with 128 / 384 output channels)
-template <int NCOLB>
-__global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+// MI / NCOLB = 32-row / 32-column blocks per wave (waves are 2 x 2): <4,4> the 256 x 256 tile with 128 x 128 wave tiles, one
+// workgroup per CU; <2,2> a 128 x 128 tile with 64 x 64 wave tiles and TWO workgroups per CU for layers with 128 / 384
+// output channels (<4,2>, 256 x 128 with one workgroup per CU, measured no better than the plain 128x128 kernel).
+template <int MI, int NCOLB>
+__global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                                  bf16_t* __restrict__ y, const float* __restrict__ bias,
                                                                  ConvParamsR3 p) {
     constexpr int VEC = 8, BKE = 64, ESZ = 2;
     constexpr int HN = 64 * NCOLB, HB = HN * HROW, WN = 32 * NCOLB;      // tile columns, weight buffer bytes, wave-tile columns
     constexpr int NBP = 2 * NCOLB;                                    // weight pieces (8 rows) per wave and K-step
+    constexpr int HM = 64 * MI, WM = 32 * MI;                         // tile rows, wave-tile rows
+    constexpr int NAP = 2 * MI;                                       // activation pieces per wave and group (+ piece NAP: rows HM..HM+7, wave 0)
+    constexpr int HA = (HM + 8) * HROW;                               // activation buffer
+    constexpr int APS = (NAP + 3) / 3;                                // activation pieces issued per K-step (3 K-steps per group)
     __shared__ __attribute__((aligned(16))) char smem[2 * HA + 2 * HB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -70,16 +74,16 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     const char* wb = (const char*)w + (p.per_sample ? (long long)bz * p.w_bstride * ESZ : 0);
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, 0x7ffffff0, 0x00020000);
-    int a_ih0[9], a_b32[9], a_sl[9], va[9], vb[NBP];
+    int a_ih0[NAP + 1], a_b32[NAP + 1], a_sl[NAP + 1], va[NAP + 1], vb[NBP];
     unsigned a_okmask = 0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int row = (j < 8 ? wid * 64 + 8 * j : 256) + (lane >> 3);            // row of the activation buffer
+    for (int j = 0; j < NAP + 1; ++j) {
+        const int row = (j < NAP ? wid * (HM / 4) + 8 * j : HM) + (lane >> 3);    // row of the activation buffer
         const int sl = slot_phys ^ ((row >> 1) & 7);
         const int s = row / (seg + 2), pos = row - s * (seg + 2);                 // segment, position (0 and seg+1: halo)
         const int inner = min(max(pos - 1, 0), seg - 1);
         const int m = m0 + s * seg + inner;                                       // the pixel (or the halo's neighbour)
-        bool ok = (s < p.n_seg) & (m < p.Mtot) & (j < 8 || wid == 0);
+        bool ok = (s < p.n_seg) & (m < p.Mtot) & (j < NAP || wid == 0);
         const int mm = ok ? m : 0;
         const int b = p.per_sample ? 0 : mm / ohw;
         const int pix = p.per_sample ? mm : mm - b * ohw;
@@ -103,16 +107,16 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     auto set_kh = [&](int kh) __attribute__((always_inline)) {                    // activation offsets of kernel row kh
         const int tap_off = kh * p.IW * p.Cx * ESZ;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
+        for (int j = 0; j < NAP + 1; ++j) {
             const bool ok = ((a_okmask >> j) & 1u) & ((unsigned)(a_ih0[j] + kh) < (unsigned)p.IH);
             va[j] = ok ? a_b32[j] + tap_off : H_OOB;
         }
     };
     // activation piece j of (kh set by set_kh, chunk) into activation buffer `abuf`
     auto dma_a = [&](int j, int abuf, int chunk, bool live) __attribute__((always_inline)) {
-        if (j == 8 && wid_u != 0) return;
+        if (j == NAP && wid_u != 0) return;
         const bool a_zero = !live | (ragged & (chunk * BKE + a_sl[j] * VEC + VEC > p.Cx));
-        lds_t la = (lds_t)(smem + abuf * HA + (j < 8 ? wid_u * 64 + 8 * j : 256) * HROW);
+        lds_t la = (lds_t)(smem + abuf * HA + (j < NAP ? wid_u * (HM / 4) + 8 * j : HM) * HROW);
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass instantiates this template too: it must not see the device builtin)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, la, 16, a_zero ? H_OOB : va[j], chunk * HROW, 0, 0);
 #endif
@@ -125,9 +129,9 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
 #endif
     };
 
-    f32x16 acc[4][NCOLB];
+    f32x16 acc[MI][NCOLB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NCOLB; ++j)
 #pragma unroll
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     // ---- prologue: activation tile of group 0 (kernel row 0, chunk 0), weights of K-step 0
     set_kh(0);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) dma_a(j, 0, 0, true);
+    for (int j = 0; j < NAP + 1; ++j) dma_a(j, 0, 0, true);
 #pragma unroll
     for (int j = 0; j < NBP; ++j) dma_b(j, 0, 0, 0, true);
 
@@ -144,9 +148,9 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     int kh = 0, chunk = 0, kw = 0;
     int kh_l = 0, chunk_l = 0;
     // fragment addressing: activation row of output row (wm*128 + i*32 + lr), tap kw: + kw + 2 * segment
-    int seg_of[4];
+    int seg_of[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) seg_of[i] = (wm * 128 + i * 32) / seg;
+    for (int i = 0; i < MI; ++i) seg_of[i] = (wm * WM + i * 32) / seg;
     const int sxb = (lr >> 1) & 7;
     const int fb_base = 2 * HA + (wn * WN + lr) * HROW;
 
@@ -172,23 +176,23 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
         more_a = kh_l < 3;
         const char* sA = smem + abuf * HA;
         const char* sB = smem + bbuf * HB;
-        int a_row[4], a_sx[4];
+        int a_row[MI], a_sx[MI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = wm * 128 + i * 32 + lr + kw + 2 * seg_of[i];
+        for (int i = 0; i < MI; ++i) {
+            const int r = wm * WM + i * 32 + lr + kw + 2 * seg_of[i];
             a_row[i] = r * HROW;
             a_sx[i] = (r >> 1) & 7;
         }
-        bf16v8 fa[2][4], fb[2][NCOLB];
+        bf16v8 fa[2][MI], fb[2][NCOLB];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            fa[0][t] = *reinterpret_cast<const bf16v8*>(sA + a_row[t] + ((lh ^ a_sx[t]) << 4));
-            if (t < NCOLB) fb[0][t] = *reinterpret_cast<const bf16v8*>(sB + fb_base + t * 32 * HROW + ((lh ^ sxb) << 4));
-        }
+        for (int t = 0; t < MI; ++t) fa[0][t] = *reinterpret_cast<const bf16v8*>(sA + a_row[t] + ((lh ^ a_sx[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < NCOLB; ++t)
+            fb[0][t] = *reinterpret_cast<const bf16v8*>(sB + fb_base + t * 32 * HROW + ((lh ^ sxb) << 4));
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < NCOLB; ++j)     // operands swapped: transposed accumulators (see the epilogue)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
@@ -197,41 +201,18 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
                     fa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sA + a_row[i] + ((s2 ^ a_sx[i]) << 4));
                     if (i < NCOLB) fb[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sB + fb_base + i * 32 * HROW + ((s2 ^ sxb) << 4));
                 }
-                // one staging instruction per group of four MFMAs: slots 0..15 of the K-step.  Even slots: weight piece
-                // slot/2 of the next K-step; odd slots: an activation piece of the next group (three per K-step).
-                const int slot = kk * 4 + i;
-                // Placement of the K-step's 11 staging instructions among its 16 groups of four MFMAs (-DR3_DMA_ORDER=n).
-                // Measured on 3x3 512->512 @256^2: spread over the whole step (0) 4290 us, one per group from the start
-                // (1) 4180, two per group from the start (2, the default) 4040; 3..11 per group: no further gain.
-#ifndef R3_DMA_ORDER
-#define R3_DMA_ORDER 2
-#endif
-                if constexpr (R3_DMA_ORDER == 0) {               // spread: even slots weights, first odd slots activations
-                    if ((slot & 1) == 0) {
-                        if ((slot >> 1) < NBP) dma_b(slot >> 1, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                    } else {
-                        const int a = slot >> 1;                 // 0..7
-                        if (a < 3) dma_a(kw * 3 + a, abuf ^ 1, chunk_l, more_a);
-                    }
-                } else if constexpr (R3_DMA_ORDER == 1) {        // front-loaded, one per slot
-                    if (slot < NBP) dma_b(slot, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                    else if (slot < NBP + 3) dma_a(kw * 3 + slot - NBP, abuf ^ 1, chunk_l, more_a);
-                } else if constexpr (R3_DMA_ORDER >= 3) {        // front-loaded, R3_DMA_ORDER per slot
-                    constexpr int PER = R3_DMA_ORDER;
+                // Staging instructions of the K-step -- NBP weight pieces of the next K-step, then up to APS activation
+                // pieces of the next group -- two per group of NCOLB MFMAs, from the START of the step: the earlier they
+                // are issued the more time the LDS-DMA has to land before the barrier.  (Measured on 3x3 512->512 @256^2:
+                // spread over the whole step 4290 us, one per group from the start 4180, two per group 4040, more: no gain.)
+                const int slot = kk * MI + i;
 #pragma unroll
-                    for (int q = 0; q < PER; ++q) {
-                        const int d = slot * PER + q;            // 0 .. NBP + 2
-                        if (d < NBP) dma_b(d, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                        else if (d < NBP + 3) dma_a(kw * 3 + d - NBP, abuf ^ 1, chunk_l, more_a);
-                    }
-                } else {                                         // front-loaded, two per slot
-                    if (2 * slot < NBP) {
-                        dma_b(2 * slot, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                        dma_b(2 * slot + 1, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                    } else if (2 * slot < NBP + 4) {
-                        const int a = 2 * slot - NBP;
-                        dma_a(kw * 3 + a, abuf ^ 1, chunk_l, more_a);
-                        if (a + 1 < 3) dma_a(kw * 3 + a + 1, abuf ^ 1, chunk_l, more_a);
+                for (int q = 0; q < 2; ++q) {
+                    const int d = 2 * slot + q;
+                    if (d < NBP) dma_b(d, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
+                    else if (d < NBP + APS) {
+                        const int a = kw * APS + (d - NBP);
+                        if (a < NAP + 1) dma_a(a, abuf ^ 1, chunk_l, more_a);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -242,11 +223,11 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the dummy pieces of the last step write zeros: they must land first)
     __syncthreads();
 
-    // ---- epilogue: wave-private 128 x WN bf16 patch in LDS, then 16-B stores.  Transposed accumulators: lane (lr, lh)
+    // ---- epilogue: wave-private WM x WN bf16 patch in LDS, then 16-B stores.  Transposed accumulators: lane (lr, lh)
     // owns pixel 32 i + lr and, per group g = e >> 2, the four CONSECUTIVE channels 32 j + 8 g + 4 lh + (0..3): one packed
     // 8-byte LDS write each; 8-byte unit u of row r lives at unit u ^ (r & 15).
     constexpr int PITCH = WN * ESZ;
-    char* ep = smem + wid * (128 * PITCH);
+    char* ep = smem + wid * (WM * PITCH);
 #pragma unroll
     for (int j = 0; j < NCOLB; ++j)
 #pragma unroll
@@ -259,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
                 for (int e = 0; e < 4; ++e) bv[e] = nb + e < p.N ? bias[nb + e] : 0.f;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const int row = i * 32 + lr;
                 uint2 pk;
                 pk.x = (unsigned)f2bf(acc[i][j][4 * g + 0] + bv[0]) | ((unsigned)f2bf(acc[i][j][4 * g + 1] + bv[1]) << 16);
@@ -274,14 +255,14 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
     const int n = n0 + wn * WN + ec;
     const bool n_ok = n < p.N;
     const int lim = p.N - n;
-    // two half-patches of 64 rows: row coordinates stepped, all rows / residual vectors of a half requested before any
-    // is used
+    // half-patches of 64 rows: row coordinates stepped, all rows / residual vectors of a half requested before any is
+    // used
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < MI / 2; ++half) {
         int gp[NP];
         float a_bias[VEC], a_noise[NP];
         {
-            const int m_first = min(m0 + wm * 128 + half * 64 + er, p.Mtot - 1);
+            const int m_first = min(m0 + wm * WM + half * 64 + er, p.Mtot - 1);
             int b = p.per_sample ? bz : m_first / ohw;
             const int pix0 = p.per_sample ? m_first : m_first - b * ohw;
             int oh = pix0 / p.OW, ow = pix0 - oh * p.OW;
@@ -293,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_row3_kernel(const bf16_t* _
             }
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
-                const bool ok = m0 + wm * 128 + half * 64 + pass * RPP + er < p.Mtot;
+                const bool ok = m0 + wm * WM + half * 64 + pass * RPP + er < p.Mtot;
                 const int pix = oh * p.OW + ow;
                 gp[pass] = ok ? b * ohw + pix : -1;
                 a_noise[pass] = (want_noise && ok) ? nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix] : 0.f;
@@ -359,24 +340,25 @@ extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("MSG_CONV_ROW3"); enabled = e ? atoi(e) : 1; }
     if (!enabled || kh != 3 || kw != 3 || IH != OH || IW != OW || Ck % 64) return 0;
-    if (!(OW == 64 || OW == 128 || OW % 256 == 0)) return 0;
     const bool per_sample = w_batch_stride != 0;
     const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;
-    // The 128-column variant (layers with 128 / 384 output channels) is opt-in, MSG_CONV_ROW3_NARROW=1: with 128 x 64
-    // wave tiles a wave has only 32 MFMAs between two workgroup barriers and one workgroup per CU cannot hide them --
-    // measured equal to or slower than the 128x128 kernel with its two workgroups per CU (3x3 128->128 @256^2 524 vs 510
-    // us, 256->128 @256^2 858 vs 865, 384->384 @64^2 232 vs 214).
+    // The 128 x 128 variant (two workgroups per CU) takes the layers with 128 / 384 output channels from the plain 128x128
+    // kernel: 3x3 128->128 @256^2 516 -> 476 us, 256->128 @256^2 866 -> 819, 256->384 @128^2 650 -> 614, 384->384 @64^2
+    // 235 -> 205.  MSG_CONV_ROW3_NARROW=0 switches it off (A/B).
     static int narrow = -1;
-    if (narrow < 0) { const char* e = getenv("MSG_CONV_ROW3_NARROW"); narrow = e ? atoi(e) : 0; }
+    if (narrow < 0) { const char* e = getenv("MSG_CONV_ROW3_NARROW"); narrow = e ? atoi(e) : 1; }
     const int hn = row3_tile_columns(N);
-    if (!hn || (hn == 128 && !narrow) || mtot < 1024 || mtot >= (1ll << 31) || mtot % 256) return 0;
+    if (!hn || (hn == 128 && !narrow)) return 0;
+    const int hm = hn;                             // square tiles: 256 x 256 or 128 x 128
+    if (!((OW >= 64 && hm % OW == 0) || OW % hm == 0)) return 0;              // whole image-row segments per tile
+    if (mtot < 1024 || mtot >= (1ll << 31) || mtot % hm) return 0;
     const long long x_bytes = (long long)(per_sample ? 1 : B) * IH * IW * Cx * 2;
     const long long w_bytes = (long long)N * 9 * Ck * 2;
     if (x_bytes >= 0x7ffffff0ll || w_bytes >= 0x7ffffff0ll) return 0;                   // 31-bit buffer offsets
     if ((long long)9 * (Ck / 64) * HROW >= (1ll << 24)) return 0;
-    const long long blocks = (mtot / HM) * ((N + hn - 1) / hn);
-    if (blocks * (per_sample ? B : 1) < 224 || blocks >= (1ll << 31)) return 0;
-    return 1;
+    const long long blocks = (mtot / hm) * ((N + hn - 1) / hn);
+    if (blocks * (per_sample ? B : 1) < (hm == 256 ? 224 : 448) || blocks >= (1ll << 31)) return 0;
+    return hm == 256 ? 1 : 2;                      // 1: 256 x 256 tile, 2: 128 x 128 tile
 }
 
 // Called by msg_conv2d_fprop (conv_fprop.hip) before the other large-tile kernels; returns 1 if it launched.
@@ -393,8 +375,9 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     ConvParamsR3 p{};
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
     p.per_sample = per_sample;
-    p.seg_len = OW < 256 ? OW : 256;
-    p.n_seg = 256 / p.seg_len;
+    const int hn = row3_tile_columns(N), hm = hn;
+    p.seg_len = OW < hm ? OW : hm;
+    p.n_seg = hm / p.seg_len;
     if (act) p.act = *act;
     p.x_bstride = (long long)IH * IW * Cx;
     p.w_bstride = w_batch_stride;
@@ -402,16 +385,15 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     p.Mtot = (int)mtot;
     p.n_chunks = n_chunks;
     p.n_iters = 9 * n_chunks;
-    p.m_tiles = (int)((mtot + HM - 1) / HM);
-    const int hn = row3_tile_columns(N);
+    p.m_tiles = (int)(mtot / hm);
     p.n_tiles = (N + hn - 1) / hn;
     const long long blocks = (long long)p.m_tiles * p.n_tiles;
     dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);
     if (hn == 256)
-        hipLaunchKernelGGL(conv_fprop_row3_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+        hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);
     else
-        hipLaunchKernelGGL(conv_fprop_row3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+        hipLaunchKernelGGL((conv_fprop_row3_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);
     return 1;
 }

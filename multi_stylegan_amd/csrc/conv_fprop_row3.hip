@@ -210,9 +210,11 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                 for (int q = 0; q < 2; ++q) {
                     const int d = 2 * slot + q;
                     if (d < NBP) dma_b(d, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                    else if (d < NBP + APS) {
-                        const int a = kw * APS + (d - NBP);
-                        if (a < NAP + 1) dma_a(a, abuf ^ 1, chunk_l, more_a);
+                    else if (d < NBP + NAP + 1) {
+                        // ALL activation pieces of the next group go out in the group's FIRST K-step: they come from
+                        // HBM rather than L2 and need the two remaining K-steps to land (spread three per K-step, the
+                        // last three had one K-step).  Small gain: 3x3 128->128 @256^2 476 -> 452 us, 512->512 @256^2 ~1 %
+                        if (kw == 0) dma_a(d - NBP, abuf ^ 1, chunk_l, more_a);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -349,10 +349,15 @@ extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int
     // 235 -> 205.  MSG_CONV_ROW3_NARROW=0 switches it off (A/B).
     static int narrow = -1;
     if (narrow < 0) { const char* e = getenv("MSG_CONV_ROW3_NARROW"); narrow = e ? atoi(e) : 1; }
-    const int hn = row3_tile_columns(N);
+    // 32-wide maps: the 128 x 128 tile holds four image rows (4 x 34 = 136 buffer rows) whatever the channel count:
+    // 3x3 768->768 @32^2, B=16: 229 -> 179 us, 1024->768: 318 -> 272 (they ran on the ping-pong kernel).  MSG_CONV_ROW3_W32=0: off.
+    static int w32 = -1;
+    if (w32 < 0) { const char* e = getenv("MSG_CONV_ROW3_W32"); w32 = e ? atoi(e) : 1; }
+    int hn = row3_tile_columns(N);
+    if (OW == 32 && w32 && N >= 128 && (long long)((N + 127) / 128) * 128 * 100 <= (long long)N * 115) hn = 128;
     if (!hn || (hn == 128 && !narrow)) return 0;
     const int hm = hn;                             // square tiles: 256 x 256 or 128 x 128
-    if (!((OW >= 64 && hm % OW == 0) || OW % hm == 0)) return 0;              // whole image-row segments per tile
+    if (!((OW >= 64 && hm % OW == 0) || OW % hm == 0 || (OW == 32 && hm == 128))) return 0;   // whole image-row segments per tile, <= 8 halo rows
     if (mtot < 1024 || mtot >= (1ll << 31) || mtot % hm) return 0;
     const long long x_bytes = (long long)(per_sample ? 1 : B) * IH * IW * Cx * 2;
     const long long w_bytes = (long long)N * 9 * Ck * 2;
@@ -377,7 +382,7 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     ConvParamsR3 p{};
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.Ck = Ck; p.OH = OH; p.OW = OW; p.N = N; p.ldy = ldy;
     p.per_sample = per_sample;
-    const int hn = row3_tile_columns(N), hm = hn;
+    const int hn = msg_conv2d_fprop_row3_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride) == 1 ? 256 : 128, hm = hn;
     p.seg_len = OW < hm ? OW : hm;
     p.n_seg = hm / p.seg_len;
     if (act) p.act = *act;

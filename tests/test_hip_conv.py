@@ -448,6 +448,8 @@ PP_CASES = [  # shapes that take the 256x256 ping-pong kernel: name, kind, B, I,
     ("row3_narrow_128", "conv", 4, 128, 128, 64, 128, 3, 1, 1, False),
     ("row3_narrow_384", "conv", 8, 64, 384, 64, 64, 3, 1, 1, False),
     ("row3_narrow_ps_136", "conv", 8, 72, 136, 128, 256, 3, 1, 1, True),
+    ("row3_32w_768", "conv", 8, 64, 768, 32, 32, 3, 1, 1, False),                # four image rows per 128-pixel tile
+    ("row3_32w_ps_264", "conv", 16, 136, 264, 32, 32, 3, 1, 1, True),
 ]
 
 
@@ -508,7 +510,8 @@ def test_grouped_linear_matches_per_layer(g, b, l, n, k):
 @pytest.mark.parametrize("shape", [(4, 512, 512, 64, 64, 3, True), (2, 256, 256, 128, 128, 3, False),
                                     (2, 128, 512, 32, 256, 3, True), (4, 256, 256, 48, 48, 1, False),
                                     (2, 128, 128, 128, 128, 3, False), (8, 64, 256, 16, 512, 3, True),
-                                    (8, 128, 128, 128, 256, 3, False), (16, 64, 384, 64, 64, 3, False)])
+                                    (8, 128, 128, 128, 256, 3, False), (16, 64, 384, 64, 64, 3, False),
+                                    (32, 768, 768, 32, 32, 3, False)])
 def test_conv_kernels_are_race_free(shape):
     """The forward kernels have no atomics: repeated launches on the same operands must agree bit for bit, and a
     staging race (an LDS-DMA piece still in flight when another wave reads it) shows up as a difference.  Shapes of the

@@ -40,6 +40,9 @@ constexpr int R3_OOB = (int)0x80000000;
 
 __device__ __forceinline__ int r3_off(int r, int ch) { return r * R3_ROW + (((ch << 4) + ((r & 3) << 6)) & (R3_ROW - 1)); }
 
+// W32: the map is exactly 32 pixels wide -- a K-step is TWO whole image rows; each occupies 34 rows of the X tile (its 32
+// pixels between two zero rows, written once), tap kw of pixel p of image row q reads X row 34 q + p + kw.
+template <bool W32>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
                                                                  float* __restrict__ gw, Row3Params p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * R3_STAGE];
@@ -57,8 +60,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
     tile = __builtin_amdgcn_readfirstlane(tile);
     if (z >= p.nz) return;
     const int o0 = __builtin_amdgcn_readfirstlane((tile / p.i_tiles) * 128), i0 = __builtin_amdgcn_readfirstlane((tile % p.i_tiles) * 128);
-    const int segs = p.W / R3_KP;
-    const int steps_per_sample = p.H * segs;
+    const int segs = W32 ? 1 : p.W / R3_KP;
+    const int steps_per_sample = W32 ? p.H / 2 : p.H * segs;
     int b = 0, s0, s1;
     if (p.per_sample) {
         b = z / p.chunks_per_sample;
@@ -77,8 +80,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
     const int n_iters = s1 - s0;
     // cursor of the next K-step to load: (sample, row, column) -- wave-uniform
     int b_s = s0 / steps_per_sample;
-    int row_s = (s0 - b_s * steps_per_sample) / segs;
-    int col_s = (s0 - b_s * steps_per_sample - row_s * segs) * R3_KP;
+    int row_s = W32 ? (s0 - b_s * steps_per_sample) * 2 : (s0 - b_s * steps_per_sample) / segs;
+    int col_s = W32 ? 0 : (s0 - b_s * steps_per_sample - row_s * segs) * R3_KP;
     b_s = __builtin_amdgcn_readfirstlane(b_s);
     row_s = __builtin_amdgcn_readfirstlane(row_s);
     col_s = __builtin_amdgcn_readfirstlane(col_s);
@@ -95,20 +98,28 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
         const int r = r0 + 16 * j;
         voff_gy[j] = oc_ok ? r * u_L + oc * 2 : R3_OOB;
         voff_x[j] = ic_ok ? r * u_C + ic * 2 : R3_OOB;
-        xw_c[j] = r - 1;
+        xw_c[j] = W32 ? 0 : r - 1;                     // (W32: every staged column exists; the halo rows are never loaded)
         st_a[j] = r3_off(r, ch);
-        st_b[j] = r3_off(r, ch);
+        st_b[j] = W32 ? r3_off((r >> 5) * 34 + (r & 31) + 1, ch) : r3_off(r, ch);
     }
     {
         const int r = 64 + r0;                        // (tid < 32: r0 is 0 or 1)
-        voff_x[4] = (ic_ok && tid < 32) ? r * u_C + ic * 2 : R3_OOB;
+        voff_x[4] = (!W32 && ic_ok && tid < 32) ? r * u_C + ic * 2 : R3_OOB;
         xw_c[4] = r - 1;
         st_b[4] = r3_off(r, ch);
+    }
+    if constexpr (W32) {                               // the four halo rows of both stages: zeros, once
+        if (tid < 64) {
+            const int hr = (tid >> 4) == 0 ? 0 : ((tid >> 4) == 1 ? 33 : ((tid >> 4) == 2 ? 34 : 67));
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                *reinterpret_cast<u32x4*>(smem + st * R3_STAGE + R3_TA + hr * R3_ROW + ((tid & 15) << 4)) = u32x4{0u, 0u, 0u, 0u};
+        }
     }
     const long long sample_gy = (long long)p.H * p.W * u_L, sample_x = (long long)p.H * p.W * u_C;
     const char* gbase = (const char*)gy + (p.per_sample ? (long long)b * sample_gy : 0);
     const char* xbase = (const char*)x + (p.per_sample ? (long long)b * sample_x : 0) +
-                        ((long long)(khi - p.pad) * p.W - 1) * u_C;       // tap (khi, 0) of pixel (0, 0): may precede the tensor
+                        ((long long)(khi - p.pad) * p.W - (W32 ? 0 : 1)) * u_C;   // tap (khi, 0) of pixel (0, 0): may precede the tensor
     const __amdgpu_buffer_rsrc_t rs_gy = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, R3_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, R3_OOB, 0x00020000);
 
@@ -127,18 +138,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
         const unsigned pixel = ((unsigned)b_s * (unsigned)p.H + (unsigned)row_s) * (unsigned)p.W + (unsigned)col_s;
         const int so_gy = (int)(pixel * (unsigned)u_L), so_x = (int)(pixel * (unsigned)u_C);
         const bool row_ok = (unsigned)(row_s + khi - p.pad) < (unsigned)p.H;
+        const bool row_ok1 = (unsigned)(row_s + 1 + khi - p.pad) < (unsigned)p.H;      // (W32: the step's second image row)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool xok = row_ok & ((unsigned)(col_s + xw_c[j]) < (unsigned)p.W);
+            const bool xok = W32 ? (j < 2 ? row_ok : row_ok1) : (row_ok & ((unsigned)(col_s + xw_c[j]) < (unsigned)p.W));
             ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gy, voff_gy[j], so_gy, 0);
             rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[j] : R3_OOB, so_x, 0);
         }
-        {
+        if constexpr (!W32) {
             const bool xok = row_ok & ((unsigned)(col_s + xw_c[4]) < (unsigned)p.W);
             rb[4] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[4] : R3_OOB, so_x, 0);
+            col_s += R3_KP;
+            if (col_s == p.W) { col_s = 0; ++row_s; }
+        } else {
+            row_s += 2;
         }
-        col_s += R3_KP;
-        if (col_s == p.W) { col_s = 0; ++row_s; }
         if (row_s == p.H) { row_s = 0; ++b_s; }
     };
     auto park = [&](int stage) __attribute__((always_inline)) {
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
             *reinterpret_cast<u32x4*>(sa + st_a[j]) = ra[j];
             *reinterpret_cast<u32x4*>(sb + st_b[j]) = rb[j];
         }
-        if (tid < 32) *reinterpret_cast<u32x4*>(sb + st_b[4]) = rb[4];
+        if (!W32 && tid < 32) *reinterpret_cast<u32x4*>(sb + st_b[4]) = rb[4];
     };
     if (n_iters > 0) {
         load_next();
@@ -162,14 +176,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
     // a per-lane constant (one per operand / tap / 32-channel block) plus a compile-time row offset.
     const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
     const int kb = 8 * (g4 >> 1), cb = 16 * (g4 & 1);
-    int cA[2], cB[3][2];
+    // (W32: pixels 32..63 of the K-step sit two rows further down the X tile, which also shifts their rotation: a second
+    //  set of constants for the k-steps 2 and 3)
+    constexpr int NPAR = W32 ? 2 : 1;
+    int cA[2], cB[NPAR][3][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         cA[t] = (kb + q) * R3_ROW + ((((wm * 64 + t * 32 + cb + 4 * pq) * 2) + ((q & 3) << 6)) & (R3_ROW - 1));
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            cB[k][t] = R3_TA + (kb + q) * R3_ROW + ((((wn * 64 + t * 32 + cb + 4 * pq) * 2) + (((q + k) & 3) << 6)) & (R3_ROW - 1));
+        for (int par = 0; par < NPAR; ++par)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                cB[par][k][t] = R3_TA + (kb + q) * R3_ROW +
+                                ((((wn * 64 + t * 32 + cb + 4 * pq) * 2) + (((q + k + 2 * par) & 3) << 6)) & (R3_ROW - 1));
     }
+    auto b_row = [](int ks, int k) { return ks * 16 + k + (W32 ? 2 * (ks >> 1) : 0); };     // first X-tile row of (k-step, tap)
     auto frag = [&](const char* stage_base, int c, int rows) __attribute__((always_inline)) {
         s16x4 part[2];
 #pragma unroll
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
         for (int t = 0; t < 2; ++t) {
             fa[0][t] = frag(sa, cA[t], 0);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) fb[0][k][t] = frag(sa, cB[k][t], k);
+            for (int k = 0; k < 3; ++k) fb[0][k][t] = frag(sa, cB[0][k][t], b_row(0, k));
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {                          // k-steps of 16 pixels, fragments one step ahead
@@ -197,7 +218,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
                 for (int t = 0; t < 2; ++t) {
                     fa[(ks + 1) & 1][t] = frag(sa, cA[t], (ks + 1) * 16);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) fb[(ks + 1) & 1][k][t] = frag(sa, cB[k][t], (ks + 1) * 16 + k);
+                    for (int k = 0; k < 3; ++k)
+                        fb[(ks + 1) & 1][k][t] = frag(sa, cB[W32 ? ((ks + 1) >> 1) : 0][k][t], b_row(ks + 1, k));
                 }
             }
 #pragma unroll
@@ -253,8 +275,11 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
                                          int per_sample, int k_chunks, int oi_major, float gain, void* stream) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("MSG_WGRAD_ROW3"); enabled = e ? atoi(e) : 1; }
-    if (!enabled || dtype != MSG_BF16 || kw != 3 || stride != 1 || pixel_shuffle || OW % R3_KP || IH != OH || IW != OW ||
-        pad != 1 || kh > 3)
+    static int w32_on = -1;                         // MSG_WGRAD_ROW3_W32=0: 32-wide maps stay on conv_wgrad_kernel (A/B)
+    if (w32_on < 0) { const char* e = getenv("MSG_WGRAD_ROW3_W32"); w32_on = e ? atoi(e) : 1; }
+    const bool w32 = w32_on && OW == 32 && OH % 2 == 0;
+    if (!enabled || dtype != MSG_BF16 || kw != 3 || stride != 1 || pixel_shuffle || (OW % R3_KP && !w32) || IH != OH ||
+        IW != OW || pad != 1 || kh > 3)
         return 0;
     // (the 'same' geometry: horizontal padding 1 is what the shifted-row trick assumes; vertical padding is free)
     const long long gy_bytes = (long long)OH * OW * ldgy * 2, x_bytes = (long long)IH * IW * Cx * 2;
@@ -269,7 +294,7 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     p.oi_major = oi_major;
     p.gain = gain;
     p.gw_zstride = oi_major ? (long long)O * I * kh * 3 : (long long)O * kh * 3 * ldgw;
-    const long long steps_per_sample = (long long)OH * (OW / R3_KP);
+    const long long steps_per_sample = w32 ? OH / 2 : (long long)OH * (OW / R3_KP);
     const long long tiles = (long long)p.o_tiles * p.i_tiles * kh;
     long long zs;
     if (per_sample) {
@@ -298,7 +323,11 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     p.nz = (int)zs;
     const long long nblk = zs * tiles;
     if (zs > (1 << 24) || nblk >= (1ll << 31)) return 0;
-    hipLaunchKernelGGL(conv_wgrad_row3_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+    if (w32)
+        hipLaunchKernelGGL(conv_wgrad_row3_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+    else
+        hipLaunchKernelGGL(conv_wgrad_row3_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, p);
     return 1;
 }

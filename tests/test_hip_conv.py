@@ -37,6 +37,8 @@ CASES = [  # name, kind, B, I, O, H, W, k, stride, pad
     ("row3_128w_ragged", "conv", 3, 72, 136, 5, 128, 3, 1, 1),
     ("row3_64w_tall", "conv", 2, 24, 40, 70, 64, 3, 1, 1),
     ("row3_512w", "conv", 2, 16, 24, 3, 512, 3, 1, 1),
+    ("row3_32w", "conv", 3, 24, 40, 32, 32, 3, 1, 1),                            # two image rows per K-step
+    ("row3_32w_ragged", "conv", 2, 136, 72, 6, 32, 3, 1, 1),
 ]
 
 

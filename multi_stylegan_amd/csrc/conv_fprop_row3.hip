@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     constexpr int HM = 64 * MI, WM = 32 * MI;                         // tile rows, wave-tile rows
     constexpr int NAP = 2 * MI;                                       // activation pieces per wave and group (+ piece NAP: rows HM..HM+7, wave 0)
     constexpr int HA = (HM + 8) * HROW;                               // activation buffer
-    constexpr int APS = (NAP + 3) / 3;                                // activation pieces issued per K-step (3 K-steps per group)
     __shared__ __attribute__((aligned(16))) char smem[2 * HA + 2 * HB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;

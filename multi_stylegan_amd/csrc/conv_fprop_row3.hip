@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                     fa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sA + a_row[i] + ((s2 ^ a_sx[i]) << 4));
                     if (i < NCOLB) fb[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sB + fb_base + i * 32 * HROW + ((s2 ^ sxb) << 4));
                 }
-                // Staging instructions of the K-step -- NBP weight pieces of the next K-step, then up to APS activation
-                // pieces of the next group -- two per group of NCOLB MFMAs, from the START of the step: the earlier they
+                // Staging instructions of the K-step -- NBP weight pieces of the next K-step, then (first K-step of a group)
+                // the activation pieces of the next group -- two per group of NCOLB MFMAs, from the START of the step: the earlier they
                 // are issued the more time the LDS-DMA has to land before the barrier.  (Measured on 3x3 512->512 @256^2:
                 // spread over the whole step 4290 us, one per group from the start 4180, two per group 4040, more: no gain.)
                 const int slot = kk * MI + i;

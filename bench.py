@@ -47,7 +47,22 @@ def parse_args():
                     help="HIP-event timing of EVERY launch (per-kernel table in the JSON line); by default only the two "
                          "roofline kernels are timed, which keeps the event overhead out of the host path")
     ap.add_argument("--cpu-baseline-iters", type=int, default=4)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device): rehearses the "
+                         "launcher, the rendezvous and the exchange path on a 1-GPU box; not a measurement")
     return ap.parse_args()
+
+
+def baseline_config(args, world) -> str:
+    """Which BASELINE.json config this run is, if any."""
+    if args.dtype != "bf16":
+        return ""
+    if args.resolution == 256 and args.batch == 16:
+        return " (BASELINE configs[1])" if world == 1 else (" (BASELINE configs[2])" if world == 8 else
+                                                            " (BASELINE configs[1] per GPU)")
+    if args.resolution == 512 and args.batch == 8:
+        return " (BASELINE configs[3] per GPU)"
+    return ""
 
 
 def note(msg):
@@ -82,17 +97,47 @@ def cpu_baseline(iters: int):
     for it in range(iters):
         ot.train_iteration(g, d, g_ema, og, od, pl, real, 2 + it)
     dt = time.perf_counter() - t0
-    return {"value": round(4 * iters / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": f"{iters} plain training iterations (no lazy regulariser) of the CPU oracle at 64x64, batch 4 "
-                      f"(BASELINE config 1), torch {torch.__version__}, {threads} threads"}
+    t1 = time.perf_counter()
+    ot.train_iteration(g, d, g_ema, og, od, pl, real, 16)            # R1 + path-length regularisers fire
+    dt_lazy = time.perf_counter() - t1
+    amortised = 16 * 4 / (15 * dt / iters + dt_lazy)                 # 15 plain + 1 regularised iteration
+    return {"value": round(amortised, 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "plain_iteration_s": round(dt / iters, 3), "regularised_iteration_s": round(dt_lazy, 3),
+            "sample": f"{iters} plain training iterations + 1 iteration with the lazy R1 / path-length regularisers "
+                      f"of the CPU oracle at 64x64, batch 4 (BASELINE config 1), weighted 15:1 as in training; "
+                      f"torch {torch.__version__}, {threads} threads"}
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one
+    process per GPU, RCCL rendezvous on 127.0.0.1) from a parent that never touches the GPU, relay their output
+    (rank 0 prints the JSON line) and return the launcher's exit code."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if visible < n and "--rehearse-on-one-gpu" not in sys.argv:
+        print(f"bench.py: --gpus {n} but only {visible} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:                       # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"no launcher environment: starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     from multi_stylegan_amd import dist as msg_dist
-    rank, world, local_rank = msg_dist.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    rank, world, local_rank = msg_dist.init_from_env("gloo" if args.rehearse_on_one_gpu else None)
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -137,10 +182,26 @@ def main():
         trainer.train_iteration(real)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    overlap_off_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+        every = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        torch.distributed.all_gather(every, torch.tensor([elapsed], device=dev, dtype=torch.float64))
+        per_rank = [t.item() for t in every]
+        elapsed = max(per_rank)                            # the job is as slow as its slowest rank
+        # what the overlap buys: the same steps with every bucket exchanged after backward instead of during it
+        # (outside the timed region of `value`)
+        n_off = min(args.steps, 8)
+        for red in (trainer.generator_reducer, trainer.discriminator_reducer):
+            red.overlap = False
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_off):
+            trainer.train_iteration(real)
+        barrier()
+        t_off = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t_off, op=torch.distributed.ReduceOp.MAX)
+        overlap_off_ms = 1e3 * t_off.item() / n_off
     note(f"timed region done: {elapsed:.2f} s for {args.steps} steps")
     clock = _lib.kernel_clock.summary()
     _lib.kernel_clock.reset(enabled=False)
@@ -197,10 +258,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.resolution}x{args.resolution}, seq_len=3, 2 channels, batch={args.batch}/GPU "
-                                   f"(BASELINE configs[1]); full iteration: D step + G step + EMA, lazy R1 and "
-                                   f"path-length every 16th", "global_batch": world * args.batch,
+            "config": {"workload": f"{args.resolution}x{args.resolution}, seq_len=3, 2 channels, batch={args.batch}/GPU"
+                                   f"{baseline_config(args, world)}; full iteration: D step + G step + EMA, lazy R1 and "
+                                   f"path-length every 16th; one synthetic real batch per rank, resident in HBM and "
+                                   f"re-used every step (fresh z / noise per step)",
+                       "global_batch": world * args.batch,
                        "parallelism": f"dp{world}", "dead_work_elided": bool(args.elide_dead_work)},
+            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "rehearsal_shared_gpu": bool(args.rehearse_on_one_gpu),
+            "backend": torch.distributed.get_backend() if world > 1 else None,
+            "per_rank_img_per_s": [round(args.batch * args.steps / t, 2) for t in per_rank],
+            "overlap": {"on_ms_per_step": round(1e3 * elapsed / args.steps, 2),
+                        "off_ms_per_step": round(overlap_off_ms, 2)} if overlap_off_ms is not None else None,
             "roofline": roof, "roofline_upfirdn2d": roof_fir, "kernels": kernels, "peak_mem_GiB": round(peak_mem, 2),
             "loss_d_real_last": round(logs["loss_discriminator_real"][-1], 4) if logs else None,
         }

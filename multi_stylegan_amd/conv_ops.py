@@ -680,14 +680,24 @@ class _ForkInput(Function):
         return g_main + g_res, None
 
 
+def _square(value, what: str) -> int:
+    """The kernels' Geometry carries one stride / padding for both axes; the reference's (h, w) tuples
+    (equalized_layer.py:18-21) are accepted when both entries agree and refused -- not silently truncated -- otherwise."""
+    if isinstance(value, int):
+        return value
+    value = tuple(value)
+    if len(value) != 2 or value[0] != value[1]:
+        raise _lib.MsgHipError(f"conv2d: only square {what} is implemented, got {value}")
+    return int(value[0])
+
+
 def fork_input(x, slot: GradSlot):
     return _ForkInput.apply(x, slot)
 
 
 def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, fork=False, grad_slot=None):
     """(conv(x, wscale * weight) + main) * gain; with fork=True two aliases of the result (see scaled_add_fork)."""
-    s = stride if isinstance(stride, int) else stride[0]
-    p = padding if isinstance(padding, int) else padding[0]
+    s, p = _square(stride, "stride"), _square(padding, "padding")
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
     return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork), grad_slot)
 
@@ -696,8 +706,7 @@ def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, 
 def conv2d_bias_act(x, weight, act_bias, stride=1, padding=0, wscale=1.0, negative_slope=0.2, scale=1.0,
                     grad_slot=None):
     """leaky_relu(conv(x, wscale * weight) + act_bias) * scale in one launch (EqualizedConv2d -> FusedLeakyReLU)."""
-    s = stride if isinstance(stride, int) else stride[0]
-    p = padding if isinstance(padding, int) else padding[0]
+    s, p = _square(stride, "stride"), _square(padding, "padding")
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
     return _ConvActF.apply(x, weight, act_bias, None, None, g, float(negative_slope), float(scale), grad_slot)
 
@@ -705,8 +714,7 @@ def conv2d_bias_act(x, weight, act_bias, stride=1, padding=0, wscale=1.0, negati
 def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):
     """Shared-weight conv: y = conv(x, wscale * weight) + bias; weight [O,I,kh,kw] fp32, x [B,I,H,W]; y in x's dtype.
     Passing the raw parameter plus its equalized-lr scale lets the re-laid weights be cached between optimizer steps."""
-    s = stride if isinstance(stride, int) else stride[0]
-    p = padding if isinstance(padding, int) else padding[0]
+    s, p = _square(stride, "stride"), _square(padding, "padding")
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
     return _ConvF.apply(x, weight, None if bias is None else bias.float(), g)
 

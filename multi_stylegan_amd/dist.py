@@ -60,6 +60,9 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+    # `.data` writes bump no version counter: any kernel-side weight image cached by an earlier forward is stale now
+    from . import conv_ops
+    conv_ops.invalidate_weight_cache(list(module.parameters()))
 
 
 def all_reduce_mean(t: torch.Tensor) -> torch.Tensor:

@@ -99,6 +99,9 @@ class ModelWrapper(object):
         self.batch_discriminator_passes = batch_discriminator_passes and \
             getattr(discriminator, "supports_minibatch_groups", False)
         self.iteration = 0                       # == progress_bar.n of the reference (1-based when tested, Q12)
+        self.step_trace: Optional[Dict[str, torch.Tensor]] = None      # see _step
+        self._param_names = {id(p): n for mod in (self.generator, self.discriminator)
+                             for n, p in mod.named_parameters()}
         self._log: Dict[str, List[torch.Tensor]] = {}
 
     # ------------------------------------------------------------------------------------------------ utilities
@@ -124,12 +127,23 @@ class ModelWrapper(object):
         return misc.get_noise(batch_size=batch_size, latent_dimension=self.latent_dimensions,
                               p_mixed_noise=self.hyperparameters["p_mixed_noise"], device=self.device)
 
-    def _step(self, reducer: msg_dist.GradBucketReducer, optimizer: torch.optim.Optimizer) -> None:
+    def _step(self, reducer: msg_dist.GradBucketReducer, optimizer: torch.optim.Optimizer, label: str = "") -> None:
         """finish the gradient exchange, clip to norm 5 (reference :296,:410), Adam step.  With torch's fused Adam the
         clip factor rides along as its `grad_scale` (the hook GradScaler uses: grad <- grad / grad_scale inside the
-        optimizer kernel), which saves a read-modify-write pass over every gradient."""
-        if isinstance(optimizer, torch.optim.Adam) and optimizer.defaults.get("fused"):
-            pending = reducer.finish(average=False)        # buckets hold rank SUMS; `pending` = 1 / world still to apply
+        optimizer kernel), which saves a read-modify-write pass over every gradient.
+
+        ``self.step_trace`` (a dict, off by default) records the step for parity tests under ``<label>.``: the
+        pre-clip mean gradient and the movement of every parameter the reducer owns, and the global gradient norm."""
+        fused = isinstance(optimizer, torch.optim.Adam) and bool(optimizer.defaults.get("fused"))
+        # fused: buckets keep rank SUMS; `pending` = 1 / world is still to be applied
+        pending = reducer.finish(average=not fused)
+        trace = self.step_trace
+        if trace is not None:
+            named = [(self._param_names[id(p)], p) for b in reducer.buckets for p in b.params]
+            before = {n: p.detach().clone() for n, p in named}
+            for n, p in named:
+                trace[f"{label}.grad.{n}"] = p.grad.detach() * pending
+        if fused:
             total = reducer.grad_norm() * pending          # norm of the mean gradient
             coef = torch.clamp(5.0 / (total + 1e-6), max=1.0) * pending
             optimizer.grad_scale = (1.0 / coef).reshape(()).float()
@@ -139,9 +153,12 @@ class ModelWrapper(object):
             finally:
                 del optimizer.grad_scale, optimizer.found_inf
         else:
-            reducer.finish()
-            reducer.clip_(5.0)
+            total = reducer.clip_(5.0)
             optimizer.step()
+        if trace is not None:
+            trace[f"{label}.gnorm"] = total.detach().clone()
+            for n, p in named:
+                trace[f"{label}.delta.{n}"] = p.detach() - before[n]
 
     def _zero(self) -> None:
         self.discriminator_reducer.zero_grad()
@@ -173,7 +190,7 @@ class ModelWrapper(object):
         loss_real, loss_fake = self.discriminator_loss(real_prediction, fake_prediction)
         loss_real_px, loss_fake_px = self.discriminator_loss(real_prediction_pixel_wise, fake_prediction_pixel_wise)
         (loss_real + loss_fake + loss_real_px + loss_fake_px).backward()
-        self._step(self.discriminator_reducer, self.discriminator_optimizer)
+        self._step(self.discriminator_reducer, self.discriminator_optimizer, "d")
         self._record(loss_discriminator_real=loss_real, loss_discriminator_fake=loss_fake,
                      loss_discriminator_real_pixel_wise=loss_real_px,
                      loss_discriminator_fake_pixel_wise=loss_fake_px)
@@ -185,7 +202,7 @@ class ModelWrapper(object):
             real_prediction, real_prediction_pixel_wise = D(real_rg, is_real=False, is_cut_mix=True)
             r1 = self.discriminator_regularization_loss(real_prediction, real_rg, real_prediction_pixel_wise)
             (hp["w_discriminator_regularization_r1"] * r1).backward()
-            self._step(self.discriminator_reducer, self.discriminator_optimizer)
+            self._step(self.discriminator_reducer, self.discriminator_optimizer, "r1")
             self._record(loss_discriminator_regularization=r1)
         # ---------------- generator step (reference :377-416)
         self._zero()
@@ -200,7 +217,7 @@ class ModelWrapper(object):
         (loss_g + loss_g_px).backward()
         if self.skip_d_wgrad:
             D.requires_grad_(True)
-        self._step(self.generator_reducer, self.generator_optimizer)
+        self._step(self.generator_reducer, self.generator_optimizer, "g")
         self._record(loss_generator=loss_g, loss_generator_pixel_wise=loss_g_px)
         # ---------------- lazy path-length regularisation (reference :418-444)
         if self.iteration % hp["lazy_generator_regularization"] == 0:
@@ -213,7 +230,12 @@ class ModelWrapper(object):
             reduce_fn = msg_dist.all_reduce_mean if msg_dist.collectives_active() else None
             pl_loss, path_length = self.path_length_regularization(grads, reduce_fn)
             (hp["w_generator_regularization"] * pl_loss).backward()
-            self._step(self.generator_reducer, self.generator_optimizer)
+            self._step(self.generator_reducer, self.generator_optimizer, "pl")
             self._record(path_length=path_length, loss_path_length_regularization=pl_loss)
         # ---------------- EMA (reference :446)
+        if self.step_trace is not None:
+            ema_before = {n: p.detach().clone() for n, p in self.generator_ema.named_parameters()}
         misc.exponential_moving_average(model_ema=self.generator_ema, model_train=self.generator)
+        if self.step_trace is not None:
+            for n, p in self.generator_ema.named_parameters():
+                self.step_trace[f"ema.delta.{n}"] = p.detach() - ema_before[n]

@@ -101,9 +101,28 @@ def _pl_grads(g, z, inject, noise, image_noise):
     return torch.autograd.grad((image * pn).sum(), latent, create_graph=True, retain_graph=True)[0]
 
 
+def clip_and_step(model, optimizer, trace: Optional[Dict], label: str) -> None:
+    """clip_grad_norm_(5.) + optimizer.step() (model_wrapper.py:296-298, 325-326, 410-412, 440-441).  With a
+    ``trace`` dict the step is recorded for parity tests: pre-clip gradients ``<label>.grad.<param>``, their global
+    norm ``<label>.gnorm`` and the parameter movement ``<label>.delta.<param>``."""
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+    if trace is not None:
+        before = {n: p.detach().clone() for n, p in named}
+        for n, p in named:
+            trace[f"{label}.grad.{n}"] = p.grad.detach().clone()
+    total = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5.)
+    optimizer.step()
+    if trace is not None:
+        trace[f"{label}.gnorm"] = total.detach().clone()
+        for n, p in named:
+            trace[f"{label}.delta.{n}"] = p.detach() - before[n]
+
+
 def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: torch.Tensor,
-                    iteration: int, draws: Optional[Draws] = None, hyper: Dict = HYPER) -> Dict[str, float]:
-    """One pass of model_wrapper.py:253-451; ``iteration`` is progress_bar.n (1-based, quirk Q12)."""
+                    iteration: int, draws: Optional[Draws] = None, hyper: Dict = HYPER,
+                    trace: Optional[Dict] = None) -> Dict[str, float]:
+    """One pass of model_wrapper.py:253-451; ``iteration`` is progress_bar.n (1-based, quirk Q12).  ``trace``: see
+    ``clip_and_step``; labels d, r1, g, pl; the EMA movement goes to ``ema.delta.<param>``."""
     dr = draws or Draws()
     bsz, ld, dev = real.shape[0], g.latent_dimensions, real.device
     log: Dict[str, float] = {}
@@ -117,8 +136,7 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
     l_r, l_f = d_logistic_loss(pr, pf)
     l_rp, l_fp = d_logistic_loss(prp, pfp)
     (l_r + l_f + l_rp + l_fp).backward()
-    torch.nn.utils.clip_grad_norm_(d.parameters(), max_norm=5.)
-    opt_d.step()
+    clip_and_step(d, opt_d, trace, "d")
     log.update(loss_d_real=l_r.item(), loss_d_fake=l_f.item(), loss_d_real_px=l_rp.item(),
                loss_d_fake_px=l_fp.item())
     # ---- lazy R1 (:307-329)
@@ -128,8 +146,7 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
         pr, prp = d(real_rg)
         r1 = r1_penalty(pr, real_rg, prp)
         (hyper["w_discriminator_regularization_r1"] * r1).backward()
-        torch.nn.utils.clip_grad_norm_(d.parameters(), max_norm=5.)
-        opt_d.step()
+        clip_and_step(d, opt_d, trace, "r1")
         log["r1"] = r1.item()
     # ---- G step (:379-416)
     opt_d.zero_grad(); opt_g.zero_grad()
@@ -138,8 +155,7 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
     pf, pfp = d(fake)
     l_g, l_gp = g_logistic_loss(pf), g_logistic_loss(pfp)
     (l_g + l_gp).backward()
-    torch.nn.utils.clip_grad_norm_(g.parameters(), max_norm=5.)
-    opt_g.step()
+    clip_and_step(g, opt_g, trace, "g")
     log.update(loss_g=l_g.item(), loss_g_px=l_gp.item())
     # ---- lazy path length (:418-444)
     if iteration % hyper["lazy_generator_regularization"] == 0:
@@ -149,8 +165,12 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
         grads = _pl_grads(g, z, dr.inject_pl, dr.noise_pl, dr.pl_image_noise)
         pl_loss, pl_len = path_length(grads)
         (hyper["w_generator_regularization"] * pl_loss).backward()
-        torch.nn.utils.clip_grad_norm_(g.parameters(), max_norm=5.)
-        opt_g.step()
+        clip_and_step(g, opt_g, trace, "pl")
         log.update(path_length=pl_len.mean().item(), loss_pl=pl_loss.item())
+    if trace is not None:
+        ema_before = {n: p.detach().clone() for n, p in g_ema.named_parameters()}
     ema_update(g_ema, g)                                            # :446
+    if trace is not None:
+        for n, p in g_ema.named_parameters():
+            trace[f"ema.delta.{n}"] = p.detach() - ema_before[n]
     return log

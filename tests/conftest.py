@@ -43,5 +43,46 @@ def golden():
 
 
 def rel_err(a, b):
+    """max|a - b| / max|b|: a true relative error, also for references far below 1 (parameter deltas of 1e-4, second
+    order gradients of 1e-5).  An all-zero reference degenerates to the absolute error."""
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
-    return ((a - b).abs().max() / b.abs().max().clamp(min=1.0)).item()
+    scale = b.abs().max().item()
+    return ((a - b).abs().max() / (scale if scale > 0 else 1.0)).item()
+
+
+def check_step_trace(got, ref, tol_grad, tol_norm, tol_delta, lr_floor=0.05):
+    """Compare one optimiser step, captured as {"grad.<name>", "gnorm", "delta.<name>"}, with the reference's.
+
+    * pre-clip gradients: relative to max|ref| of each tensor (`tol_grad`), and the global norm (`tol_norm`);
+    * parameter deltas p_after - p_before: Adam with beta1 = 0 moves an element by ~lr * sign(g) (first step) or
+      lr * g / sqrt(v) -- where |g| is at rounding-noise level the sign is arbitrary, so deltas are compared only on
+      elements whose reference gradient is above `lr_floor` of the tensor's largest, relative to max|ref delta|.
+    Returns statistics: compared / total delta elements (callers assert a healthy share) and the worst errors."""
+    names = sorted(k[len("grad."):] for k in ref if k.startswith("grad."))
+    assert names and sorted(k[len("grad."):] for k in got if k.startswith("grad.")) == names
+    bad = []
+    compared = total = 0
+    worst = {"grad": 0.0, "delta": 0.0}
+    for n in names:
+        g_ref, g_got = ref["grad." + n].double().cpu(), got["grad." + n].double().cpu()
+        e = rel_err(g_got, g_ref)
+        worst["grad"] = max(worst["grad"], e)
+        if e > tol_grad:
+            bad.append(("grad", n, e))
+        d_ref, d_got = ref["delta." + n].double().cpu(), got["delta." + n].double().cpu()
+        gmax, dmax = g_ref.abs().max().item(), d_ref.abs().max().item()
+        if gmax == 0.0 or dmax == 0.0:          # an exactly-zero gradient: its delta is the sign of rounding noise
+            continue
+        mask = g_ref.abs() > lr_floor * gmax
+        total += mask.numel()
+        compared += int(mask.sum())
+        e = ((d_got - d_ref).abs() * mask).max().item() / dmax
+        worst["delta"] = max(worst["delta"], e)
+        if e > tol_delta:
+            bad.append(("delta", n, e))
+    e = abs(float(got["gnorm"]) - float(ref["gnorm"])) / max(abs(float(ref["gnorm"])), 1e-30)
+    if e > tol_norm:
+        bad.append(("gnorm", "", e))
+    assert not bad, bad[:12]
+    return {"compared": compared, "total": total, "worst_grad": worst["grad"], "worst_delta": worst["delta"],
+            "gnorm_err": e}

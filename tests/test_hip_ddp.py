@@ -1,7 +1,8 @@
 """Data-parallel trainer on the real GPU: two ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device;
 gloo accepts GPU tensors), so the hook -> side-stream -> async all-reduce -> finish() path of GradBucketReducer runs
-with real HIP streams.  Checks that the replicas stay bit-identical and that the result equals the mean-of-shards
-gradient step computed by a single process."""
+with real HIP streams.  Checks that the replicas stay bit-identical and -- through tests/ddp_probe.py, which snapshots
+every bucket's local gradient as it is handed to the collective -- that each optimiser step equals the step a single
+process would take with the mean of the shards' gradients."""
 import os
 import sys
 
@@ -15,21 +16,31 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, sgd):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import multi_stylegan_amd as m
+    from ddp_probe import StepProbe
     from tools.gen_golden import TINY_D, TINY_G
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(10 + rank)                                   # different init per rank: broadcast must fix it
     g, d = m.MultiStyleGANGenerator(TINY_G), m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True)
-    tr = m.ModelWrapper(g, d, device="cuda:0", bucket_bytes=1 << 15)
+    # sgd=True: plain SGD through _step's clip_ branch (movement proportional to the exchanged gradient);
+    # sgd=False: the product default, fused Adam with 1/world and the clip folded into grad_scale
+    opts = dict(generator_optimizer=torch.optim.SGD(g.parameters(), lr=1e-3),
+                discriminator_optimizer=torch.optim.SGD(d.parameters(), lr=1e-3)) if sgd else {}
+    tr = m.ModelWrapper(g, d, device="cuda:0", bucket_bytes=1 << 15, **opts)
     assert tr.generator_reducer.comm_stream is not None and len(tr.generator_reducer.buckets) > 2
+    probe = StepProbe(tr)
     tr.iteration = 15                                              # -> iteration 16: R1 and path length fire too
     torch.manual_seed(1000 + rank)
-    for _ in range(2):
+    for it in range(2):
+        tr.step_trace.clear(); probe.local.clear()
         tr.train_iteration(torch.rand(2, 2, 3, 32, 32, device="cuda:0"))
+        # every optimiser step == the single-process step with the mean of the two shards' gradients
+        assert probe.check(world, lr=1e-3 if sgd else None) == (["d", "g", "pl", "r1"] if it == 0 else ["d", "g"])
     logs = tr.pop_logs()
     assert all(all(v == v for v in vals) for vals in logs.values()), "NaN in losses"
     flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())]).cpu()
@@ -41,11 +52,12 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_trainer_two_ranks_one_gpu_gloo():
+@pytest.mark.parametrize("sgd", [True, False])
+def test_trainer_two_ranks_one_gpu_gloo(sgd):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 200
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + os.getpid() % 200 + (7 if sgd else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sgd)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)

@@ -8,7 +8,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, rel_err
+from conftest import GOLDEN, check_step_trace, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -111,29 +111,56 @@ def test_bf16_models_track_fp32(golden):
     assert rel_err(s, z["tinyD.scalar"]) < 5e-2 and rel_err(px, z["tinyD.pixel"]) < 5e-2
 
 
-def test_train_iteration(golden):
-    """ModelWrapper.train_iteration x2 (iterations 1 and 16 -> R1 and path length fire) vs the reference-driven
-    golden run: four D losses, R1, G losses, path length + running mean, post-step parameters, EMA, and the dead
-    second-stream weights staying bit-identical."""
-    import multi_stylegan_amd as m
-    from test_oracle_golden import load_train_draws
-    z, g, d = _models(golden, "train_step", "train.G0.", "train.D0.")
-    dead0 = g.main_convolutions_2[3].modulated_convolution.weight.detach().clone()
-    trainer = m.ModelWrapper(g, d, device=DEV)
-    names = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_discriminator_fake",
-             "loss_d_real_px": "loss_discriminator_real_pixel_wise", "loss_d_fake_px": "loss_discriminator_fake_pixel_wise",
+LOG_NAMES = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_discriminator_fake",
+             "loss_d_real_px": "loss_discriminator_real_pixel_wise",
+             "loss_d_fake_px": "loss_discriminator_fake_pixel_wise",
              "r1": "loss_discriminator_regularization", "loss_g": "loss_generator",
              "loss_g_px": "loss_generator_pixel_wise", "path_length": "path_length",
              "loss_pl": "loss_path_length_regularization"}
+# fp32 path on the GPU against the reference-driven golden run.  Pre-clip gradients: 1e-3 of each tensor's largest
+# element (north star); the R1 / path-length steps are second-order quantities through every kernel and get 3e-3.
+# Parameter movement: 2e-2 of the largest movement, on the elements whose gradient is above rounding noise (Adam
+# with beta1 = 0 turns noise-level gradients into +-lr).
+STEP_TOL = {"d": (1e-3, 1e-3, 2e-2), "g": (1e-3, 1e-3, 2e-2), "r1": (3e-3, 1e-3, 2e-2), "pl": (3e-3, 1e-3, 2e-2)}
+
+
+def _golden_trainer(golden, **kw):
+    import multi_stylegan_amd as m
+    z, g, d = _models(golden, "train_step", "train.G0.", "train.D0.")
+    ema = copy.deepcopy(g)
+    ema.load_state_dict(z.state_dict("train.Gema0."))
+    return z, g, d, m.ModelWrapper(g, d, generator_ema=ema, device=DEV, **kw)
+
+
+def _run_golden_iterations(golden, fused, prepare=None):
+    import multi_stylegan_amd as m
+    from test_oracle_golden import load_train_draws, split_trace, step_traces
+    z, g, d, trainer = _golden_trainer(golden, fused_optimizer=fused)
+    if prepare is not None:
+        prepare(trainer)
+    dead0 = g.main_convolutions_2[3].modulated_convolution.weight.detach().clone()
+    report = {}
     for step, iteration in enumerate((1, 16)):
         real, draws = load_train_draws(z, step, m.model_wrapper)
         trainer.iteration = iteration - 1
+        trainer.step_trace = {}
         trainer.train_iteration(real.to(DEV), draws.to(DEV))
         log = trainer.pop_logs()
         pre = f"train.it{step}."
         for key in z.keys(pre + "log."):
-            want, got = float(z[key]), log[names[key[len(pre + "log."):]]][0]
-            assert abs(got - want) <= TOL * max(1.0, abs(want)), (key, got, want)
+            want, got = float(z[key]), log[LOG_NAMES[key[len(pre + "log."):]]][0]
+            assert abs(got - want) <= TOL * abs(want), (key, got, want)
+        want_steps, want_ema = step_traces(z, pre)
+        got_steps, got_ema = split_trace(trainer.step_trace)
+        assert list(got_steps) == (["d", "g"] if iteration == 1 else ["d", "r1", "g", "pl"])
+        for label, want in want_steps.items():
+            tg, tn, td = STEP_TOL[label]
+            st = check_step_trace(got_steps[label], want, tol_grad=tg, tol_norm=tn, tol_delta=td)
+            assert st["compared"] > 0.2 * st["total"], (label, st)
+            report[f"it{iteration}.{label}"] = st
+        worst_ema = max(rel_err(got_ema[n], want) for n, want in want_ema.items())
+        assert worst_ema < 1e-2, ("ema", worst_ema)
+        report[f"it{iteration}.ema"] = worst_ema
         gp, dp = dict(g.named_parameters()), dict(d.named_parameters())
         ep = dict(trainer.generator_ema.named_parameters())
         for key in z.keys(pre + "G."):
@@ -144,6 +171,90 @@ def test_train_iteration(golden):
             assert rel_err(dp[key[len(pre + "D."):]], z[key]) < TOL, key
     assert rel_err(trainer.path_length_regularization.mean_path_length, z["train.it1.mean_path_length"]) < TOL
     assert torch.equal(g.main_convolutions_2[3].modulated_convolution.weight.cpu(), dead0.cpu())
+    return report
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_train_iteration(golden, fused):
+    """ModelWrapper.train_iteration x2 (iterations 1 and 16 -> R1 and path length fire) vs the reference-driven
+    golden run: every loss, and every optimiser step WHOLE -- the pre-clip gradient of every parameter, the global
+    gradient norm, the movement of every parameter (where its gradient is above rounding noise), the EMA movement
+    from an EMA copy that starts away from the generator -- plus post-step parameters, the running path-length mean
+    and the dead second-stream weights staying bit-identical.  Both optimiser paths: torch's fused
+    Adam with the clip folded into grad_scale (the product default) and clip_ + plain Adam."""
+    print("step parity:", json.dumps(_run_golden_iterations(golden, fused)))
+
+
+@pytest.mark.parametrize("broken", ["no_step", "double_step", "no_clip", "no_ema", "double_ema"])
+def test_train_iteration_check_catches_a_broken_trainer(golden, broken):
+    """The same run on deliberately broken trainers must FAIL (round-1 review: a no-op optimiser, a wrong clip and a
+    missing EMA step all passed the old post-step value checks).  The R1 step of the golden run has a gradient norm of
+    3e4, so a trainer that does not clip moves every parameter differently."""
+    from multi_stylegan_amd import dist as msg_dist, misc
+    restore = []
+
+    def prepare(trainer):
+        if broken in ("no_step", "double_step"):
+            for opt in (trainer.generator_optimizer, trainer.discriminator_optimizer):
+                orig = opt.step
+                opt.step = (lambda: None) if broken == "no_step" else (lambda orig=orig: (orig(), orig()))
+        elif broken == "no_clip":
+            restore.append((msg_dist.GradBucketReducer, "clip_", msg_dist.GradBucketReducer.clip_))
+            msg_dist.GradBucketReducer.clip_ = lambda self, max_norm: self.grad_norm()
+        else:
+            orig_ema = misc.exponential_moving_average
+            restore.append((misc, "exponential_moving_average", orig_ema))
+            misc.exponential_moving_average = (lambda **kw: None) if broken == "no_ema" else \
+                (lambda **kw: (orig_ema(**kw), orig_ema(**kw)))
+    try:
+        with pytest.raises(AssertionError) as info:
+            _run_golden_iterations(golden, False, prepare)
+    finally:
+        for obj, name, orig in restore:
+            setattr(obj, name, orig)
+    want = "ema" if "ema" in broken else "delta"
+    assert want in str(info.value), str(info.value)[:300]
+
+
+def test_fused_step_equals_plain_clip_and_adam(golden):
+    """ModelWrapper._step's fused branch (bucket SUMS + `pending` = 1/world and the clip factor folded into fused
+    Adam's grad_scale) against finish() + clip_() + plain Adam on the same gradients, with a faked world factor of 4
+    so that the 1/world scaling is exercised, for a norm below and one above the clip threshold."""
+    import multi_stylegan_amd as m
+    torch.manual_seed(9)
+    for gain in (1e-3, 3.0):
+        results = []
+        for fused in (True, False):
+            _, g, d = _models(golden)
+            tr = m.ModelWrapper(g, d, device=DEV, fused_optimizer=fused)
+            red = tr.discriminator_reducer
+            gen = torch.Generator(device=DEV).manual_seed(5)
+            for bkt in red.buckets:                       # "sum over 4 ranks" of some gradient
+                bkt.flat.copy_(torch.randn(bkt.flat.shape, generator=gen, device=DEV) * gain * 4)
+            red.world, red.active = 4, True
+            orig_finish = red.finish
+
+            def finish(average=True, red=red):            # no communicator: the buckets already hold the rank sums
+                red._armed = False
+                if average:
+                    torch._foreach_mul_([b.flat for b in red.buckets], 0.25)
+                    return 1.0
+                return 0.25
+            red.finish = finish
+            before = [p.detach().clone() for p in d.parameters()]
+            sums = [b.flat.clone() for b in red.buckets]
+            tr.step_trace = {}
+            for _ in range(2):                             # second step: Adam's v remembers the first one's scale
+                for b, s0 in zip(red.buckets, sums):       # (the plain path scales the buckets in place)
+                    b.flat.copy_(s0)
+                tr._step(red, tr.discriminator_optimizer, "x")
+            results.append(([p.detach() - b for p, b in zip(d.parameters(), before)],
+                            float(tr.step_trace["x.gnorm"])))
+        (d_fused, n_fused), (d_plain, n_plain) = results
+        assert abs(n_fused - n_plain) <= 1e-5 * n_plain
+        assert (n_plain > 5.0) == (gain > 1.0)
+        for a, b in zip(d_fused, d_plain):
+            assert rel_err(a, b) < 1e-4
 
 
 def test_config1_64px_matches_oracle():
@@ -173,6 +284,70 @@ def test_config1_64px_matches_oracle():
         ws, wp = do(x)
         gs, gp = dd(x.to(DEV))
     assert rel_err(gs, ws) < TOL and rel_err(gp, wp) < TOL
+
+
+def test_config2_256px_batch16_matches_oracle():
+    """BASELINE config 2 at its own size -- 256x256, 7 x 512 channels, batch 16, the shapes and the batch the kernel
+    selection keys on (row-sharing 3x3 kernels, ping-pong kernel, sub-pixel up-convs, B=16 grid sizes) -- against the
+    CPU oracle run on this box with the same weights, z, noise: generator image, discriminator outputs on that image
+    and the gradients of one discriminator backward.  fp32 storage: 1e-3 of max|ref| (north star); bf16 storage (the
+    benchmarked path): 5e-2 for outputs, 0.1 for gradients (norm-wise), as documented in DESIGN.md section 4."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    from oracle import models as om
+    torch.manual_seed(21)
+    bsz = 16
+    cfg = generator_config_for_resolution(256)
+    go, do = om.Generator(cfg), om.Discriminator(no_rfp=True)
+    gen_cpu = torch.Generator().manual_seed(22)
+    with torch.no_grad():                                   # move zero-initialised scalars off zero so they matter
+        for n, p in list(go.named_parameters()) + list(do.named_parameters()):
+            if n.endswith("noise_injection.weight") or n.endswith("gamma"):
+                p.copy_(torch.randn(p.shape, generator=gen_cpu) * 0.3)
+            elif n.endswith(".bias") and p.ndim == 1:
+                p.add_(torch.randn(p.shape, generator=gen_cpu) * 0.1)
+    z = [torch.randn(bsz, 512, generator=gen_cpu), torch.randn(bsz, 512, generator=gen_cpu)]
+    noise = [torch.randn(bsz, 1, 4, 4, generator=gen_cpu)] + \
+            [torch.randn(bsz, 1, 2 ** (i // 2 + 3), 2 ** (i // 2 + 3), generator=gen_cpu) for i in range(12)]
+    watch = ["encoder_blocks.0.main_mapping.0.weight", "encoder_blocks.1.main_mapping.2.weight",
+             "encoder_blocks.2.theta.weight", "downscale_convolutions.1.0.weight",
+             "decoder_blocks.3.main_mapping.0.weight", "transposed_convolutions.3.1.weight", "final_mapping.1.weight",
+             "classification_head.2.weight", "encoder_blocks.4.main_mapping.1.bias"]
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        want_img = go(z, noise=noise, inject_index=6)
+    ws, wp = do(want_img)
+    (ws.mean() + wp.mean()).backward()
+    want_grads = {n: dict(do.named_parameters())[n].grad.clone() for n in watch}
+    ws, wp = ws.detach(), wp.detach()
+    do.zero_grad(set_to_none=True)
+    print(f"oracle on the CPU: {time.time() - t0:.1f} s")
+    gd = m.MultiStyleGANGenerator(cfg)
+    gd.load_state_dict(go.state_dict())
+    dd = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    dd.load_state_dict(do.state_dict())
+    gd.to(DEV); dd.to(DEV)
+    for dt, tol_out, tol_grad in ((torch.float32, 1e-3, 2e-3), (torch.bfloat16, 5e-2, 0.1)):
+        gd.compute_dtype = dd.compute_dtype = dt
+        dd.zero_grad()
+        with torch.no_grad():
+            img = gd([t.to(DEV) for t in z], noise=[t.to(DEV) for t in noise], inject_index=6)
+        e_img = rel_err(img, want_img)
+        s, px = dd(want_img.to(DEV))
+        (s.mean() + px.mean()).backward()
+        e_s, e_px = rel_err(s, ws), rel_err(px, wp)
+        params = dict(dd.named_parameters())
+        if dt == torch.float32:
+            e_g = {n: rel_err(params[n].grad, want_grads[n]) for n in watch}
+        else:
+            e_g = {n: ((params[n].grad.cpu() - want_grads[n]).norm() / want_grads[n].norm()).item() for n in watch}
+        print(f"{dt}: image {e_img:.2e}  score {e_s:.2e}  pixel map {e_px:.2e}  grads " +
+              " ".join(f"{v:.1e}" for v in e_g.values()))
+        assert e_img < tol_out and e_s < tol_out and e_px < tol_out, (dt, e_img, e_s, e_px)
+        assert max(e_g.values()) < tol_grad, (dt, e_g)
+        del img, s, px
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("batch", [1, 3])

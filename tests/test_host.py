@@ -128,6 +128,7 @@ def _trainer_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from multi_stylegan_amd.model_wrapper import ModelWrapper
     from oracle import models as om                      # CPU stand-ins for G/D: the trainer logic is device-agnostic
     from tools.gen_golden import TINY_D, TINY_G
@@ -136,11 +137,18 @@ def _trainer_worker(rank, world, port, out):
     g.live_parameters = lambda: [p for n, p in g.named_parameters() if not n.startswith("main_convolutions_2.")]
     orig_forward = g.forward
     g.forward = lambda *a, path_length_noise=None, **k: orig_forward(*a, **k)
-    tr = ModelWrapper(g, d, device="cpu", bucket_bytes=1 << 16)
+    # plain SGD: the parameter movement is proportional to the exchanged gradient, so a wrong reduction shows
+    tr = ModelWrapper(g, d, device="cpu", bucket_bytes=1 << 16,
+                      generator_optimizer=torch.optim.SGD(g.parameters(), lr=1e-3),
+                      discriminator_optimizer=torch.optim.SGD(d.parameters(), lr=1e-3))
+    from ddp_probe import StepProbe
+    probe = StepProbe(tr)
     tr.iteration = 15                                    # next iteration is 16: R1 and path length fire
     torch.manual_seed(1000 + rank)                       # different data per rank
     tr.train_iteration(torch.rand(2, 2, 3, 32, 32))
     logs = tr.pop_logs()
+    # every step == the single-process step with the mean of the two shards' gradients
+    assert probe.check(world, lr=1e-3) == ["d", "g", "pl", "r1"]
     assert {"loss_discriminator_regularization", "path_length", "loss_generator"} <= set(logs)
     flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())])
     both = [torch.zeros_like(flat) for _ in range(world)]
@@ -163,3 +171,13 @@ def test_trainer_data_parallel_gloo_world2():
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=5) == "ok"
+
+
+def test_non_square_conv_geometry_is_refused():
+    """EqualizedConv2d keeps the reference's (h, w) tuple arguments; a non-square stride / padding must raise instead
+    of being computed with the first entry (round-1 advice)."""
+    from multi_stylegan_amd import _lib, conv_ops
+    assert conv_ops._square((2, 2), "stride") == 2 and conv_ops._square(1, "padding") == 1
+    for bad in ((1, 2), (2, 1), (1, 1, 1)):
+        with pytest.raises(_lib.MsgHipError, match="square"):
+            conv_ops._square(bad, "stride")

@@ -9,7 +9,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, rel_err
+from conftest import GOLDEN, check_step_trace, rel_err
 from oracle import models as om
 from oracle import ops as oo
 from oracle import train as ot
@@ -162,8 +162,33 @@ def load_train_draws(z, step, ot_mod=ot):
         z_pl=lst("z_pl"), inject_pl=4, noise_pl=lst("noise_pl"), pl_image_noise=z[pre + "pl_image_noise"])
 
 
+def step_traces(z, pre):
+    """{label: {"grad.<p>", "delta.<p>", "gnorm"}} of one golden iteration, plus the EMA movement."""
+    steps, ema = {}, {}
+    for key in z.keys(pre + "step."):
+        label, rest = key[len(pre + "step."):].split(".", 1)
+        if label == "ema":
+            ema[rest[len("delta."):]] = z[key]
+        else:
+            steps.setdefault(label, {})[rest] = z[key]
+    return steps, ema
+
+
+def split_trace(trace):
+    steps, ema = {}, {}
+    for key, v in trace.items():
+        label, rest = key.split(".", 1)
+        if label == "ema":
+            ema[rest[len("delta."):]] = v
+        else:
+            steps.setdefault(label, {})[rest] = v
+    return steps, ema
+
+
 def test_train_iteration(golden):
-    """Two iterations (1 and 16): losses, R1, path length and post-step parameters."""
+    """Two iterations (1 and 16): losses, R1, path length, and EVERY optimiser step whole -- pre-clip gradients of all
+    parameters, the global norm, the parameter movement where the gradient is above rounding noise -- plus the EMA
+    movement from an EMA copy that starts away from the generator."""
     import copy
     from tools.gen_golden import TINY_D, TINY_G
     z = golden("train_step")
@@ -171,15 +196,25 @@ def test_train_iteration(golden):
     g.load_state_dict(z.state_dict("train.G0.")); d.load_state_dict(z.state_dict("train.D0."))
     dead0 = g.main_convolutions_2[3].modulated_convolution.weight.detach().clone()
     g_ema = copy.deepcopy(g)
+    g_ema.load_state_dict(z.state_dict("train.Gema0."))
     og, od = ot.make_optimizers(g, d)
     pl = ot.PathLength()
     for step, iteration in enumerate((1, 16)):
         real, draws = load_train_draws(z, step)
-        log = ot.train_iteration(g, d, g_ema, og, od, pl, real, iteration, draws)
+        trace = {}
+        log = ot.train_iteration(g, d, g_ema, og, od, pl, real, iteration, draws, trace=trace)
         pre = f"train.it{step}."
         for key in z.keys(pre + "log."):
             want = float(z[key])
-            assert abs(log[key[len(pre + "log."):]] - want) <= 2e-4 * max(1.0, abs(want)), key
+            assert abs(log[key[len(pre + "log."):]] - want) <= 2e-4 * abs(want), key
+        want_steps, want_ema = step_traces(z, pre)
+        got_steps, got_ema = split_trace(trace)
+        assert list(got_steps) == (["d", "g"] if iteration == 1 else ["d", "r1", "g", "pl"])
+        for label, want in want_steps.items():
+            st = check_step_trace(got_steps[label], want, tol_grad=5e-4, tol_norm=1e-4, tol_delta=2e-3)
+            assert st["compared"] > 0.2 * st["total"], (label, st)
+        for n, want in want_ema.items():
+            assert rel_err(got_ema[n], want) < 2e-3, n
         gp, dp, ep = dict(g.named_parameters()), dict(d.named_parameters()), dict(g_ema.named_parameters())
         for key in z.keys(pre + "G."):
             assert rel_err(gp[key[len(pre + "G."):]], z[key]) < 1e-4, key
@@ -189,3 +224,28 @@ def test_train_iteration(golden):
             assert rel_err(dp[key[len(pre + "D."):]], z[key]) < 1e-4, key
     assert rel_err(pl.mean_path_length, z["train.it1.mean_path_length"]) < 1e-4
     assert torch.equal(g.main_convolutions_2[3].modulated_convolution.weight, dead0)   # dead branch untouched
+
+
+def test_step_trace_check_bites(golden):
+    """The comparison itself must fail for the errors it exists to catch: a skipped optimiser step, a step applied
+    twice, a clip with the wrong threshold (gradients fine, deltas not), and a skipped / doubled EMA update."""
+    z = golden("train_step")
+    steps, ema = step_traces(z, "train.it1.")
+    want = steps["r1"]                                   # the R1 step: its gradient norm is far above 5, the clip acts
+    assert float(want["gnorm"]) > 5.0
+    same = {k: v.clone() for k, v in want.items()}
+    check_step_trace(same, want, 5e-4, 1e-4, 2e-3)
+    for name, factor in (("skipped", 0.0), ("doubled", 2.0)):
+        broken = {k: (v * factor if k.startswith("delta.") else v.clone()) for k, v in want.items()}
+        with pytest.raises(AssertionError):
+            check_step_trace(broken, want, 5e-4, 1e-4, 2e-3)
+    # Adam's second/third step depends on the clipped gradient's size through v: a missing clip changes the deltas
+    unclipped = {k: v.clone() for k, v in want.items()}
+    scale = float(want["gnorm"]) / 5.0
+    for k in unclipped:
+        if k.startswith("delta."):
+            unclipped[k] = unclipped[k] * (1 + 0.05 * min(scale, 2.0))
+    with pytest.raises(AssertionError):
+        check_step_trace(unclipped, want, 5e-4, 1e-4, 2e-3)
+    some = next(iter(ema))
+    assert rel_err(ema[some] * 0.0, ema[some]) > 0.5 and rel_err(ema[some] * 2.0, ema[some]) > 0.5

@@ -342,7 +342,12 @@ def gen_tiny_models(ref, om, store):
 
 def gen_train_step(ref, om, ot, store):
     """Two iterations (the 2nd with iteration=16 so both lazy regularisers fire), reference modules driven by the
-    step order of model_wrapper.py:253-451 (the wrapper itself needs rtpt/tqdm/torchvision and cannot be imported)."""
+    step order of model_wrapper.py:253-451 (the wrapper itself needs rtpt/tqdm/torchvision and cannot be imported).
+
+    Besides losses and post-step parameters, every optimiser step is recorded whole: the pre-clip gradient of every
+    parameter, the global gradient norm clip_grad_norm_ returns, and the movement p_after - p_before of every
+    parameter; the EMA copy starts AWAY from the generator (G0 + 0.05 randn) so that its movement per iteration
+    (0.001 (p - ema) ~ 5e-5) is far above fp32 resolution and a missing / doubled EMA step is visible."""
     G, D, L = ref["multi_stylegan_generator"], ref["u_net_2d_discriminator"], ref["loss"]
     import copy
     g = torch.Generator().manual_seed(16)
@@ -351,9 +356,16 @@ def gen_train_step(ref, om, ot, store):
     perturb_small_params(gen, g); perturb_small_params(dis, g)
     ogen, odis = om.Generator(TINY_G), om.Discriminator(TINY_D, no_rfp=True)
     load_matching(ogen, gen); load_matching(odis, dis)
-    gen_ema, ogen_ema = copy.deepcopy(gen), copy.deepcopy(ogen)
+    gen_ema = copy.deepcopy(gen)
+    with torch.no_grad():
+        for p in gen_ema.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    ogen_ema = copy.deepcopy(ogen)
+    load_matching(ogen_ema, gen_ema)
     for k, v in gen.state_dict().items():
         store["train.G0." + k] = npy(v)
+    for k, v in gen_ema.state_dict().items():
+        store["train.Gema0." + k] = npy(v)
     for k, v in dis.state_dict().items():
         store["train.D0." + k] = npy(v)
     hp = ref["config"].generation_hyperparameters
@@ -364,6 +376,17 @@ def gen_train_step(ref, om, ot, store):
     d_loss, g_loss, r1_loss = L.NonSaturatingLogisticDiscriminatorLoss(), L.NonSaturatingLogisticGeneratorLoss(), \
         L.R1Regularization()
     bsz = 4
+
+    def clip_step(model, optimizer, trace, label):      # model_wrapper.py:296-298 and its three siblings, recorded
+        named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+        before = {n: p.detach().clone() for n, p in named}
+        for n, p in named:
+            trace[f"{label}.grad.{n}"] = p.grad.detach().clone()
+        trace[f"{label}.gnorm"] = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5.).detach().clone()
+        optimizer.step()
+        for n, p in named:
+            trace[f"{label}.delta.{n}"] = p.detach() - before[n]
+
     for step, iteration in enumerate((1, 16)):
         real = torch.rand(bsz, 2, 3, 32, 32, generator=g)
         dr = ot.Draws(
@@ -379,7 +402,7 @@ def gen_train_step(ref, om, ot, store):
                 store[f"{pre}{key}.{i}"] = npy(t)
         store[pre + "pl_image_noise"] = npy(dr.pl_image_noise)
         # ---- reference sequence
-        log = {}
+        log, trace = {}, {}
         od.zero_grad(); og.zero_grad()
         with torch.no_grad():
             fake = gen(input=dr.z_d, inject_index=dr.inject_d, noise=dr.noise_d)
@@ -387,7 +410,7 @@ def gen_train_step(ref, om, ot, store):
         pf, pfp = dis(fake, is_real=False, is_cut_mix=False)
         lr_, lf = d_loss(pr, pf); lrp, lfp = d_loss(prp, pfp)
         (lr_ + lf + lrp + lfp).backward()
-        torch.nn.utils.clip_grad_norm_(dis.parameters(), max_norm=5.); od.step()
+        clip_step(dis, od, trace, "d")
         log.update(loss_d_real=lr_.item(), loss_d_fake=lf.item(), loss_d_real_px=lrp.item(), loss_d_fake_px=lfp.item())
         if iteration % hp["lazy_discriminator_regularization"] == 0:
             od.zero_grad(); og.zero_grad()
@@ -395,14 +418,14 @@ def gen_train_step(ref, om, ot, store):
             pr, prp = dis(rr)
             r1 = r1_loss(pr, rr, prp)
             (hp["w_discriminator_regularization_r1"] * r1).backward()
-            torch.nn.utils.clip_grad_norm_(dis.parameters(), max_norm=5.); od.step()
+            clip_step(dis, od, trace, "r1")
             log["r1"] = r1.item()
         od.zero_grad(); og.zero_grad()
         fake = gen(input=dr.z_g, noise=dr.noise_g)
         pf, pfp = dis(fake)
         lg, lgp = g_loss(pf), g_loss(pfp)
         (lg + lgp).backward()
-        torch.nn.utils.clip_grad_norm_(gen.parameters(), max_norm=5.); og.step()
+        clip_step(gen, og, trace, "g")
         log.update(loss_g=lg.item(), loss_g_px=lgp.item())
         if iteration % hp["lazy_generator_regularization"] == 0:
             od.zero_grad(); og.zero_grad()
@@ -411,18 +434,33 @@ def gen_train_step(ref, om, ot, store):
             grads = torch.autograd.grad((im * pn).sum(), la, create_graph=True, retain_graph=True)[0]
             lpl, plen = pl_ref(grads)
             (hp["w_generator_regularization"] * lpl).backward()
-            torch.nn.utils.clip_grad_norm_(gen.parameters(), max_norm=5.); og.step()
+            clip_step(gen, og, trace, "pl")
             log.update(path_length=plen.mean().item(), loss_pl=lpl.item())
             store[pre + "mean_path_length"] = npy(pl_ref.mean_path_length)
         with torch.no_grad():
             src = dict(gen.named_parameters())
             for n, p in gen_ema.named_parameters():
+                before = p.detach().clone()
                 p.mul_(0.999).add_(src[n], alpha=0.001)
+                trace["ema.delta." + n] = p.detach() - before
         # ---- oracle
-        olog = ot.train_iteration(ogen, odis, ogen_ema, oog, ood, pl_or, real, iteration, dr)
+        otrace = {}
+        olog = ot.train_iteration(ogen, odis, ogen_ema, oog, ood, pl_or, real, iteration, dr, trace=otrace)
         for k, v in log.items():
             assert abs(olog[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, olog[k], v)
             store[pre + "log." + k] = np.array(v)
+        assert sorted(otrace) == sorted(trace)
+        for k, v in trace.items():
+            kind = k.split(".")[1]
+            scale = max(v.abs().max().item(), 1e-30)
+            err = (otrace[k] - v).abs().max().item() / scale
+            if kind == "delta" and not k.startswith("ema."):
+                # Adam(beta1=0) turns gradient rounding noise into +-lr: compare where the gradient is above noise
+                gk = k.replace(".delta.", ".grad.", 1)
+                mask = trace[gk].abs() > 0.05 * trace[gk].abs().max()
+                err = ((otrace[k] - v).abs() * mask).max().item() / scale
+            assert err <= (2e-3 if kind == "delta" else 5e-4), f"oracle != reference for {pre}{k}: {err:.3e}"
+            store[pre + "step." + k] = npy(v)
         watch_g = ["style_mapping.layers.1.weight", "main_convolutions_1.5.modulated_convolution.weight",
                    "main_convolutions_1.2.modulated_convolution.modulation_mapping.bias",
                    "main_convolutions_2.3.modulated_convolution.weight", "output_blocks_2.0.modulated_convolution.weight"]

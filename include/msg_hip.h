@@ -11,7 +11,10 @@
  *   - return value: MSG_OK (0) or a negative MSG_E* code -- an unsupported
  *     configuration is an error, never a silent no-op (the reference silently
  *     launches nothing for unmatched modes: op_static/upfirdn2d_kernel.cu:172-211);
- *   - dtype: MSG_F32 or MSG_BF16 storage; arithmetic is always fp32.
+ *   - dtype: MSG_F32 or MSG_BF16 storage; arithmetic is always fp32.  The two entries that replace the
+ *     reference's CUDA modules (msg_upfirdn2d[_pitched], msg_fused_bias_act, msg_bias_act_backward) also take
+ *     MSG_F16, the `half` of AT_DISPATCH_FLOATING_TYPES_AND_HALF (op_static/upfirdn2d_kernel.cu:225,
+ *     op_static/fused_bias_act_kernel.cu:79); double is not provided.
  *
  * Each entry cites the reference interface it replaces (paths relative to the
  * reference repository root).
@@ -24,7 +27,7 @@ extern "C" {
 #endif
 
 enum { MSG_OK = 0, MSG_EINVAL = -1, MSG_EUNSUPPORTED = -2, MSG_ELAUNCH = -3 };
-enum { MSG_F32 = 0, MSG_BF16 = 1 };
+enum { MSG_F32 = 0, MSG_BF16 = 1, MSG_F16 = 2 };
 
 /* Library/ABI version and the code-object architecture it was built for ("gfx950"). */
 int msg_abi_version(void);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsg_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msg_hip.h")
 
-MSG_F32, MSG_BF16 = 0, 1
+MSG_F32, MSG_BF16, MSG_F16 = 0, 1, 2
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_longlong, _c.c_float
 
@@ -86,12 +86,17 @@ def check(code, what):
         raise MsgHipError(f"{what}: {lib().msg_strerror(code).decode()} (code {code})")
 
 
-def dtype_code(t: torch.Tensor) -> int:
+def dtype_code(t: torch.Tensor, allow_half: bool = False) -> int:
+    """MSG_* storage code of a tensor.  float16 only where `allow_half` (the FIR / activation entries that replace the
+    reference's CUDA modules, which dispatch float / double / half: upfirdn2d_kernel.cu:225)."""
     if t.dtype == torch.float32:
         return MSG_F32
     if t.dtype == torch.bfloat16:
         return MSG_BF16
-    raise MsgHipError(f"dtype {t.dtype} is not supported by the gfx950 kernels (float32 / bfloat16 only)")
+    if allow_half and t.dtype == torch.float16:
+        return MSG_F16
+    raise MsgHipError(f"dtype {t.dtype} is not supported by the gfx950 kernels (float32 / bfloat16"
+                      f"{' / float16' if allow_half else ''} only)")
 
 
 def require_gpu(*tensors):

@@ -144,6 +144,7 @@ extern "C" int msg_fused_bias_act(const void* x, const float* bias, const void* 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MSG_F32) return fwd_dispatch<float>(x, bias, ref, y, noise, noise_weight, p, s);
     if (dtype == MSG_BF16) return fwd_dispatch<bf16_t>(x, bias, ref, y, noise, noise_weight, p, s);
+    if (dtype == MSG_F16) return fwd_dispatch<f16_t>(x, bias, ref, y, noise, noise_weight, p, s);
     return MSG_EUNSUPPORTED;
 }
 
@@ -297,6 +298,7 @@ extern "C" int msg_bias_act_backward(const void* gy, const void* out, void* gx, 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MSG_F32) return bwd_dispatch<float>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
     if (dtype == MSG_BF16) return bwd_dispatch<bf16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
+    if (dtype == MSG_F16) return bwd_dispatch<f16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
     return MSG_EUNSUPPORTED;
 }
 

@@ -409,10 +409,6 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
                                          int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                          int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
                                          long long w_batch_stride, const ActEpilogue* act, void* stream);
-extern "C" int msg_conv2d_fprop_big_try(const void* x, const void* w, const float* bias, void* y,
-                                        int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
-                                        int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
-                                        long long w_batch_stride, const ActEpilogue* act, void* stream);
 
 extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                               int kh, int kw, long long w_batch_stride);
@@ -487,10 +483,6 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
         msg_conv2d_fprop_row3_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
                                   pixel_shuffle, w_batch_stride, &act, stream))
         return MSG_CHECK_LAUNCH();                 // 3x3 'same' convs on wide maps: activation tile shared by the three horizontal taps
-    if (dtype == MSG_BF16 &&
-        msg_conv2d_fprop_big_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
-                                 pixel_shuffle, w_batch_stride, &act, stream))
-        return MSG_CHECK_LAUNCH();                 // MSG_CONV_BIG=1: 256x256 tile with 128x128 wave tiles (conv_fprop_big.hip)
     if (dtype == MSG_BF16 &&
         msg_conv2d_fprop_pp_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
                                 pixel_shuffle, w_batch_stride, &act, stream))

@@ -13,7 +13,7 @@
 // Structure: 256 x 256 output tile, four waves with 128 x 128 wave tiles (256 accumulators in the unified VGPR/AGPR
 // file, one workgroup per CU), LDS-DMA staging through buffer descriptors, the K-step software-pipelined inside the wave
 // (fragment reads of sub-step kk+1 and the DMA of the next K-step / next activation tile between the MFMAs of sub-step
-// kk), one workgroup barrier per K-step -- the design of conv_fprop_big.hip.  LDS: 2 activation buffers of 264 rows +
+// kk), one workgroup barrier per K-step -- the one-wave-per-SIMD design measured in round 1.  LDS: 2 activation buffers of 264 rows +
 // 2 weight buffers of 256 rows, 128-B rows with XOR-swizzled 16-B slots (130 KiB); the epilogue (transposed
 // accumulators, packed LDS writes, batched 16-B stores, optional fused activation / residual merge) reuses it.
 // An output tile is 256 consecutive pixels = one or more whole image-row segments (map width 64, 128, or a multiple of

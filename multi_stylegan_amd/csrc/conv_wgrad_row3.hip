@@ -10,7 +10,7 @@
 // one neighbour on each side, zeros at the image border) once, and the transposing fragment reads of tap kw simply
 // start kw rows further down the LDS tile.  Per MFMA: a third of the staging traffic, two thirds of the LDS reads
 // (the GY fragments are shared by the three taps).  Three accumulator sets (3 x 64 registers) mean one workgroup of four
-// waves per CU, in the unified VGPR/AGPR file -- the regime of conv_fprop_big.hip, with a third of its staging per MFMA.
+// waves per CU, in the unified VGPR/AGPR file -- the one-wave-per-SIMD regime, with a third of its staging per MFMA.
 //
 // Same LDS image as conv_wgrad.hip ([pixel][128 channels], rows rotated by 64 B * (pixel & 3), ds_read_b64_tr_b16),
 // same buffer-load addressing (per-thread constant offset + wave-uniform SGPR cursor, out-of-range rows read zeros),

@@ -10,6 +10,7 @@ typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef short  bf16x8 __attribute__((ext_vector_type(8)));
 typedef short  bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
+typedef _Float16 f16_t;            // IEEE half storage (the reference's `half` dispatch): FIR / activation entries only
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-B staging register (plain vector: stays in VGPRs)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -40,10 +41,28 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    uint4 raw;
+    __device__ __forceinline__ void zero() { raw = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ float get(int i) const {
+        const uint32_t w = (&raw.x)[i >> 1];
+        const unsigned short h = (unsigned short)((i & 1) ? (w >> 16) : (w & 0xffffu));
+        return (float)__builtin_bit_cast(_Float16, h);
+    }
+    __device__ __forceinline__ void set2(int pair, float lo, float hi) {
+        const unsigned short a = __builtin_bit_cast(unsigned short, (_Float16)lo);      // RNE
+        const unsigned short b = __builtin_bit_cast(unsigned short, (_Float16)hi);
+        (&raw.x)[pair] = (uint32_t)a | ((uint32_t)b << 16);
+    }
+};
+
 template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
 template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float load_as_f32<f16_t>(const f16_t* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void store_from_f32(T* p, float v);
+template <> __device__ __forceinline__ void store_from_f32<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 template <> __device__ __forceinline__ void store_from_f32<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 

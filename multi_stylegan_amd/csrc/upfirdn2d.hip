@@ -275,5 +275,6 @@ extern "C" int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, i
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MSG_F32) return dispatch<float>(x, fir, y, p, s);
     if (dtype == MSG_BF16) return dispatch<bf16_t>(x, fir, y, p, s);
+    if (dtype == MSG_F16) return dispatch<f16_t>(x, fir, y, p, s);
     return MSG_EUNSUPPORTED;
 }

@@ -48,7 +48,7 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
     nbytes = (2 + (ref is not None)) * x.numel() * x.element_size()
     with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_fwd/{x.dtype}", nbytes):
         code = _lib.lib().msg_fused_bias_act(
-            x.data_ptr(), _lib.ptr(b32), _lib.ptr(ref), y.data_ptr(), _lib.dtype_code(x), x.numel(), step_b,
+            x.data_ptr(), _lib.ptr(b32), _lib.ptr(ref), y.data_ptr(), _lib.dtype_code(x, True), x.numel(), step_b,
             x.shape[1], _lib.ptr(nz), _lib.ptr(nw32), nb, pix, act, grad, float(alpha), float(scale),
             _lib.stream_of(dev))
     _lib.check(code, "msg_fused_bias_act")
@@ -69,7 +69,7 @@ class FusedLeakyReLUFunctionBackward(Function):
         gnw = torch.zeros(1, dtype=torch.float32, device=dev) if noise is not None else None
         with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
             code = _lib.lib().msg_bias_act_backward(
-                g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g), g.numel(), step_b, channels,
+                g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g, True), g.numel(), step_b, channels,
                 _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
                 _lib.stream_of(dev))
         _lib.check(code, "msg_bias_act_backward")

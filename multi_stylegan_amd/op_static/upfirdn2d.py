@@ -47,6 +47,9 @@ def _separable(fir: torch.Tensor):
     return out
 
 
+_DT_NAME = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
+
+
 def _launch(x, fir, up, down, pad):
     """x [B,C,H,W] (either layout), fir [kh,kw] fp32 on the same device -> y, same layout and dtype as x."""
     up_x, up_y = up
@@ -66,16 +69,16 @@ def _launch(x, fir, up, down, pad):
         sb, _, sh, sw = x.stride()
         vec = 16 // x.element_size()
         if sh == w * sw and (sb == h * w * sw or b == 1) and sw % vec == 0 and c % vec == 0 and x.data_ptr() % 16 == 0 \
-                and kh <= 4 and kw <= 4 and x.dtype in (torch.float32, torch.bfloat16):
+                and kh <= 4 and kw <= 4 and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
             pitch = sw
         else:
             x = x.contiguous(memory_format=torch.channels_last)
     if pitch is not None:
         major, minor = b, c
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up{up_x}down{down_x}/vec"
+        key = f"upfirdn2d/{_DT_NAME[x.dtype]}/up{up_x}down{down_x}/vec"
         with _lib.on_device(dev), _lib.kernel_clock.span(key, (b * c * h * w + y.numel()) * x.element_size()):
-            code = _lib.lib().msg_upfirdn2d_pitched(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x),
+            code = _lib.lib().msg_upfirdn2d_pitched(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x, True),
                                                     major, h, w, minor, pitch, kh, kw, up_x, up_y, down_x, down_y,
                                                     px0, px1, py0, py1, _lib.stream_of(dev))
         _lib.check(code, "msg_upfirdn2d_pitched")
@@ -88,7 +91,7 @@ def _launch(x, fir, up, down, pad):
         major, minor = b * c, 1
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev)
     vec_ok = minor % (16 // x.element_size()) == 0 and kh <= 4 and kw <= 4
-    key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up{up_x}down{down_x}/"
+    key = f"upfirdn2d/{_DT_NAME[x.dtype]}/up{up_x}down{down_x}/"
     if vec_ok and minor > 1 and up == (1, 1) and down == (1, 1) and kh == 4 and kw == 4 and \
             (_SEPARABLE == 2 or (_SEPARABLE == 1 and x.dtype == torch.bfloat16)):
         factors = _separable(fir)
@@ -101,7 +104,7 @@ def _launch(x, fir, up, down, pad):
             return y
     key += "vec" if vec_ok else "generic"
     with _lib.on_device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
-        code = _lib.lib().msg_upfirdn2d(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x),
+        code = _lib.lib().msg_upfirdn2d(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x, True),
                                         major, h, w, minor, kh, kw, up_x, up_y, down_x, down_y,
                                         px0, px1, py0, py1, _lib.stream_of(dev))
     _lib.check(code, "msg_upfirdn2d")

@@ -101,6 +101,16 @@ def _pl_grads(g, z, inject, noise, image_noise):
     return torch.autograd.grad((image * pn).sum(), latent, create_graph=True, retain_graph=True)[0]
 
 
+def _zero(*optimizers) -> None:
+    """optimizer.zero_grad() as the reference's pinned torch 1.8.1 (requirements.txt:1) executes it: gradients are
+    ZEROED, not dropped (set_to_none became the default only in torch 2.0).  It matters in the two regulariser steps:
+    parameters the double-backward graph does not reach (e.g. the additive output-block biases in the path-length
+    step) keep a zero gradient, so Adam still takes a (zero-length) step for them -- its step count advances and its
+    second-moment estimate decays -- instead of skipping them."""
+    for opt in optimizers:
+        opt.zero_grad(set_to_none=False)
+
+
 def clip_and_step(model, optimizer, trace: Optional[Dict], label: str) -> None:
     """clip_grad_norm_(5.) + optimizer.step() (model_wrapper.py:296-298, 325-326, 410-412, 440-441).  With a
     ``trace`` dict the step is recorded for parity tests: pre-clip gradients ``<label>.grad.<param>``, their global
@@ -127,7 +137,7 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
     bsz, ld, dev = real.shape[0], g.latent_dimensions, real.device
     log: Dict[str, float] = {}
     # ---- D step (:260-305)
-    opt_d.zero_grad(); opt_g.zero_grad()
+    _zero(opt_d, opt_g)
     with torch.no_grad():
         z = dr.z_d if dr.z_d is not None else get_noise(bsz, ld, hyper["p_mixed_noise"], dev)
         fake = g(z, inject_index=dr.inject_d, noise=dr.noise_d)
@@ -141,7 +151,7 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
                loss_d_fake_px=l_fp.item())
     # ---- lazy R1 (:307-329)
     if iteration % hyper["lazy_discriminator_regularization"] == 0:
-        opt_d.zero_grad(); opt_g.zero_grad()
+        _zero(opt_d, opt_g)
         real_rg = real.detach().requires_grad_(True)
         pr, prp = d(real_rg)
         r1 = r1_penalty(pr, real_rg, prp)
@@ -149,7 +159,7 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
         clip_and_step(d, opt_d, trace, "r1")
         log["r1"] = r1.item()
     # ---- G step (:379-416)
-    opt_d.zero_grad(); opt_g.zero_grad()
+    _zero(opt_d, opt_g)
     z = dr.z_g if dr.z_g is not None else get_noise(bsz, ld, hyper["p_mixed_noise"], dev)
     fake = g(z, inject_index=dr.inject_g, noise=dr.noise_g)
     pf, pfp = d(fake)
@@ -159,7 +169,7 @@ def train_iteration(g, d, g_ema, opt_g, opt_d, path_length: PathLength, real: to
     log.update(loss_g=l_g.item(), loss_g_px=l_gp.item())
     # ---- lazy path length (:418-444)
     if iteration % hyper["lazy_generator_regularization"] == 0:
-        opt_d.zero_grad(); opt_g.zero_grad()
+        _zero(opt_d, opt_g)
         n_pl = max(1, int(hyper["batch_size_shrink_path_length_regularization"] * bsz))
         z = dr.z_pl if dr.z_pl is not None else get_noise(n_pl, ld, hyper["p_mixed_noise"], dev)
         grads = _pl_grads(g, z, dr.inject_pl, dr.noise_pl, dr.pl_image_noise)

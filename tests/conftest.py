@@ -71,7 +71,11 @@ def check_step_trace(got, ref, tol_grad, tol_norm, tol_delta, lr_floor=0.05):
             bad.append(("grad", n, e))
         d_ref, d_got = ref["delta." + n].double().cpu(), got["delta." + n].double().cpu()
         gmax, dmax = g_ref.abs().max().item(), d_ref.abs().max().item()
-        if gmax == 0.0 or dmax == 0.0:          # an exactly-zero gradient: its delta is the sign of rounding noise
+        if gmax == 0.0:          # a parameter this step's graph does not reach: zero gradient, Adam must not move it
+            if g_got.abs().max().item() != 0.0 or d_got.abs().max().item() != 0.0:
+                bad.append(("moved-without-gradient", n, d_got.abs().max().item()))
+            continue
+        if dmax == 0.0:
             continue
         mask = g_ref.abs() > lr_floor * gmax
         total += mask.numel()

@@ -147,9 +147,6 @@ def _run_golden_iterations(golden, fused, prepare=None):
         trainer.train_iteration(real.to(DEV), draws.to(DEV))
         log = trainer.pop_logs()
         pre = f"train.it{step}."
-        for key in z.keys(pre + "log."):
-            want, got = float(z[key]), log[LOG_NAMES[key[len(pre + "log."):]]][0]
-            assert abs(got - want) <= TOL * abs(want), (key, got, want)
         want_steps, want_ema = step_traces(z, pre)
         got_steps, got_ema = split_trace(trainer.step_trace)
         assert list(got_steps) == (["d", "g"] if iteration == 1 else ["d", "r1", "g", "pl"])
@@ -161,6 +158,9 @@ def _run_golden_iterations(golden, fused, prepare=None):
         worst_ema = max(rel_err(got_ema[n], want) for n, want in want_ema.items())
         assert worst_ema < 1e-2, ("ema", worst_ema)
         report[f"it{iteration}.ema"] = worst_ema
+        for key in z.keys(pre + "log."):
+            want, got = float(z[key]), log[LOG_NAMES[key[len(pre + "log."):]]][0]
+            assert abs(got - want) <= TOL * abs(want), (key, got, want)
         gp, dp = dict(g.named_parameters()), dict(d.named_parameters())
         ep = dict(trainer.generator_ema.named_parameters())
         for key in z.keys(pre + "G."):
@@ -253,8 +253,8 @@ def test_fused_step_equals_plain_clip_and_adam(golden):
         (d_fused, n_fused), (d_plain, n_plain) = results
         assert abs(n_fused - n_plain) <= 1e-5 * n_plain
         assert (n_plain > 5.0) == (gain > 1.0)
-        for a, b in zip(d_fused, d_plain):
-            assert rel_err(a, b) < 1e-4
+        for a, b in zip(d_fused, d_plain):       # movements of ~1e-3 on parameters of ~1: fp32 resolves them to ~2e-4
+            assert rel_err(a, b) < 1e-3
 
 
 def test_config1_64px_matches_oracle():

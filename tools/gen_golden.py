@@ -347,7 +347,11 @@ def gen_train_step(ref, om, ot, store):
     Besides losses and post-step parameters, every optimiser step is recorded whole: the pre-clip gradient of every
     parameter, the global gradient norm clip_grad_norm_ returns, and the movement p_after - p_before of every
     parameter; the EMA copy starts AWAY from the generator (G0 + 0.05 randn) so that its movement per iteration
-    (0.001 (p - ema) ~ 5e-5) is far above fp32 resolution and a missing / doubled EMA step is visible."""
+    (0.001 (p - ema) ~ 5e-5) is far above fp32 resolution and a missing / doubled EMA step is visible.
+
+    ``zero_grad(set_to_none=False)``: the reference calls ``optimizer.zero_grad()`` under its pinned torch 1.8.1
+    (requirements.txt:1), where that ZEROES gradients; torch 2's default would drop them and make Adam skip the
+    parameters a regulariser's graph does not reach."""
     G, D, L = ref["multi_stylegan_generator"], ref["u_net_2d_discriminator"], ref["loss"]
     import copy
     g = torch.Generator().manual_seed(16)
@@ -403,7 +407,7 @@ def gen_train_step(ref, om, ot, store):
         store[pre + "pl_image_noise"] = npy(dr.pl_image_noise)
         # ---- reference sequence
         log, trace = {}, {}
-        od.zero_grad(); og.zero_grad()
+        od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
         with torch.no_grad():
             fake = gen(input=dr.z_d, inject_index=dr.inject_d, noise=dr.noise_d)
         pr, prp = dis(real, is_real=True, is_cut_mix=False)
@@ -413,14 +417,14 @@ def gen_train_step(ref, om, ot, store):
         clip_step(dis, od, trace, "d")
         log.update(loss_d_real=lr_.item(), loss_d_fake=lf.item(), loss_d_real_px=lrp.item(), loss_d_fake_px=lfp.item())
         if iteration % hp["lazy_discriminator_regularization"] == 0:
-            od.zero_grad(); og.zero_grad()
+            od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
             rr = real.clone().requires_grad_(True)
             pr, prp = dis(rr)
             r1 = r1_loss(pr, rr, prp)
             (hp["w_discriminator_regularization_r1"] * r1).backward()
             clip_step(dis, od, trace, "r1")
             log["r1"] = r1.item()
-        od.zero_grad(); og.zero_grad()
+        od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
         fake = gen(input=dr.z_g, noise=dr.noise_g)
         pf, pfp = dis(fake)
         lg, lgp = g_loss(pf), g_loss(pfp)
@@ -428,7 +432,7 @@ def gen_train_step(ref, om, ot, store):
         clip_step(gen, og, trace, "g")
         log.update(loss_g=lg.item(), loss_g_px=lgp.item())
         if iteration % hp["lazy_generator_regularization"] == 0:
-            od.zero_grad(); og.zero_grad()
+            od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
             im, la = gen(input=dr.z_pl, inject_index=dr.inject_pl, noise=dr.noise_pl, return_main_style_vectors=True)
             pn = dr.pl_image_noise / math.sqrt(im.shape[2] * im.shape[3] * im.shape[4])
             grads = torch.autograd.grad((im * pn).sum(), la, create_graph=True, retain_graph=True)[0]

@@ -73,6 +73,29 @@ def all_reduce_mean(t: torch.Tensor) -> torch.Tensor:
     return out / world_size()
 
 
+def global_top_k(scores: torch.Tensor, v: float):
+    """Top-k over the GLOBAL batch (reference loss.py:436-443 ranks the batch gathered on device 0): every rank
+    contributes its [B] scores, the k = max(1, int(world * B * v)) largest of all of them are kept.  Returns the indices
+    of this rank's kept samples and the weight k_local * world / k that makes the ranks' averaged mean-losses equal the
+    mean over the k kept samples.  A rank that keeps nothing returns index [0] with weight 0 (its backward still runs,
+    so the gradient exchange stays aligned).  One small all-gather and one device->host copy of k indices."""
+    world, rank = world_size(), (dist.get_rank() if collectives_active() else 0)
+    local = scores.reshape(-1)
+    everything = [torch.empty_like(local) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(everything, local.contiguous())
+    else:
+        everything = [local]
+    flat = torch.cat(everything)
+    k = max(1, int(flat.shape[0] * v))
+    kept = torch.topk(flat, k=k).indices
+    lo = rank * local.shape[0]
+    mine = kept[(kept >= lo) & (kept < lo + local.shape[0])] - lo
+    if mine.numel() == 0:
+        return torch.zeros(1, dtype=torch.long, device=scores.device), 0.0
+    return mine, mine.numel() * world / k
+
+
 class _Bucket:
     __slots__ = ("flat", "params", "pending", "work", "ready")
 

@@ -26,6 +26,14 @@ class NonSaturatingLogisticDiscriminatorLoss(nn.Module):
         return _weighted(F.softplus(-prediction_real), weight), _weighted(F.softplus(prediction_fake), weight)
 
 
+class NonSaturatingLogisticDiscriminatorLossCutMix(nn.Module):
+    """Per-pixel logistic loss against a binary CutMix label map (reference loss.py:173-196): the real term counts
+    where the label is 1, the fake term where it is 0; both are means over ALL pixels."""
+
+    def forward(self, prediction: torch.Tensor, label: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return (F.softplus(-prediction) * label).mean(), (F.softplus(prediction) * (1. - label)).mean()
+
+
 class R1Regularization(nn.Module):
     def forward(self, prediction_real: torch.Tensor, image_real: torch.Tensor,
                 prediction_real_pixel_wise: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -57,3 +65,29 @@ class PathLengthRegularization(nn.Module):
         penalty = torch.mean((path_lengths - mean) ** 2)
         self.mean_path_length = mean.detach()
         return penalty, path_lengths
+
+
+class TopK(nn.Module):
+    """Top-k training of the generator (reference loss.py:398-444): only the k = max(1, int(B v)) samples the
+    discriminator rates most realistic contribute; v anneals linearly from 1 to 0.5 between `starting_iteration` and
+    `final_iteration` (counted in forward calls).  Returns torch.topk's (values, indices) of the flattened scores."""
+
+    def __init__(self, starting_iteration: int, final_iteration: int) -> None:
+        super().__init__()
+        self.starting_iteration = starting_iteration
+        self.final_iteration = final_iteration
+        self.iterations = 0
+
+    def calc_v(self) -> float:
+        self.iterations += 1
+        if self.iterations <= self.starting_iteration:
+            return 1.
+        if self.iterations >= self.final_iteration:
+            return 0.5
+        progress = float(self.iterations - self.starting_iteration) / float(self.final_iteration - self.starting_iteration)
+        return 0.5 * (1. - progress) + 0.5
+
+    def forward(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        v = self.calc_v()
+        scores = input.reshape(-1)
+        return torch.topk(scores, k=max(1, int(scores.shape[0] * v)))

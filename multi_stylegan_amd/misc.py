@@ -13,6 +13,17 @@ def get_noise(batch_size: int, latent_dimension, p_mixed_noise: float = 0.9, dev
     return torch.randn(batch_size, latent_dimension, dtype=torch.float32, device=device)
 
 
+def random_permutation(n: int) -> torch.Tensor:
+    """Index vector for the wrongly-ordered-sequence augmentation (reference misc.py:202-213).  As in the reference the
+    n indices are drawn WITH replacement from numpy's global generator -- a time step may repeat -- and only the
+    identity is excluded: it is replaced by the reversed order."""
+    import numpy as np
+    permutation = torch.from_numpy(np.random.choice(range(n), size=n))
+    if torch.equal(permutation, torch.arange(n)):
+        permutation = torch.arange(n - 1, -1, -1)
+    return permutation
+
+
 @torch.no_grad()
 def exponential_moving_average(model_ema, model_train, decay: float = 0.999) -> None:
     """ema <- decay * ema + (1 - decay) * train over the named parameters, as ONE multi-tensor launch."""

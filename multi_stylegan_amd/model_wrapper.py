@@ -12,6 +12,8 @@ the device (the reference calls ``.item()`` ten times per iteration), fused mult
 """
 import copy
 import math
+import os
+import random
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Union
 
@@ -21,6 +23,7 @@ import torch.nn as nn
 from . import dist as msg_dist
 from . import loss, misc
 from .config import generation_hyperparameters
+from .u_net_2d_discriminator import generate_cut_mix_augmentation_data, generate_cut_mix_transformation_data
 
 
 @dataclass
@@ -36,10 +39,14 @@ class Draws:
     noise_g: Optional[List[torch.Tensor]] = None
     noise_pl: Optional[List[torch.Tensor]] = None
     pl_image_noise: Optional[torch.Tensor] = None
+    wrong_order_perm: Optional[torch.Tensor] = None       # replaces misc.random_permutation (reference :276)
+    cut_mix: Optional[bool] = None                        # replaces the random gate of the CutMix block (:331-332)
+    cut_mix_map_aug: Optional[torch.Tensor] = None        # replace the two random binary maps (:337, :357)
+    cut_mix_map_reg: Optional[torch.Tensor] = None
 
     def to(self, device):
         def mv(v):
-            if v is None or isinstance(v, int):
+            if v is None or isinstance(v, (int, bool)):
                 return v
             if isinstance(v, (list, tuple)):
                 return [mv(t) for t in v]
@@ -61,6 +68,8 @@ class ModelWrapper(object):
                  generator_loss: nn.Module = None, discriminator_loss: nn.Module = None,
                  discriminator_regularization_loss: nn.Module = None,
                  path_length_regularization: nn.Module = None, generator_ema: Optional[nn.Module] = None,
+                 trap_weights_map: Optional[torch.Tensor] = None,
+                 cut_mix_augmentation_loss: nn.Module = None, cut_mix_regularization_loss: nn.Module = None,
                  device: str = "cuda", lr_generator: float = 2e-4, lr_discriminator: float = 6e-4,
                  bucket_bytes: int = 32 << 20, overlap_communication: bool = True,
                  skip_discriminator_weight_grads_in_generator_step: bool = False,
@@ -74,6 +83,10 @@ class ModelWrapper(object):
         self.discriminator_regularization_loss = discriminator_regularization_loss or loss.R1Regularization()
         self.path_length_regularization = (path_length_regularization or loss.PathLengthRegularization()) \
             .to(self.device)
+        self.cut_mix_augmentation_loss = cut_mix_augmentation_loss or loss.NonSaturatingLogisticDiscriminatorLossCutMix()
+        self.cut_mix_regularization_loss = cut_mix_regularization_loss or nn.MSELoss(reduction="mean")
+        self.trap_weights_map = trap_weights_map
+        self.epoch, self.epochs = 0, 1           # the reference's schedule position (model_wrapper.py:138); see train()
         # identical replicas on every rank, then the EMA copy (reference :81-90)
         msg_dist.broadcast_module(self.generator)
         msg_dist.broadcast_module(self.discriminator)
@@ -164,19 +177,48 @@ class ModelWrapper(object):
         self.discriminator_reducer.zero_grad()
         self.generator_reducer.zero_grad()
 
+    def _top_k(self, top_k, prediction: torch.Tensor, prediction_pixel_wise: torch.Tensor):
+        """Reference :392-401.  Returns the kept scalar / pixel-wise predictions and the factor the (mean-reduced)
+        generator losses have to be multiplied with.  Single process: torch.topk of the batch, factor 1.  Data parallel:
+        the reference ranks the GATHERED batch (DataParallel computes the loss on device 0), so the k best of the global
+        batch are kept -- every rank keeps those of them that are its own, and since a rank's mean runs over its own
+        k_local kept samples while the ranks' gradients are averaged, its losses are weighted by k_local * world / k."""
+        if top_k is None or isinstance(top_k, nn.Identity):
+            return prediction, prediction_pixel_wise, 1.0
+        if msg_dist.collectives_active() and hasattr(top_k, "calc_v"):
+            index, factor = msg_dist.global_top_k(prediction.detach().reshape(-1), top_k.calc_v())
+            return prediction.reshape(-1)[index], prediction_pixel_wise[index], factor
+        output = top_k(prediction)
+        if isinstance(output, tuple):
+            return output[0], prediction_pixel_wise[output[1]], 1.0
+        return output, prediction_pixel_wise, 1.0
+
     # ------------------------------------------------------------------------------------------- one iteration
-    def train_iteration(self, real_images: torch.Tensor, draws: Optional[Draws] = None) -> None:
+    def train_iteration(self, real_images: torch.Tensor, draws: Optional[Draws] = None,
+                        resume_training: bool = False, top_k: Optional[nn.Module] = None) -> None:
+        """One pass of the reference's loop body (model_wrapper.py:253-451).  ``self.epoch`` / ``self.epochs`` and
+        ``resume_training`` switch on the late-training branches as the reference does: wrongly ordered reals among the
+        fakes (:272-277), the trap-region weight map on the pixel-wise losses (:289-291, :404-406), CutMix augmentation
+        and consistency regularisation (:331-376); ``top_k`` is the module of loss.py:398-444 (:392-401)."""
         hp = self.hyperparameters
         dr = draws or Draws()
         G, D = self.generator, self.discriminator
         self.iteration += 1
         real_images = real_images.to(self.device, non_blocking=True)
         batch = real_images.shape[0]
+        late = self.epoch >= hp["wrong_order_start"] * self.epochs or resume_training
+        weight = self.trap_weights_map if (hp["trap_weight"] * self.epochs <= self.epoch or resume_training) else None
         # ---------------- discriminator step (reference :258-305)
         self._zero()
         with torch.no_grad():
             z = dr.z_d if dr.z_d is not None else self._noise(batch)
             fake_images = G(input=z, inject_index=dr.inject_d, noise=dr.noise_d)
+            if late:            # a few real sequences with their time steps re-ordered count as fakes (:272-277)
+                perm = dr.wrong_order_perm if dr.wrong_order_perm is not None else \
+                    misc.random_permutation(real_images.shape[2])
+                count = max(1, int(hp["batch_factor_wrong_order"] * batch))
+                fake_images = torch.cat([fake_images.to(real_images.dtype),
+                                         real_images[:count].index_select(2, perm.to(real_images.device))], dim=0)
         self.discriminator_reducer.arm()
         if self.batch_discriminator_passes and real_images.shape == fake_images.shape:
             # D(real) and D(fake) of the reference (:272-275) as ONE batch of 2B with per-half minibatch statistics:
@@ -188,22 +230,53 @@ class ModelWrapper(object):
             real_prediction, real_prediction_pixel_wise = D(real_images, is_real=True, is_cut_mix=False)
             fake_prediction, fake_prediction_pixel_wise = D(fake_images, is_real=False, is_cut_mix=False)
         loss_real, loss_fake = self.discriminator_loss(real_prediction, fake_prediction)
-        loss_real_px, loss_fake_px = self.discriminator_loss(real_prediction_pixel_wise, fake_prediction_pixel_wise)
+        loss_real_px, loss_fake_px = self.discriminator_loss(real_prediction_pixel_wise, fake_prediction_pixel_wise,
+                                                             weight=weight)
         (loss_real + loss_fake + loss_real_px + loss_fake_px).backward()
         self._step(self.discriminator_reducer, self.discriminator_optimizer, "d")
         self._record(loss_discriminator_real=loss_real, loss_discriminator_fake=loss_fake,
                      loss_discriminator_real_pixel_wise=loss_real_px,
                      loss_discriminator_fake_pixel_wise=loss_fake_px)
         # ---------------- lazy R1 (reference :307-329)
+        real_for_cut_mix = real_images
         if self.iteration % hp["lazy_discriminator_regularization"] == 0:
             self._zero()
             real_rg = real_images.detach().requires_grad_(True)
             self.discriminator_reducer.arm()
+            # (the reference keeps requires_grad on the batch and overwrites the D step's real predictions here, :313-316:
+            # a CutMix block in the same iteration mixes THESE predictions)
             real_prediction, real_prediction_pixel_wise = D(real_rg, is_real=False, is_cut_mix=True)
             r1 = self.discriminator_regularization_loss(real_prediction, real_rg, real_prediction_pixel_wise)
             (hp["w_discriminator_regularization_r1"] * r1).backward()
             self._step(self.discriminator_reducer, self.discriminator_optimizer, "r1")
             self._record(loss_discriminator_regularization=r1)
+            real_for_cut_mix = real_rg
+        # ---------------- CutMix augmentation + consistency regularisation (reference :331-376)
+        if dr.cut_mix is not None:
+            do_cut_mix = dr.cut_mix
+        else:
+            do_cut_mix = (random.random() <= (0.5 / float(self.epochs)) * float(self.epoch)) or \
+                (resume_training and random.random() <= 0.5)
+        if do_cut_mix:
+            w_reg = hp["w_discriminator_regularization"]
+            self._zero()
+            images, label = generate_cut_mix_augmentation_data(real_for_cut_mix, fake_images, dr.cut_mix_map_aug)
+            self.discriminator_reducer.arm()
+            _, prediction = D(images, is_cut_mix=True)
+            cm_real, cm_fake = self.cut_mix_augmentation_loss(prediction, label)
+            (w_reg * (cm_real + cm_fake)).backward()
+            self._step(self.discriminator_reducer, self.discriminator_optimizer, "cm_aug")
+            self._record(loss_cut_mix_augmentation=cm_real + cm_fake)
+            self.discriminator_reducer.zero_grad()
+            images, label = generate_cut_mix_transformation_data(
+                real_for_cut_mix.detach(), fake_images.detach(), real_prediction_pixel_wise.detach(),
+                fake_prediction_pixel_wise.detach(), dr.cut_mix_map_reg)
+            self.discriminator_reducer.arm()
+            _, prediction = D(images, is_cut_mix=True)
+            cm_consistency = self.cut_mix_regularization_loss(prediction, label)
+            (w_reg * cm_consistency).backward()
+            self._step(self.discriminator_reducer, self.discriminator_optimizer, "cm_reg")
+            self._record(loss_cut_mix_regularization=cm_consistency)
         # ---------------- generator step (reference :377-416)
         self._zero()
         z = dr.z_g if dr.z_g is not None else self._noise(batch)
@@ -212,9 +285,11 @@ class ModelWrapper(object):
         self.generator_reducer.arm()
         fake_images = G(input=z, inject_index=dr.inject_g, noise=dr.noise_g)
         fake_prediction, fake_prediction_pixel_wise = D(fake_images, is_real=False, is_cut_mix=False)
+        fake_prediction, fake_prediction_pixel_wise, factor = self._top_k(top_k, fake_prediction,
+                                                                           fake_prediction_pixel_wise)
         loss_g = self.generator_loss(fake_prediction)
-        loss_g_px = self.generator_loss(fake_prediction_pixel_wise)
-        (loss_g + loss_g_px).backward()
+        loss_g_px = self.generator_loss(fake_prediction_pixel_wise, weight=weight)
+        ((loss_g + loss_g_px) * factor if factor != 1.0 else loss_g + loss_g_px).backward()
         if self.skip_d_wgrad:
             D.requires_grad_(True)
         self._step(self.generator_reducer, self.generator_optimizer, "g")
@@ -239,3 +314,109 @@ class ModelWrapper(object):
         if self.step_trace is not None:
             for n, p in self.generator_ema.named_parameters():
                 self.step_trace[f"ema.delta.{n}"] = p.detach() - ema_before[n]
+
+    # --------------------------------------------------------------------------------------------- epoch loop
+    def _gan_training(self, training_dataset, resume_training: bool = False,
+                      top_k: Optional[nn.Module] = None) -> None:
+        """One epoch: the reference's ``_gan_training`` (model_wrapper.py:245-451) over any iterable of real batches
+        ``[B, 2, 3, H, W]`` (host or device tensors; host batches are copied asynchronously)."""
+        for real_images in training_dataset:
+            self.train_iteration(real_images, resume_training=resume_training, top_k=top_k)
+
+    def train(self, training_dataset, epochs: int = 20, save_model_after_n_epochs: int = 5,
+              resume_training: bool = False, top_k: bool = False, checkpoint_directory: Optional[str] = None,
+              on_epoch_end=None) -> None:
+        """The reference's ``train`` (model_wrapper.py:104-195) restricted to the hot path: top-k schedule set-up
+        (:115-125), the epoch loop, a checkpoint in the reference's layout every ``save_model_after_n_epochs`` epochs
+        (:179-192, written by rank 0).  Sample dumps, metric validation and the process-title / progress-bar plumbing
+        are outside the scope; ``on_epoch_end(wrapper, epoch)`` is the hook for them."""
+        steps_per_epoch = len(training_dataset)
+        top_k_module: Optional[nn.Module] = None
+        if top_k:
+            hp = self.hyperparameters
+            top_k_module = loss.TopK(starting_iteration=int(hp["top_k_start"] * epochs * steps_per_epoch),
+                                     final_iteration=int(hp["top_k_finish"] * epochs * steps_per_epoch))
+            if resume_training:
+                top_k_module.starting_iteration, top_k_module.final_iteration = 0, 1
+        self.epochs = epochs
+        for self.epoch in range(epochs):
+            self.generator.train()
+            self.discriminator.train()
+            self._gan_training(training_dataset, resume_training=resume_training, top_k=top_k_module)
+            if on_epoch_end is not None:
+                on_epoch_end(self, self.epoch)
+            if checkpoint_directory is not None and (self.epoch + 1) % save_model_after_n_epochs == 0:
+                self.save_checkpoint(os.path.join(checkpoint_directory, f"checkpoint_{self.epoch + 1}.pt"))
+
+    # --------------------------------------------------------------------------------------------- checkpoints
+    def checkpoint_dict(self, data_parallel_prefix: bool = False) -> Dict[str, Any]:
+        """The reference's six checkpoint entries (model_wrapper.py:181-192).  ``path_length_regularization`` carries
+        the running path-length mean, which the reference loses (a plain attribute); the extra key
+        ``multi_stylegan_amd`` holds what else a resumed run needs (iteration counter, ADA state when the
+        discriminator is wrapped).  ``data_parallel_prefix=True`` writes the ``module.`` key prefix of a checkpoint
+        saved from ``nn.DataParallel`` models, for consumers that load into wrapped models (scripts/get_gan_samples.py:35)."""
+        def sd(module):
+            state = module.state_dict()
+            return {("module." + k if data_parallel_prefix else k): v for k, v in state.items()}
+        extra = {"iteration": self.iteration, "epoch": self.epoch}
+        ada = getattr(self.discriminator, "ada_state", None)
+        if callable(ada):
+            extra["ada"] = ada()
+        return {"generator_ema": sd(self.generator_ema), "generator": sd(self.generator),
+                "generator_optimizer": self.generator_optimizer.state_dict(),
+                "discriminator": sd(self.discriminator),
+                "discriminator_optimizer": self.discriminator_optimizer.state_dict(),
+                "path_length_regularization": self.path_length_regularization.state_dict(),
+                "multi_stylegan_amd": extra}
+
+    def save_checkpoint(self, path: str, data_parallel_prefix: bool = False) -> None:
+        """``Logger.save_checkpoint`` of the reference (misc.py:124-130): one ``torch.save`` of the dict; rank 0 only."""
+        if msg_dist.collectives_active() and torch.distributed.get_rank() != 0:
+            return
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(self.checkpoint_dict(data_parallel_prefix), path)
+
+    def load_checkpoint(self, checkpoint: Union[str, Dict[str, Any]]) -> None:
+        """Load a checkpoint written by ``save_checkpoint`` OR by the reference (train_multi_stylegan.py:74-90): the
+        ``module.`` prefix of DataParallel checkpoints and the ``discriminator.`` prefix of an ADA-wrapped reference
+        discriminator are stripped (or added, when this wrapper's discriminator is itself ADA-wrapped); a reference
+        checkpoint's empty ``path_length_regularization`` entry leaves the running mean at its current value."""
+        from . import conv_ops
+        if isinstance(checkpoint, str):
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        self.generator.load_state_dict(_match_keys(checkpoint["generator"], self.generator))
+        self.generator_ema.load_state_dict(_match_keys(checkpoint["generator_ema"], self.generator_ema))
+        self.discriminator.load_state_dict(_match_keys(checkpoint["discriminator"], self.discriminator))
+        self.generator_optimizer.load_state_dict(checkpoint["generator_optimizer"])
+        self.discriminator_optimizer.load_state_dict(checkpoint["discriminator_optimizer"])
+        pl_state = checkpoint.get("path_length_regularization") or {}
+        if "mean_path_length" in pl_state:
+            self.path_length_regularization.mean_path_length = \
+                pl_state["mean_path_length"].to(self.device, torch.float).reshape(1)
+        extra = checkpoint.get("multi_stylegan_amd", {})
+        self.iteration = int(extra.get("iteration", self.iteration))
+        if "ada" in extra and callable(getattr(self.discriminator, "load_ada_state", None)):
+            self.discriminator.load_ada_state(extra["ada"])
+        # load_state_dict copies into the parameters in place: kernel-side weight images cached so far are stale
+        conv_ops.invalidate_weight_cache()
+        # gradients live in the reducers' flat buckets; loading must not have detached them
+        self.generator_reducer.zero_grad()
+        self.discriminator_reducer.zero_grad()
+
+
+def _match_keys(state: Dict[str, torch.Tensor], module: nn.Module) -> Dict[str, torch.Tensor]:
+    """Rename checkpoint keys to the target module's: drop ``module.`` (nn.DataParallel) path components and a leading
+    ``discriminator.`` (the reference's ADA wrapper) that the target does not have; add the latter if only the target
+    has it."""
+    want = set(module.state_dict().keys())
+    wrapped = any(k.startswith("discriminator.") for k in want)
+    out = {}
+    for key, value in state.items():
+        name = ".".join(part for part in key.split(".") if part != "module")
+        if name not in want:
+            if name.startswith("discriminator.") and not wrapped:
+                name = name[len("discriminator."):]
+            elif wrapped and "discriminator." + name in want:
+                name = "discriminator." + name
+        out[name] = value
+    return out

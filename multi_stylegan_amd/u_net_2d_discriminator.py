@@ -4,7 +4,8 @@ state_dict keys.  Feature maps run channels-last (optionally bf16); the 6-channe
 heads' outputs stay fp32."""
 import math
 import os
-from typing import Any, Dict, List, Tuple
+import random
+from typing import Any, Dict, List, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -50,9 +51,6 @@ class Blur(nn.Module):
         return upfirdn2d(input, self.kernel, pad=self.padding)
 
 
-_MBSTD_GROUPS = [1]     # number of independent forward batches concatenated along dim 0 (set by Discriminator.forward)
-
-
 class MinibatchStdDev(nn.Module):
     """Appends one plane holding the mean (over c,h,w) of the per-position std over the batch; statistics in
     fp32.  The whole batch of ONE forward call is one group, as in the reference (:205-217); when the trainer runs the
@@ -62,9 +60,10 @@ class MinibatchStdDev(nn.Module):
     def __init__(self, alpha: float = 1e-8) -> None:
         super().__init__()
         self.alpha = alpha
+        self.groups = 1        # independent forward batches concatenated along dim 0 (set by Discriminator.forward)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        groups = _MBSTD_GROUPS[0]
+        groups = self.groups
         b, _, h, w = input.shape
         assert b % groups == 0
         x = input.float().reshape(groups, b // groups, *input.shape[1:])
@@ -193,11 +192,14 @@ class Discriminator(nn.Module):
         """minibatch_groups > 1: `input` is that many forward batches concatenated along dim 0 (the real and the fake
         batch of the discriminator step); everything is per-sample except the minibatch statistic, which is taken per
         group -- the result equals separate forward calls, at the launch count and tile efficiency of one."""
-        _MBSTD_GROUPS[0] = minibatch_groups
+        stats = [m for m in self.modules() if isinstance(m, MinibatchStdDev)] if minibatch_groups != 1 else []
+        for m in stats:
+            m.groups = minibatch_groups
         try:
             return self._forward(input)
         finally:
-            _MBSTD_GROUPS[0] = 1
+            for m in stats:
+                m.groups = 1
 
     def _forward(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         x = input.flatten(start_dim=1, end_dim=2)
@@ -226,3 +228,45 @@ class Discriminator(nn.Module):
             x = block(conv_ops.cat_channels([fir(mix(x)) if commute else up(x), skip]))
         pixel_wise = self.final_mapping(x).float().contiguous().unsqueeze(dim=2)
         return classification, pixel_wise
+
+
+# ---------------------------------------------------------------------------------------------------- CutMix
+# (reference u_net_2d_discriminator.py:384-448; used by ModelWrapper's late-training branch, model_wrapper.py:331-376)
+def _generate_binary_cut_mix_map(height: int, width: int, device: Union[str, torch.device] = "cpu") -> torch.Tensor:
+    """Random two-region binary map [1,1,1,H,W]: one corner rectangle against the rest, randomly inverted.  The random
+    draws are the reference's, in its order (two torch.randint on the CPU generator for the cut row / column, then two
+    random.random() for the corner and the inversion), so a seeded run reproduces the reference's maps; the map itself
+    is built on `device` from two comparisons instead of slice assignments."""
+    cut_row = int(torch.randint(int(0.1 * height), int(0.9 * height), size=(1,)))
+    cut_col = int(torch.randint(int(0.1 * width), int(0.9 * width), size=(1,)))
+    rows = torch.arange(height, device=device).view(height, 1)
+    cols = torch.arange(width, device=device).view(1, width)
+    lower_right = random.random() > 0.5
+    region = (rows >= cut_row) & (cols >= cut_col) if lower_right else (rows < cut_row) & (cols < cut_col)
+    binary_map = region.to(torch.float).view(1, 1, 1, height, width)
+    if random.random() > 0.5:
+        binary_map = 1. - binary_map
+    return binary_map
+
+
+def generate_cut_mix_augmentation_data(image_real: torch.Tensor, image_fake: torch.Tensor,
+                                       binary_map: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Mixed image (real where the map is 1, fake elsewhere) and the map as its per-pixel real/fake label.  The fake
+    batch may be longer than the real one (wrongly ordered reals appended); it is cut to the real batch's length."""
+    image_fake = image_fake[:image_real.shape[0]]
+    if binary_map is None:
+        binary_map = _generate_binary_cut_mix_map(image_real.shape[-2], image_fake.shape[-1], image_real.device)
+    keep = binary_map.to(image_real.dtype)
+    return image_real * keep + image_fake * (1. - keep), binary_map
+
+
+def generate_cut_mix_transformation_data(image_real: torch.Tensor, image_fake: torch.Tensor,
+                                         prediction_real: torch.Tensor, prediction_fake: torch.Tensor,
+                                         binary_map: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Mixed image and the equally mixed pixel-wise predictions (the soft target of the consistency term)."""
+    count = image_real.shape[0]
+    image_fake, prediction_fake = image_fake[:count], prediction_fake[:count]
+    if binary_map is None:
+        binary_map = _generate_binary_cut_mix_map(image_real.shape[-2], image_fake.shape[-1], image_real.device)
+    keep = binary_map.to(image_real.dtype)
+    return image_real * keep + image_fake * (1. - keep), prediction_real * keep + prediction_fake * (1. - keep)

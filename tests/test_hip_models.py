@@ -116,12 +116,14 @@ LOG_NAMES = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_disc
              "loss_d_fake_px": "loss_discriminator_fake_pixel_wise",
              "r1": "loss_discriminator_regularization", "loss_g": "loss_generator",
              "loss_g_px": "loss_generator_pixel_wise", "path_length": "path_length",
-             "loss_pl": "loss_path_length_regularization"}
+             "loss_pl": "loss_path_length_regularization", "cut_mix_aug": "loss_cut_mix_augmentation",
+             "cut_mix_reg": "loss_cut_mix_regularization"}
 # fp32 path on the GPU against the reference-driven golden run.  Pre-clip gradients: 1e-3 of each tensor's largest
 # element (north star); the R1 / path-length steps are second-order quantities through every kernel and get 3e-3.
 # Parameter movement: 2e-2 of the largest movement, on the elements whose gradient is above rounding noise (Adam
 # with beta1 = 0 turns noise-level gradients into +-lr).
-STEP_TOL = {"d": (1e-3, 1e-3, 2e-2), "g": (1e-3, 1e-3, 2e-2), "r1": (3e-3, 1e-3, 2e-2), "pl": (3e-3, 1e-3, 2e-2)}
+STEP_TOL = {"d": (1e-3, 1e-3, 2e-2), "g": (1e-3, 1e-3, 2e-2), "r1": (3e-3, 1e-3, 2e-2), "pl": (3e-3, 1e-3, 2e-2),
+            "cm_aug": (1e-3, 1e-3, 2e-2), "cm_reg": (1e-3, 1e-3, 2e-2)}
 
 
 def _golden_trainer(golden, **kw):
@@ -134,22 +136,23 @@ def _golden_trainer(golden, **kw):
 
 def _run_golden_iterations(golden, fused, prepare=None):
     import multi_stylegan_amd as m
-    from test_oracle_golden import load_train_draws, split_trace, step_traces
+    from test_oracle_golden import GOLDEN_ITERATIONS, STEP_LABELS, load_train_draws, split_trace, step_traces
     z, g, d, trainer = _golden_trainer(golden, fused_optimizer=fused)
     if prepare is not None:
         prepare(trainer)
     dead0 = g.main_convolutions_2[3].modulated_convolution.weight.detach().clone()
     report = {}
-    for step, iteration in enumerate((1, 16)):
+    top_k = m.loss.TopK(0, 1)                    # as resumed training sets it (model_wrapper.py:121-123): v = 0.5
+    for step, (iteration, late) in enumerate(GOLDEN_ITERATIONS):
         real, draws = load_train_draws(z, step, m.model_wrapper)
         trainer.iteration = iteration - 1
         trainer.step_trace = {}
-        trainer.train_iteration(real.to(DEV), draws.to(DEV))
+        trainer.train_iteration(real.to(DEV), draws.to(DEV), resume_training=late, top_k=top_k if late else None)
         log = trainer.pop_logs()
         pre = f"train.it{step}."
         want_steps, want_ema = step_traces(z, pre)
         got_steps, got_ema = split_trace(trainer.step_trace)
-        assert list(got_steps) == (["d", "g"] if iteration == 1 else ["d", "r1", "g", "pl"])
+        assert list(got_steps) == STEP_LABELS[iteration]
         for label, want in want_steps.items():
             tg, tn, td = STEP_TOL[label]
             st = check_step_trace(got_steps[label], want, tol_grad=tg, tol_norm=tn, tol_delta=td)
@@ -161,6 +164,8 @@ def _run_golden_iterations(golden, fused, prepare=None):
         for key in z.keys(pre + "log."):
             want, got = float(z[key]), log[LOG_NAMES[key[len(pre + "log."):]]][0]
             assert abs(got - want) <= TOL * abs(want), (key, got, want)
+        if late:
+            assert torch.equal(top_k(torch.zeros(4, 1))[1].cpu(), torch.tensor([0, 1]))      # the module kept counting
         gp, dp = dict(g.named_parameters()), dict(d.named_parameters())
         ep = dict(trainer.generator_ema.named_parameters())
         for key in z.keys(pre + "G."):
@@ -169,14 +174,15 @@ def _run_golden_iterations(golden, fused, prepare=None):
             assert rel_err(ep[key[len(pre + "Gema."):]], z[key]) < TOL, key
         for key in z.keys(pre + "D."):
             assert rel_err(dp[key[len(pre + "D."):]], z[key]) < TOL, key
-    assert rel_err(trainer.path_length_regularization.mean_path_length, z["train.it1.mean_path_length"]) < TOL
+    assert rel_err(trainer.path_length_regularization.mean_path_length, z["train.it2.mean_path_length"]) < TOL
     assert torch.equal(g.main_convolutions_2[3].modulated_convolution.weight.cpu(), dead0.cpu())
     return report
 
 
 @pytest.mark.parametrize("fused", [True, False])
 def test_train_iteration(golden, fused):
-    """ModelWrapper.train_iteration x2 (iterations 1 and 16 -> R1 and path length fire) vs the reference-driven
+    """ModelWrapper.train_iteration x3 (iterations 1, 16 -> R1 and path length fire -- and 32 with the late-training
+    branches: wrongly ordered reals among the fakes, CutMix augmentation + consistency, top-k) vs the reference-driven
     golden run: every loss, and every optimiser step WHOLE -- the pre-clip gradient of every parameter, the global
     gradient norm, the movement of every parameter (where its gradient is above rounding noise), the EMA movement
     from an EMA copy that starts away from the generator -- plus post-step parameters, the running path-length mean
@@ -255,6 +261,32 @@ def test_fused_step_equals_plain_clip_and_adam(golden):
         assert (n_plain > 5.0) == (gain > 1.0)
         for a, b in zip(d_fused, d_plain):       # movements of ~1e-3 on parameters of ~1: fp32 resolves them to ~2e-4
             assert rel_err(a, b) < 1e-3
+
+
+def test_checkpoint_reload_on_device(golden, tmp_path):
+    """save_checkpoint / load_checkpoint with the HIP modules: a second trainer that loads the file continues bit for bit
+    (parameters, optimiser moments, EMA, path-length mean; re-laid kernel-side weight images are rebuilt, gradients stay
+    in the flat buckets), and the file keeps the reference's six entries."""
+    import multi_stylegan_amd as m
+    from test_oracle_golden import load_train_draws
+    z, g, d, tr = _golden_trainer(golden)
+    real, draws = load_train_draws(z, 1, m.model_wrapper)
+    tr.iteration = 15
+    tr.train_iteration(real.to(DEV), draws.to(DEV))
+    path = str(tmp_path / "checkpoint_1.pt")
+    tr.save_checkpoint(path)
+    _, g2, d2, tr2 = _golden_trainer(golden)
+    with torch.no_grad():                                  # make sure stale weight images exist before loading
+        g2([z["train.it0.z_d.0"].to(DEV), z["train.it0.z_d.1"].to(DEV)], inject_index=2)
+    tr2.load_checkpoint(path)
+    real, draws = load_train_draws(z, 0, m.model_wrapper)
+    for t in (tr, tr2):
+        t.train_iteration(real.to(DEV), draws.to(DEV))
+    for (n, p), (_, q) in zip(list(g.named_parameters()) + list(d.named_parameters()),
+                              list(g2.named_parameters()) + list(d2.named_parameters())):
+        assert rel_err(q, p) < 1e-6, n                     # float atomics in the weight-gradient kernels: not bitwise
+    for (n, p), (_, q) in zip(tr.generator_ema.named_parameters(), tr2.generator_ema.named_parameters()):
+        assert rel_err(q, p) < 1e-6, n
 
 
 def test_config1_64px_matches_oracle():

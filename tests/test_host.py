@@ -181,3 +181,167 @@ def test_non_square_conv_geometry_is_refused():
     for bad in ((1, 2), (2, 1), (1, 1, 1)):
         with pytest.raises(_lib.MsgHipError, match="square"):
             conv_ops._square(bad, "stride")
+
+
+# ------------------------------------------------------------------------------ trainer surface, host logic
+def _cpu_trainer(golden, **kw):
+    """The product's ModelWrapper driving the CPU oracle's modules: the trainer's control flow (step order, zeroing,
+    late-training branches, top-k, clipping, EMA, checkpoints) is device-agnostic and is checked here without a GPU;
+    the same iterations run on the HIP modules in tests/test_hip_models.py."""
+    import copy
+    from multi_stylegan_amd.model_wrapper import ModelWrapper
+    from oracle import models as om
+    from tools.gen_golden import TINY_D, TINY_G
+    z = golden("train_step")
+    g, d = om.Generator(TINY_G), om.Discriminator(TINY_D, no_rfp=True)
+    g.load_state_dict(z.state_dict("train.G0.")); d.load_state_dict(z.state_dict("train.D0."))
+    ema = copy.deepcopy(g)
+    ema.load_state_dict(z.state_dict("train.Gema0."))
+    for mod in (g, ema):
+        mod.live_parameters = lambda mod=mod: [p for n, p in mod.named_parameters()
+                                               if not n.startswith("main_convolutions_2.")]
+    orig_forward = g.forward
+
+    def forward(*a, path_length_noise=None, **k):            # the oracle draws the image noise inside (generator.py:195)
+        if path_length_noise is None:
+            return orig_forward(*a, **k)
+        from oracle.train import _pl_grads
+        k.pop("return_path_length_grads")
+        return _pl_grads(g, k.pop("input"), k.pop("inject_index"), k.pop("noise"), path_length_noise)
+    g.forward = forward
+    return z, g, d, ModelWrapper(g, d, generator_ema=ema, device="cpu", **kw)
+
+
+def test_trainer_three_golden_iterations_on_cpu(golden):
+    """ModelWrapper.train_iteration (host logic) against the reference-driven golden run, iteration 32 included: wrongly
+    ordered reals, CutMix augmentation + consistency, top-k with v = 0.5 -- every optimiser step whole."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import check_step_trace
+    from multi_stylegan_amd import loss, model_wrapper
+    from test_oracle_golden import GOLDEN_ITERATIONS, STEP_LABELS, load_train_draws, split_trace, step_traces
+    z, g, d, tr = _cpu_trainer(golden)
+    top_k = loss.TopK(0, 1)
+    names = {"cut_mix_aug": "loss_cut_mix_augmentation", "cut_mix_reg": "loss_cut_mix_regularization",
+             "loss_g": "loss_generator", "r1": "loss_discriminator_regularization", "loss_pl": "loss_path_length_regularization"}
+    for step, (iteration, late) in enumerate(GOLDEN_ITERATIONS):
+        real, draws = load_train_draws(z, step, model_wrapper)
+        tr.iteration = iteration - 1
+        tr.step_trace = {}
+        tr.train_iteration(real, draws, resume_training=late, top_k=top_k if late else None)
+        log = tr.pop_logs()
+        pre = f"train.it{step}."
+        want_steps, want_ema = step_traces(z, pre)
+        got_steps, got_ema = split_trace(tr.step_trace)
+        assert list(got_steps) == STEP_LABELS[iteration]
+        for label, want in want_steps.items():
+            st = check_step_trace(got_steps[label], want, tol_grad=5e-4, tol_norm=1e-4, tol_delta=2e-3)
+            assert st["compared"] > 0.2 * st["total"], (label, st)
+        for n, want in want_ema.items():
+            assert rel_err(got_ema[n], want) < 2e-3, n
+        for short, long in names.items():
+            if z.keys(pre + "log." + short):
+                want = float(z[pre + "log." + short])
+                assert abs(log[long][0] - want) <= 2e-4 * abs(want), (short, log[long][0], want)
+
+
+def test_checkpoint_round_trip_and_reference_layout(golden, tmp_path):
+    """save_checkpoint writes the reference's six entries (model_wrapper.py:181-192); load_checkpoint restores a run
+    exactly, and also accepts the reference's own layouts: DataParallel `module.` prefixes, the ADA wrapper's
+    `discriminator.` prefix, an empty path-length entry."""
+    from multi_stylegan_amd import model_wrapper
+    from test_oracle_golden import load_train_draws
+    z, g, d, tr = _cpu_trainer(golden)
+    real, draws = load_train_draws(z, 1, model_wrapper)
+    tr.iteration = 15
+    tr.train_iteration(real, draws)                           # both regularisers fire: optimiser state, PL mean
+    path = str(tmp_path / "models" / "checkpoint_5.pt")
+    tr.save_checkpoint(path)
+    ck = torch.load(path, weights_only=False)
+    assert list(ck)[:6] == ["generator_ema", "generator", "generator_optimizer", "discriminator",
+                            "discriminator_optimizer", "path_length_regularization"]
+    assert float(ck["path_length_regularization"]["mean_path_length"]) == float(tr.path_length_regularization.mean_path_length)
+    _, g2, d2, tr2 = _cpu_trainer(golden)
+    tr2.load_checkpoint(path)
+    assert tr2.iteration == 16
+    for a, b in ((g, g2), (d, d2), (tr.generator_ema, tr2.generator_ema)):
+        for (n, p), (_, q) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert torch.equal(p, q), n
+    assert torch.equal(tr.path_length_regularization.mean_path_length, tr2.path_length_regularization.mean_path_length)
+    # the resumed run continues identically (optimiser moments restored, gradients still inside the flat buckets)
+    real, draws = load_train_draws(z, 0, model_wrapper)
+    for t in (tr, tr2):
+        t.train_iteration(real, draws)
+    for p, q in zip(list(g.parameters()) + list(d.parameters()), list(g2.parameters()) + list(d2.parameters())):
+        assert torch.equal(p, q)
+    assert all(p.grad.data_ptr() >= b.flat.data_ptr() for b in tr2.generator_reducer.buckets for p in b.params)
+    # reference layouts
+    ref = {"generator": {"module." + k: v for k, v in ck["generator"].items()},
+           "generator_ema": {"module." + k: v for k, v in ck["generator_ema"].items()},
+           "discriminator": {"discriminator.module." + k: v for k, v in ck["discriminator"].items()},
+           "generator_optimizer": ck["generator_optimizer"], "discriminator_optimizer": ck["discriminator_optimizer"],
+           "path_length_regularization": {}}
+    _, g3, d3, tr3 = _cpu_trainer(golden)
+    tr3.path_length_regularization.mean_path_length = torch.tensor([0.25])
+    tr3.load_checkpoint(ref)
+    assert float(tr3.path_length_regularization.mean_path_length) == 0.25
+    for n, q in d3.state_dict().items():
+        assert torch.equal(ck["discriminator"][n], q), n
+    for n, q in tr3.generator_ema.state_dict().items():
+        assert torch.equal(ck["generator_ema"][n], q), n
+    wrapped = tr.checkpoint_dict(data_parallel_prefix=True)
+    assert all(k.startswith("module.") for k in wrapped["generator_ema"])
+
+
+def test_train_loop_schedules(golden, tmp_path):
+    """train(): top-k marks from the epoch / dataset length (model_wrapper.py:115-125), the wrong-order switch at
+    3/4 of the epochs, checkpoints every n epochs."""
+    z, g, d, tr = _cpu_trainer(golden)
+    seen = []
+    tr.train_iteration = lambda real, draws=None, resume_training=False, top_k=None: seen.append(
+        (tr.epoch, tr.epoch >= tr.hyperparameters["wrong_order_start"] * tr.epochs, resume_training,
+         None if top_k is None else (top_k.starting_iteration, top_k.final_iteration)))
+    data = [torch.zeros(2, 2, 3, 32, 32)] * 3
+    tr.train(data, epochs=4, save_model_after_n_epochs=2, top_k=True, checkpoint_directory=str(tmp_path))
+    assert len(seen) == 12 and seen[0] == (0, False, False, (3, 9)) and seen[-1] == (3, True, False, (3, 9))
+    assert sorted(os.listdir(tmp_path)) == ["checkpoint_2.pt", "checkpoint_4.pt"]
+    seen.clear()
+    tr.train(data, epochs=1, resume_training=True, top_k=True)
+    assert seen[0][2:] == (True, (0, 1))
+
+
+def _topk_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multi_stylegan_amd import dist as msg_dist
+    torch.manual_seed(7)
+    everything = torch.randn(world, 6)
+    everything[1] -= 5.0 * (world > 1)                      # rank 1 mostly loses ...
+    for v, case in ((0.5, everything), (0.5, everything * torch.tensor([[1.0], [0.0]]) + torch.tensor([[0.0], [-9.0]])),
+                    (1.0, everything), (0.01, everything)):
+        index, factor = msg_dist.global_top_k(case[rank], v)
+        k = max(1, int(case.numel() * v))
+        kept = torch.topk(case.reshape(-1), k).indices
+        mine = sorted((kept[(kept >= rank * 6) & (kept < rank * 6 + 6)] - rank * 6).tolist())
+        if mine:
+            assert sorted(index.tolist()) == mine and abs(factor - len(mine) * world / k) < 1e-12
+        else:
+            assert index.tolist() == [0] and factor == 0.0    # ... and sometimes keeps nothing at all
+        # the ranks' averaged weighted means equal the mean over the global k best
+        local = case[rank][index].mean() * factor
+        total = local.clone()
+        dist.all_reduce(total)
+        assert abs(total.item() / world - case.reshape(-1)[kept].mean().item()) < 1e-6
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_global_top_k_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 300
+    procs = [ctx.Process(target=_topk_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == "ok"

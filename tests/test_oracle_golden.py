@@ -152,25 +152,38 @@ def test_state_dict_manifest():
     assert sum(p.numel() for p in d.parameters()) == man["discriminator_params"] == 50855682
 
 
+GOLDEN_ITERATIONS = ((1, False), (16, False), (32, True))      # (iteration, late-training branches on)
+STEP_LABELS = {1: ["d", "g"], 16: ["d", "r1", "g", "pl"], 32: ["d", "r1", "cm_aug", "cm_reg", "g", "pl"]}
+
+
 def load_train_draws(z, step, ot_mod=ot):
     pre = f"train.it{step}."
     def lst(key):
         return [z[k] for k in sorted(z.keys(pre + key + "."), key=lambda s: int(s.rsplit(".", 1)[1]))]
     zg = lst("z_g")
+    late = bool(z.keys(pre + "wrong_order_perm"))
+    extra = dict(wrong_order_perm=z[pre + "wrong_order_perm"], cut_mix=True, cut_mix_map_aug=z[pre + "cut_mix_map_aug"],
+                 cut_mix_map_reg=z[pre + "cut_mix_map_reg"]) if late else dict(cut_mix=False)
     return z[pre + "real"], ot_mod.Draws(
         z_d=lst("z_d"), inject_d=2, noise_d=lst("noise_d"), z_g=zg[0] if len(zg) == 1 else zg, noise_g=lst("noise_g"),
-        z_pl=lst("z_pl"), inject_pl=4, noise_pl=lst("noise_pl"), pl_image_noise=z[pre + "pl_image_noise"])
+        z_pl=lst("z_pl"), inject_pl=4, noise_pl=lst("noise_pl"), pl_image_noise=z[pre + "pl_image_noise"], **extra)
 
 
 def step_traces(z, pre):
-    """{label: {"grad.<p>", "delta.<p>", "gnorm"}} of one golden iteration, plus the EMA movement."""
+    """{label: {"grad.<p>", "delta.<p>", "gnorm"}} of one golden iteration, plus the EMA movement.  Movements are
+    stored as fp16 fractions of the tensor's largest one (`dscale.<p>`)."""
     steps, ema = {}, {}
     for key in z.keys(pre + "step."):
         label, rest = key[len(pre + "step."):].split(".", 1)
+        if rest.startswith("dscale."):
+            continue
+        value = z[key]
+        if rest.startswith("delta."):
+            value = value.double() * float(z[pre + "step." + label + ".dscale." + rest[len("delta."):]])
         if label == "ema":
-            ema[rest[len("delta."):]] = z[key]
+            ema[rest[len("delta."):]] = value
         else:
-            steps.setdefault(label, {})[rest] = z[key]
+            steps.setdefault(label, {})[rest] = value
     return steps, ema
 
 
@@ -186,9 +199,10 @@ def split_trace(trace):
 
 
 def test_train_iteration(golden):
-    """Two iterations (1 and 16): losses, R1, path length, and EVERY optimiser step whole -- pre-clip gradients of all
+    """Three iterations (1, 16, and 32 with the late-training branches: wrongly ordered reals, CutMix augmentation +
+    consistency, top-k): losses, R1, path length, and EVERY optimiser step whole -- pre-clip gradients of all
     parameters, the global norm, the parameter movement where the gradient is above rounding noise -- plus the EMA
-    movement from an EMA copy that starts away from the generator (SURVEY 8a-a8)."""
+    movement from an EMA copy that starts away from the generator (SURVEY 8a-a8, 8f-3)."""
     import copy
     from tools.gen_golden import TINY_D, TINY_G
     z = golden("train_step")
@@ -199,17 +213,19 @@ def test_train_iteration(golden):
     g_ema.load_state_dict(z.state_dict("train.Gema0."))
     og, od = ot.make_optimizers(g, d)
     pl = ot.PathLength()
-    for step, iteration in enumerate((1, 16)):
+    top_k = ot.TopK(0, 1)                        # as resumed training sets it (model_wrapper.py:121-123): v = 0.5
+    for step, (iteration, late) in enumerate(GOLDEN_ITERATIONS):
         real, draws = load_train_draws(z, step)
         trace = {}
-        log = ot.train_iteration(g, d, g_ema, og, od, pl, real, iteration, draws, trace=trace)
+        log = ot.train_iteration(g, d, g_ema, og, od, pl, real, iteration, draws, trace=trace,
+                                 resume_training=late, top_k=top_k if late else None)
         pre = f"train.it{step}."
         for key in z.keys(pre + "log."):
             want = float(z[key])
             assert abs(log[key[len(pre + "log."):]] - want) <= 2e-4 * abs(want), key
         want_steps, want_ema = step_traces(z, pre)
         got_steps, got_ema = split_trace(trace)
-        assert list(got_steps) == (["d", "g"] if iteration == 1 else ["d", "r1", "g", "pl"])
+        assert list(got_steps) == STEP_LABELS[iteration] and sorted(want_steps) == sorted(got_steps)
         for label, want in want_steps.items():
             st = check_step_trace(got_steps[label], want, tol_grad=5e-4, tol_norm=1e-4, tol_delta=2e-3)
             assert st["compared"] > 0.2 * st["total"], (label, st)
@@ -222,7 +238,7 @@ def test_train_iteration(golden):
             assert rel_err(ep[key[len(pre + "Gema."):]], z[key]) < 1e-4, key
         for key in z.keys(pre + "D."):
             assert rel_err(dp[key[len(pre + "D."):]], z[key]) < 1e-4, key
-    assert rel_err(pl.mean_path_length, z["train.it1.mean_path_length"]) < 1e-4
+    assert rel_err(pl.mean_path_length, z["train.it2.mean_path_length"]) < 1e-4
     assert torch.equal(g.main_convolutions_2[3].modulated_convolution.weight, dead0)   # dead branch untouched
 
 
@@ -249,3 +265,39 @@ def test_step_trace_check_bites(golden):
         check_step_trace(unclipped, want, 5e-4, 1e-4, 2e-3)
     some = next(iter(ema))
     assert rel_err(ema[some] * 0.0, ema[some]) > 0.5 and rel_err(ema[some] * 2.0, ema[some]) > 0.5
+
+
+def test_cut_mix_maps_and_wrong_order_draws_are_pinned(golden):
+    """The RNG-consuming helpers: with the seeds stored beside the fixtures the oracle's binary CutMix map
+    (u_net_2d_discriminator.py:425-448) and its 'permutation' (misc.py:202-213) reproduce what the reference's own
+    functions drew when the fixtures were generated."""
+    import random
+    import numpy as np
+    z = golden("train_step")
+    seeds = [int(v) for v in z["train.it2.cut_mix_seeds"]]
+    for seed, key in zip(seeds, ("cut_mix_map_aug", "cut_mix_map_reg")):
+        torch.manual_seed(seed); random.seed(seed)
+        assert torch.equal(ot.binary_cut_mix_map(32, 32), z["train.it2." + key])
+    np.random.seed(302)
+    assert torch.equal(ot.random_permutation(3), z["train.it2.wrong_order_perm"])
+    # the identity draw is replaced by the reversal
+    class _Fixed:
+        @staticmethod
+        def choice(r, size):
+            return np.arange(size)
+    orig, np.random.choice = np.random.choice, _Fixed.choice
+    try:
+        assert ot.random_permutation(4).tolist() == [3, 2, 1, 0]
+    finally:
+        np.random.choice = orig
+
+
+def test_top_k_schedule():
+    """loss.py:413-428: v = 1 up to the start mark, 0.5 from the final mark on, linear in between; k = max(1, int(B v))."""
+    tk = ot.TopK(starting_iteration=2, final_iteration=6)
+    vs = [tk.calc_v() for _ in range(8)]
+    assert vs == [1.0, 1.0, 0.875, 0.75, 0.625, 0.5, 0.5, 0.5]
+    tk = ot.TopK(0, 1)
+    vals, idx = tk(torch.tensor([[0.3], [-1.0], [2.0], [0.1], [0.2]]))
+    assert idx.tolist() == [2, 0] and vals.tolist() == [2.0, 0.30000001192092896]
+    assert ot.TopK(0, 1)(torch.tensor([[1.0]]))[1].tolist() == [0]          # k never drops below 1

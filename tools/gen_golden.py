@@ -13,7 +13,8 @@ torchvision/kornia/rtpt which are not installed.  So
     ``upfirdn2d_native`` (same 10-argument signature, op_static/upfirdn2d.py:156),
   * ``fused_act_cuda.fused_bias_act`` is a three-line torch statement of
     fused_bias_act_kernel.cu:26-47 (the only arithmetic of the path that cannot be
-    executed from the reference's own code here).
+    executed from the reference's own code here),
+  * ``torchvision`` (imported by misc.py for image dumps only) is an empty module.
 While generating, every vector is also compared with ``oracle/`` and the script
 fails if the restatement disagrees.
 
@@ -53,8 +54,11 @@ def import_reference():
 
     act_mod.fused_bias_act = fused_bias_act
     up_mod.upfirdn2d = lambda *a: sys.modules["multi_stylegan.op_static.upfirdn2d"].upfirdn2d_native(*a)
+    # misc.py imports torchvision (absent here) for Logger.save_prediction only; an empty module lets the hot-path
+    # helpers random_permutation / get_noise / exponential_moving_average be taken from the reference itself
+    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
     names = ["op_static.upfirdn2d", "op_static.fused_act", "equalized_layer", "multi_stylegan_generator",
-             "u_net_2d_discriminator", "loss", "config"]
+             "u_net_2d_discriminator", "loss", "config", "misc"]
     return {n.split(".")[-1]: importlib.import_module("multi_stylegan." + n) for n in names}
 
 
@@ -391,7 +395,12 @@ def gen_train_step(ref, om, ot, store):
         for n, p in named:
             trace[f"{label}.delta.{n}"] = p.detach() - before[n]
 
-    for step, iteration in enumerate((1, 16)):
+    M, U = ref["misc"], ref["u_net_2d_discriminator"]
+    top_k_ref, top_k_or = L.TopK(starting_iteration=0, final_iteration=1), ot.TopK(0, 1)
+    cm_loss = L.NonSaturatingLogisticDiscriminatorLossCutMix()
+    # third iteration: the late-training branches, as `--resume_training` switches them on (model_wrapper.py:121-123,
+    # 272, 331-332): wrongly ordered reals among the fakes, CutMix augmentation + consistency, top-k with v = 0.5
+    for step, (iteration, late) in enumerate(((1, False), (16, False), (32, True))):
         real = torch.rand(bsz, 2, 3, 32, 32, generator=g)
         dr = ot.Draws(
             z_d=[torch.randn(bsz, 16, generator=g) for _ in range(2)], inject_d=2, noise_d=fixed_noise(g, 3, bsz),
@@ -410,6 +419,14 @@ def gen_train_step(ref, om, ot, store):
         od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
         with torch.no_grad():
             fake = gen(input=dr.z_d, inject_index=dr.inject_d, noise=dr.noise_d)
+        if late:
+            np.random.seed(300 + step)
+            perm = M.random_permutation(real.shape[2])
+            np.random.seed(300 + step)
+            assert torch.equal(ot.random_permutation(real.shape[2]), perm)
+            dr.wrong_order_perm = perm
+            store[pre + "wrong_order_perm"] = npy(perm)
+            fake = torch.cat([fake, real[:max(1, int(hp["batch_factor_wrong_order"] * real.shape[0])), :, perm]], dim=0)
         pr, prp = dis(real, is_real=True, is_cut_mix=False)
         pf, pfp = dis(fake, is_real=False, is_cut_mix=False)
         lr_, lf = d_loss(pr, pf); lrp, lfp = d_loss(prp, pfp)
@@ -419,14 +436,53 @@ def gen_train_step(ref, om, ot, store):
         if iteration % hp["lazy_discriminator_regularization"] == 0:
             od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
             rr = real.clone().requires_grad_(True)
-            pr, prp = dis(rr)
+            pr, prp = dis(rr)                       # overwrites the D step's real predictions, as the reference does
             r1 = r1_loss(pr, rr, prp)
             (hp["w_discriminator_regularization_r1"] * r1).backward()
             clip_step(dis, od, trace, "r1")
             log["r1"] = r1.item()
+        if late:                                    # model_wrapper.py:331-376
+            import random as pyrandom
+            real_cm = rr if iteration % hp["lazy_discriminator_regularization"] == 0 else real
+
+            def seeded(fn, seed):                   # the map generators draw from torch's CPU RNG and Python's
+                state = torch.get_rng_state()
+                torch.manual_seed(seed); pyrandom.seed(seed)
+                out = fn()
+                torch.set_rng_state(state)
+                return out
+            od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
+            cm_images, cm_label = seeded(lambda: U.generate_cut_mix_augmentation_data(real_cm, fake), 400 + step)
+            map_aug = seeded(lambda: U._generate_binary_cut_mix_map(32, 32), 400 + step)
+            assert torch.equal(map_aug, cm_label)
+            assert torch.equal(seeded(lambda: ot.binary_cut_mix_map(32, 32), 400 + step), map_aug)
+            _, cm_pred = dis(cm_images, is_cut_mix=True)
+            cm_r, cm_f = cm_loss(cm_pred, cm_label)
+            (hp["w_discriminator_regularization"] * (cm_r + cm_f)).backward()
+            clip_step(dis, od, trace, "cm_aug")
+            log["cut_mix_aug"] = (cm_r + cm_f).item()
+            od.zero_grad(set_to_none=False)
+            cr_images, cr_label = seeded(lambda: U.generate_cut_mix_transformation_data(
+                real_cm.detach(), fake.detach(), prp.detach(), pfp.detach()), 500 + step)
+            map_reg = seeded(lambda: U._generate_binary_cut_mix_map(32, 32), 500 + step)
+            assert torch.equal(cr_images, real_cm.detach() * map_reg + fake.detach()[:bsz] * (1. - map_reg))
+            _, cr_pred = dis(cr_images, is_cut_mix=True)
+            cr = torch.nn.functional.mse_loss(cr_pred, cr_label, reduction="mean")
+            (hp["w_discriminator_regularization"] * cr).backward()
+            clip_step(dis, od, trace, "cm_reg")
+            log["cut_mix_reg"] = cr.item()
+            dr.cut_mix, dr.cut_mix_map_aug, dr.cut_mix_map_reg = True, map_aug, map_reg
+            store[pre + "cut_mix_map_aug"], store[pre + "cut_mix_map_reg"] = npy(map_aug), npy(map_reg)
+            store[pre + "cut_mix_seeds"] = np.array([400 + step, 500 + step])
+        else:
+            dr.cut_mix = False
         od.zero_grad(set_to_none=False); og.zero_grad(set_to_none=False)
         fake = gen(input=dr.z_g, noise=dr.noise_g)
         pf, pfp = dis(fake)
+        if late:                                    # model_wrapper.py:392-401 with the resumed TopK(0, 1): v = 0.5
+            pf, indexes = top_k_ref(pf)
+            pfp = pfp[indexes]
+            store[pre + "top_k_indexes"] = npy(indexes)
         lg, lgp = g_loss(pf), g_loss(pfp)
         (lg + lgp).backward()
         clip_step(gen, og, trace, "g")
@@ -449,7 +505,8 @@ def gen_train_step(ref, om, ot, store):
                 trace["ema.delta." + n] = p.detach() - before
         # ---- oracle
         otrace = {}
-        olog = ot.train_iteration(ogen, odis, ogen_ema, oog, ood, pl_or, real, iteration, dr, trace=otrace)
+        olog = ot.train_iteration(ogen, odis, ogen_ema, oog, ood, pl_or, real, iteration, dr, trace=otrace,
+                                  resume_training=late, top_k=top_k_or if late else None)
         for k, v in log.items():
             assert abs(olog[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, olog[k], v)
             store[pre + "log." + k] = np.array(v)
@@ -464,7 +521,12 @@ def gen_train_step(ref, om, ot, store):
                 mask = trace[gk].abs() > 0.05 * trace[gk].abs().max()
                 err = ((otrace[k] - v).abs() * mask).max().item() / scale
             assert err <= (2e-3 if kind == "delta" else 5e-4), f"oracle != reference for {pre}{k}: {err:.3e}"
-            store[pre + "step." + k] = npy(v)
+            if kind == "delta":          # movements: fp16 relative to the tensor's largest (5e-4 of it), 40 % of the file
+                top = max(v.abs().max().item(), 1e-30)
+                store[pre + "step." + k] = npy(v / top).astype(np.float16)
+                store[pre + "step." + k.replace(".delta.", ".dscale.", 1)] = np.array(top, dtype=np.float64)
+            else:
+                store[pre + "step." + k] = npy(v)
         watch_g = ["style_mapping.layers.1.weight", "main_convolutions_1.5.modulated_convolution.weight",
                    "main_convolutions_1.2.modulated_convolution.modulation_mapping.bias",
                    "main_convolutions_2.3.modulated_convolution.weight", "output_blocks_2.0.modulated_convolution.weight"]

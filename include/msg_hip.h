@@ -204,6 +204,28 @@ int msg_softmax_rows(const void* x, void* y, int dtype, long long rows, int cols
 int msg_softmax_rows_backward(const void* y, const void* gy, void* gx, int dtype, long long rows, int cols,
                               void* stream);
 
+/* ---------------------------------------------------------------------------
+ * a6 / 8f-1  fused attention of the NonLocalBlock -- replaces the torch.bmm -> F.softmax -> torch.bmm sequence of
+ *     multi_stylegan/u_net_2d_discriminator.py:376-380 (beta = softmax(theta^T phi), o = g beta^T) without the
+ *     [B, Nq, Nk] attention map ever reaching HBM.
+ * q  [B, Nq, dk]  theta(x), one row per query pixel        k  [B, Nk, dk]  max-pooled phi(x), one row per key pixel
+ * v  [B, Nk, dv]  max-pooled g(x)                           vt [B, dv, Nk]  its transpose (the caller provides both
+ * orientations of the operands whose contraction index would otherwise be strided: qt [B,dk,Nq], kt [B,dk,Nk],
+ * dOt [B,dv,Nq]); all dense, in the storage type.
+ * forward:  o [B, Nq, dv] = softmax_rows(q k^T) v,  lse [B, Nq] fp32 = log sum_j exp(q_i . k_j)  (kept for backward)
+ * backward: given dO [B, Nq, dv] and delta [B, Nq] fp32 = sum_d dO * o:  dq, dk_out, dv_out  (probabilities are
+ *           recomputed from q, k and lse; two kernels, no atomics: results are deterministic).
+ * Supported: (dk, dv) = (48, 192) -- the reference's 384-channel blocks -- and (16, 64); Nq, Nk multiples of 128;
+ * MSG_BF16 (bf16 MFMA, fp32 accumulate / softmax) and MSG_F32 (exact-fp32 MFMA).  Anything else:
+ * MSG_EUNSUPPORTED (msg_nonlocal_attention_supported tells beforehand). */
+int msg_nonlocal_attention_supported(int B, int Nq, int Nk, int dk, int dv);
+int msg_nonlocal_attention_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int dtype,
+                               int B, int Nq, int Nk, int dk, int dv, void* stream);
+int msg_nonlocal_attention_bwd(const void* q, const void* qt, const void* k, const void* kt, const void* v,
+                               const void* dO, const void* dOt, const float* lse, const float* delta,
+                               void* dq, void* dk_out, void* dv_out, int dtype,
+                               int B, int Nq, int Nk, int dk, int dv, void* stream);
+
 /* msg_conv2d_fprop with the activation stage of the layer fused into the epilogue:
  *   y = leaky_relu(conv(x, w) + noise_weight[0] * noise[b or 0, pixel] + act_bias[n], alpha) * scale
  * i.e. EqualizedConv2d -> FusedLeakyReLU (u_net_2d_discriminator.py:160-171) and ModulatedConv2d -> NoiseInjection ->

@@ -2,9 +2,12 @@
 reference's nn.Module / op_static API).  See DESIGN.md.  Public names follow multi_stylegan/__init__.py."""
 from .config import (generation_hyperparameters, multi_style_gan_generator_config,
                      u_net_2d_discriminator_config)
+from .inference import GeneratorSampler, load_generator_ema, split_sequences, validation_samples
+from .loss import PathLengthRegularization, TopK
 from .model_wrapper import Draws, ModelWrapper
 from .multi_stylegan_generator import Generator as MultiStyleGANGenerator
 from .u_net_2d_discriminator import Discriminator as MultiStyleGANDiscriminator
 
-__all__ = ["MultiStyleGANGenerator", "MultiStyleGANDiscriminator", "ModelWrapper", "Draws",
+__all__ = ["MultiStyleGANGenerator", "MultiStyleGANDiscriminator", "ModelWrapper", "Draws", "PathLengthRegularization",
+           "TopK", "GeneratorSampler", "load_generator_ema", "split_sequences", "validation_samples",
            "multi_style_gan_generator_config", "u_net_2d_discriminator_config", "generation_hyperparameters"]

@@ -2,5 +2,6 @@
 from .fused_act import FusedLeakyReLU, fused_leaky_relu, fused_bias_noise_leaky_relu, scaled_add, scaled_add_fork
 from .upfirdn2d import upfirdn2d, blur_bias_act
 from .softmax import softmax_rows
+from .attention import non_local_attention
 
-__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "fused_bias_noise_leaky_relu", "scaled_add", "scaled_add_fork", "upfirdn2d", "blur_bias_act", "softmax_rows"]
+__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "fused_bias_noise_leaky_relu", "scaled_add", "scaled_add_fork", "upfirdn2d", "blur_bias_act", "softmax_rows", "non_local_attention"]

@@ -76,7 +76,7 @@ def _launch(x, fir, up, down, pad):
     if pitch is not None:
         major, minor = b, c
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        key = f"upfirdn2d/{_DT_NAME[x.dtype]}/up{up_x}down{down_x}/vec"
+        key = f"upfirdn2d/{_DT_NAME.get(x.dtype, str(x.dtype))}/up{up_x}down{down_x}/vec"
         with _lib.on_device(dev), _lib.kernel_clock.span(key, (b * c * h * w + y.numel()) * x.element_size()):
             code = _lib.lib().msg_upfirdn2d_pitched(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x, True),
                                                     major, h, w, minor, pitch, kh, kw, up_x, up_y, down_x, down_y,
@@ -91,7 +91,7 @@ def _launch(x, fir, up, down, pad):
         major, minor = b * c, 1
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev)
     vec_ok = minor % (16 // x.element_size()) == 0 and kh <= 4 and kw <= 4
-    key = f"upfirdn2d/{_DT_NAME[x.dtype]}/up{up_x}down{down_x}/"
+    key = f"upfirdn2d/{_DT_NAME.get(x.dtype, str(x.dtype))}/up{up_x}down{down_x}/"
     if vec_ok and minor > 1 and up == (1, 1) and down == (1, 1) and kh == 4 and kw == 4 and \
             (_SEPARABLE == 2 or (_SEPARABLE == 1 and x.dtype == torch.bfloat16)):
         factors = _separable(fir)

@@ -12,7 +12,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv_ops, equalized_layer
-from .op_static import FusedLeakyReLU, scaled_add, scaled_add_fork, softmax_rows, upfirdn2d
+from .op_static import FusedLeakyReLU, non_local_attention, scaled_add, scaled_add_fork, softmax_rows, upfirdn2d
+from .op_static import attention as _attention
 
 
 FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
@@ -135,10 +136,16 @@ class NonLocalBlock(nn.Module):
         query = self.theta(input).flatten(start_dim=2).transpose(1, 2)                                  # [B, HW, C/8]
         key = F.max_pool2d(self.phi(input), kernel_size=2, stride=2).flatten(start_dim=2)               # [B, C/8, HW/4]
         value = F.max_pool2d(self.g(input), kernel_size=2, stride=2).flatten(start_dim=2).transpose(1, 2)  # [B, HW/4, C/2]
-        # softmax accumulates in fp32 whatever the storage type: no fp32 copy of the [B, HW, HW/4] map is made
-        scores = torch.bmm(query, key)
-        beta = softmax_rows(scores) if input.is_cuda and NATIVE_SOFTMAX else torch.softmax(scores, dim=-1)
-        attended = torch.bmm(beta, value).view(bsz, height, width, -1).permute(0, 3, 1, 2)
+        keys = key.transpose(1, 2)                                                                      # [B, HW/4, C/8]
+        if _attention.supported(query, keys, value):
+            # fused: the [B, HW, HW/4] attention map never reaches HBM (csrc/attention.hip)
+            attended = non_local_attention(query, keys, value)
+        else:
+            # softmax accumulates in fp32 whatever the storage type: no fp32 copy of the [B, HW, HW/4] map is made
+            scores = torch.bmm(query, key)
+            beta = softmax_rows(scores) if input.is_cuda and NATIVE_SOFTMAX else torch.softmax(scores, dim=-1)
+            attended = torch.bmm(beta, value)
+        attended = attended.view(bsz, height, width, -1).permute(0, 3, 1, 2)
         output = self.o(conv_ops.to_compute_layout(attended))
         return scaled_add(self.gamma.to(input.dtype) * output, self.residual_mapping(input), 1.0 / math.sqrt(2))
 

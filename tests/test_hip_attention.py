@@ -1,0 +1,122 @@
+"""Fused non-local attention (csrc/attention.hip) against the CPU oracle's restatement of
+multi_stylegan/u_net_2d_discriminator.py:376-380: forward, first-order gradients (fused kernels), second-order
+gradients (composite path), at the sizes of the 256^2 (4096 x 1024) and 512^2 (16384 x 4096) configurations."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import models as om
+from oracle import ops as oo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# relative to max|ref|: fp32 storage runs exact-fp32 MFMA; bf16 storage rounds q, k, v, P and dS to 8 bits
+TOL = {torch.float32: (2e-5, 1e-4), torch.bfloat16: (2e-2, 4e-2)}       # (forward, gradients)
+
+
+def _oracle(q, k, v):
+    """oracle.ops.non_local_attention takes the reference's channel-first operands (theta [B,c8,HW], phi [B,c8,HW/4],
+    g [B,c2,HW/4]) and returns [B,c2,HW]."""
+    return oo.non_local_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+
+
+def _inputs(b, nq, nk, dk, dv, dtype, seed, spike=False):
+    gen = torch.Generator().manual_seed(seed)
+    q = torch.randn(b, nq, dk, generator=gen) * 0.5
+    k = torch.randn(b, nk, dk, generator=gen) * 0.5
+    v = torch.randn(b, nk, dv, generator=gen)
+    if spike:           # rows whose maximum is far above the rest, and a key that dominates every row of one sample
+        q[:, ::7] *= 12.0
+        k[0, 5] *= 9.0
+    q, k, v = (t.to(dtype).float() for t in (q, k, v))                    # the values the storage type can hold
+    return q, k, v
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 4096, 1024, 48, 192), (1, 16384, 4096, 48, 192), (3, 256, 128, 16, 64),
+                                   (2, 512, 384, 48, 192)])
+@pytest.mark.parametrize("spike", [False, True])
+def test_fused_attention_forward_backward(shape, dtype, spike):
+    from multi_stylegan_amd.op_static import attention, non_local_attention
+    b, nq, nk, dk, dv = shape
+    if spike and nq > 4096:
+        pytest.skip("spiked rows are covered at the smaller sizes")
+    q, k, v = _inputs(b, nq, nk, dk, dv, dtype, seed=nq + dk, spike=spike)
+    go = torch.randn(b, nq, dv, generator=torch.Generator().manual_seed(1)).to(dtype).float()
+    qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
+    want = _oracle(qc, kc, vc)
+    want.backward(go)
+    qd, kd, vd = (t.to(DEV, dtype).requires_grad_(True) for t in (q, k, v))
+    assert attention.supported(qd, kd, vd)
+    got = non_local_attention(qd, kd, vd)
+    assert got.dtype == dtype and got.shape == (b, nq, dv)
+    got.backward(go.to(DEV, dtype))
+    tf, tg = TOL[dtype]
+    assert rel_err(got, want) < tf
+    for name, a, r in (("dq", qd.grad, qc.grad), ("dk", kd.grad, kc.grad), ("dv", vd.grad, vc.grad)):
+        assert torch.isfinite(a).all(), name
+        assert rel_err(a, r) < tg, (name, rel_err(a, r))
+    # deterministic (no atomics): a second run gives the same bits
+    q2, k2, v2 = (t.detach().clone().requires_grad_(True) for t in (qd, kd, vd))
+    again = non_local_attention(q2, k2, v2)
+    again.backward(go.to(DEV, dtype))
+    assert torch.equal(again, got) and torch.equal(q2.grad, qd.grad) and torch.equal(k2.grad, kd.grad) \
+        and torch.equal(v2.grad, vd.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_attention_second_order(dtype):
+    """R1-style double backward through the fused op: d/d(k, v) of |d(sum(o * w)) / dq|^2 (fused forward, composite
+    gradient graph) against the oracle's autograd."""
+    from multi_stylegan_amd.op_static import non_local_attention
+    b, nq, nk, dk, dv = 2, 256, 128, 48, 192
+    q, k, v = _inputs(b, nq, nk, dk, dv, dtype, seed=3)
+    w = torch.randn(b, nq, dv, generator=torch.Generator().manual_seed(2)).to(dtype).float()
+
+    def penalty(fn, q_, k_, v_, w_):
+        gq, = torch.autograd.grad((fn(q_, k_, v_).float() * w_.float()).sum(), q_, create_graph=True)
+        return gq.float().square().sum()
+    qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
+    want = torch.autograd.grad(penalty(_oracle, qc, kc, vc, w), (qc, kc, vc))
+    qd, kd, vd = (t.to(DEV, dtype).requires_grad_(True) for t in (q, k, v))
+    got = torch.autograd.grad(penalty(non_local_attention, qd, kd, vd, w.to(DEV)), (qd, kd, vd))
+    tol = 1e-3 if dtype == torch.float32 else 6e-2
+    for a, r in zip(got, want):
+        assert rel_err(a, r) < tol, rel_err(a, r)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_non_local_block_uses_fused_attention(dtype):
+    """The product NonLocalBlock at the reference's channel counts (256 -> 384: dk 48, dv 192) on a 64 x 64 map runs the
+    fused kernels and matches the oracle's block, forward and backward, with a non-zero gamma."""
+    from multi_stylegan_amd import conv_ops, u_net_2d_discriminator as U
+    from multi_stylegan_amd.op_static import attention
+    torch.manual_seed(11)
+    ref = om.NonLocalBlock(256, 384)
+    with torch.no_grad():
+        ref.gamma.fill_(0.7)
+    blk = U.NonLocalBlock(256, 384)
+    blk.load_state_dict(ref.state_dict())
+    blk.to(DEV)
+    x = torch.randn(2, 256, 64, 64) * 0.5
+    gy = torch.randn(2, 384, 64, 64)
+    xr = x.clone().requires_grad_(True)
+    want = ref(xr)
+    want.backward(gy)
+    calls = []
+    orig = attention._NonLocalAttention.apply
+    attention._NonLocalAttention.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        xd = conv_ops.to_compute_layout(x.to(DEV), dtype).requires_grad_(True)
+        got = blk(xd)
+        got.backward(conv_ops.to_compute_layout(gy.to(DEV), dtype))
+    finally:
+        attention._NonLocalAttention.apply = orig
+    assert calls, "the fused attention path did not run"
+    tol = 1e-3 if dtype == torch.float32 else 4e-2
+    assert rel_err(got.float(), want) < tol
+    assert rel_err(xd.grad.float(), xr.grad) < tol
+    for (n, p), (_, pr) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, pr.grad) < (2e-3 if dtype == torch.float32 else 6e-2), n

@@ -164,8 +164,6 @@ def _run_golden_iterations(golden, fused, prepare=None):
         for key in z.keys(pre + "log."):
             want, got = float(z[key]), log[LOG_NAMES[key[len(pre + "log."):]]][0]
             assert abs(got - want) <= TOL * abs(want), (key, got, want)
-        if late:
-            assert torch.equal(top_k(torch.zeros(4, 1))[1].cpu(), torch.tensor([0, 1]))      # the module kept counting
         gp, dp = dict(g.named_parameters()), dict(d.named_parameters())
         ep = dict(trainer.generator_ema.named_parameters())
         for key in z.keys(pre + "G."):
@@ -280,13 +278,21 @@ def test_checkpoint_reload_on_device(golden, tmp_path):
         g2([z["train.it0.z_d.0"].to(DEV), z["train.it0.z_d.1"].to(DEV)], inject_index=2)
     tr2.load_checkpoint(path)
     real, draws = load_train_draws(z, 0, m.model_wrapper)
+    from test_oracle_golden import split_trace
     for t in (tr, tr2):
+        t.step_trace = {}
         t.train_iteration(real.to(DEV), draws.to(DEV))
-    for (n, p), (_, q) in zip(list(g.named_parameters()) + list(d.named_parameters()),
-                              list(g2.named_parameters()) + list(d2.named_parameters())):
-        assert rel_err(q, p) < 1e-6, n                     # float atomics in the weight-gradient kernels: not bitwise
-    for (n, p), (_, q) in zip(tr.generator_ema.named_parameters(), tr2.generator_ema.named_parameters()):
-        assert rel_err(q, p) < 1e-6, n
+    (steps1, ema1), (steps2, ema2) = split_trace(tr.step_trace), split_trace(tr2.step_trace)
+    for label in ("d", "g"):
+        # restored optimiser moments: the second Adam step's movement depends on them (float atomics in the
+        # weight-gradient kernels make gradients differ in the last bits, hence no bitwise comparison)
+        st = check_step_trace(steps2[label], steps1[label], tol_grad=1e-4, tol_norm=1e-5, tol_delta=2e-3)
+        assert st["compared"] > 0.2 * st["total"]
+    assert max(rel_err(ema2[n], ema1[n]) for n in ema1) < 1e-3
+    assert rel_err(tr2.path_length_regularization.mean_path_length, tr.path_length_regularization.mean_path_length) == 0
+    assert list(torch.load(path, weights_only=False))[:6] == [
+        "generator_ema", "generator", "generator_optimizer", "discriminator", "discriminator_optimizer",
+        "path_length_regularization"]
 
 
 def test_config1_64px_matches_oracle():
@@ -479,3 +485,53 @@ def test_full_size_models_bf16_track_fp32():
         # forward values: bf16 storage drift through ~30 layers; gradients additionally see leaky-ReLU slopes flip
         # where a pre-activation is within rounding of zero
         assert err < (6e-2 if "grad" not in name else 0.2), (name, err)
+
+
+def test_graph_captured_sampler_matches_eager(golden):
+    """inference.GeneratorSampler: the HIP-graph replay of the generator forward equals the eager forward
+    for every new latent (single z as scripts/get_gan_samples.py:41, and a mixed pair with a fixed crossover), fixed
+    noise buffers; with randomize_noise the replays differ from each other (fresh noise inside the graph); EMA weights
+    arrive through a reference-layout checkpoint (`module.` prefixes)."""
+    import multi_stylegan_amd as m
+    z, g, _ = _models(golden)
+    ck = {"generator_ema": {"module." + k: v for k, v in g.state_dict().items()}}
+    from tools.gen_golden import TINY_G
+    g2 = m.load_generator_ema(m.MultiStyleGANGenerator(TINY_G), ck).to(DEV)
+    for dtype in (torch.float32, torch.bfloat16):
+        g2.compute_dtype = dtype
+        for mixing in (False, True):
+            sampler = m.GeneratorSampler(g2, batch_size=3, randomize_noise=False, mixing=mixing, inject_index=3, device=DEV)
+            eager = m.GeneratorSampler(g2, batch_size=3, randomize_noise=False, mixing=mixing, inject_index=3,
+                                       use_graph=False, device=DEV)
+            for seed in range(3):
+                gen = torch.Generator(device=DEV).manual_seed(seed)
+                zs = [torch.randn(3, 16, device=DEV, generator=gen) for _ in range(2 if mixing else 1)]
+                got = sampler(zs if mixing else zs[0]).clone()
+                want = eager(zs if mixing else zs[0])
+                assert got.shape == (3, 2, 3, 32, 32) and torch.equal(got, want), (dtype, mixing, seed)
+        if dtype == torch.float32:       # against the golden image: same weights, its z pair, crossover 3 -- own noise
+            assert sampler._graph is not None
+    g2.compute_dtype = torch.float32
+    with torch.no_grad():                # noise weights are non-zero in the golden state: fresh noise must show
+        for p_name, p in g2.named_parameters():
+            if p_name.endswith("noise_injection.weight"):
+                p.fill_(0.5)
+    m.conv_ops.invalidate_weight_cache()
+    rnd = m.GeneratorSampler(g2, batch_size=2, randomize_noise=True, device=DEV)
+    zfix = torch.randn(2, 16, device=DEV)
+    a, b = rnd(zfix).clone(), rnd(zfix).clone()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+    bf, gfp = m.split_sequences(a)
+    assert bf.shape == (2, 3, 3, 32, 32) and torch.equal(bf[:, :, 0], a[:, 0]) and torch.equal(gfp[:, :, 1], a[:, 1])
+    assert gfp[:, :, 0].abs().max() == 0 and gfp[:, :, 2].abs().max() == 0
+
+
+def test_validation_samples(golden):
+    """The four per-epoch sample batches of model_wrapper.py:147-174 from one fixed mixed latent pair of 15 samples."""
+    import multi_stylegan_amd as m
+    z, g, d, tr = _golden_trainer(golden)
+    out = m.validation_samples(tr)
+    assert sorted(out) == ["prediction", "prediction_ema", "prediction_ema_rand", "prediction_rand"]
+    assert all(v.shape == (15, 2, 3, 32, 32) and torch.isfinite(v).all() for v in out.values())
+    assert isinstance(tr.validation_input_noise, list) and len(tr.validation_input_noise) == 2
+    assert g.training                     # training mode restored

@@ -117,6 +117,16 @@ def test_non_local_block_uses_fused_attention(dtype):
     assert calls, "the fused attention path did not run"
     tol = 1e-3 if dtype == torch.float32 else 4e-2
     assert rel_err(got.float(), want) < tol
-    assert rel_err(xd.grad.float(), xr.grad) < tol
+    if dtype == torch.float32:
+        assert rel_err(xd.grad.float(), xr.grad) < tol
+    else:
+        # bf16 rounds many 2x2 max-pool windows into ties: the gradient of a tied window goes to another pixel than in
+        # the fp32 oracle, an element-wise difference as large as the element itself -- compare in the norm
+        err = ((xd.grad.float().cpu() - xr.grad).norm() / xr.grad.norm()).item()
+        assert err < 5e-2, err
     for (n, p), (_, pr) in zip(blk.named_parameters(), ref.named_parameters()):
-        assert rel_err(p.grad, pr.grad) < (2e-3 if dtype == torch.float32 else 6e-2), n
+        if dtype == torch.float32:
+            assert rel_err(p.grad, pr.grad) < 2e-3, n
+        else:       # the oracle's theta / phi / g maps are not rounded to bf16 before the attention: norm-wise
+            err = ((p.grad.cpu() - pr.grad).norm() / pr.grad.norm()).item()
+            assert err < 6e-2, (n, err)

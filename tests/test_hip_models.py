@@ -119,11 +119,10 @@ LOG_NAMES = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_disc
              "loss_pl": "loss_path_length_regularization", "cut_mix_aug": "loss_cut_mix_augmentation",
              "cut_mix_reg": "loss_cut_mix_regularization"}
 # fp32 path on the GPU against the reference-driven golden run.  Pre-clip gradients: 1e-3 of each tensor's largest
-# element (north star); the R1 / path-length steps are second-order quantities through every kernel and get 3e-3.
-# Parameter movement: 2e-2 of the largest movement, on the elements whose gradient is above rounding noise (Adam
-# with beta1 = 0 turns noise-level gradients into +-lr).
-STEP_TOL = {"d": (1e-3, 1e-3, 2e-2), "g": (1e-3, 1e-3, 2e-2), "r1": (3e-3, 1e-3, 2e-2), "pl": (3e-3, 1e-3, 2e-2),
-            "cm_aug": (1e-3, 1e-3, 2e-2), "cm_reg": (1e-3, 1e-3, 2e-2)}
+# element (north star; measured: 1e-6 first order, 3e-4 for the second-order path-length step), global norm 1e-4,
+# parameter movement 5e-3 of the largest movement (measured 7e-4, most of it the fp16 storage of the fixtures), on
+# the elements whose gradient is above rounding noise (Adam with beta1 = 0 turns noise-level gradients into +-lr).
+STEP_TOL = {label: (1e-3, 1e-4, 5e-3) for label in ("d", "g", "r1", "pl", "cm_aug", "cm_reg")}
 
 
 def _golden_trainer(golden, **kw):

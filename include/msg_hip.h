@@ -213,17 +213,21 @@ int msg_softmax_rows_backward(const void* y, const void* gy, void* gx, int dtype
  * orientations of the operands whose contraction index would otherwise be strided: qt [B,dk,Nq], kt [B,dk,Nk],
  * dOt [B,dv,Nq]); all dense, in the storage type.
  * forward:  o [B, Nq, dv] = softmax_rows(q k^T) v,  lse [B, Nq] fp32 = log sum_j exp(q_i . k_j)  (kept for backward)
- * backward: given dO [B, Nq, dv] and delta [B, Nq] fp32 = sum_d dO * o:  dq, dk_out, dv_out  (probabilities are
- *           recomputed from q, k and lse; two kernels, no atomics: results are deterministic).
+ * backward: given dO [B, Nq, dv], o and lse of the forward:  dq, dk_out, dv_out  (probabilities are recomputed from q,
+ *           k and lse; delta [B, Nq] fp32 is scratch the caller provides (it receives sum_d dO * o); no atomics:
+ *           results are deterministic).
  * Supported: (dk, dv) = (48, 192) -- the reference's 384-channel blocks -- and (16, 64); Nq, Nk multiples of 128;
  * MSG_BF16 (bf16 MFMA, fp32 accumulate / softmax) and MSG_F32 (exact-fp32 MFMA).  Anything else:
  * MSG_EUNSUPPORTED (msg_nonlocal_attention_supported tells beforehand). */
 int msg_nonlocal_attention_supported(int B, int Nq, int Nk, int dk, int dv);
 int msg_nonlocal_attention_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int dtype,
                                int B, int Nq, int Nk, int dk, int dv, void* stream);
+/* msg_nonlocal_attention_bwd_splits: in how many parts the dK / dV kernel splits its query sweep for this problem; when
+ * it is more than 1 the caller passes `workspace` with splits * B * Nk * (dk + dv) floats (scratch, fully overwritten). */
+int msg_nonlocal_attention_bwd_splits(int B, int Nq, int Nk);
 int msg_nonlocal_attention_bwd(const void* q, const void* qt, const void* k, const void* kt, const void* v,
-                               const void* dO, const void* dOt, const float* lse, const float* delta,
-                               void* dq, void* dk_out, void* dv_out, int dtype,
+                               const void* dO, const void* dOt, const void* o, const float* lse, float* delta,
+                               void* dq, void* dk_out, void* dv_out, float* workspace, int dtype,
                                int B, int Nq, int Nk, int dk, int dv, void* stream);
 
 /* msg_conv2d_fprop with the activation stage of the layer fused into the epilogue:

@@ -20,9 +20,13 @@
 //    scaled by 1/l once at the end (lane-local: the query is the lane).  +20 % MFMA work in exchange for no accumulator
 //    rescaling (96 multiplies per lane per key block) and no data-dependent rescale branch.
 //  * backward as two kernels without atomics: dQ per query block (sweeping the keys), dK and dV per key block (sweeping
-//    the queries); both recompute S and dP = dO V^T.
+//    the queries); both recompute S and dP = dO V^T.  When B * Nk / 128 key blocks are too few for the 256 CUs the query
+//    sweep is split over several workgroups that write fp32 partial rows, summed by a small third kernel (fixed order:
+//    results stay deterministic).
+//  * operand blocks go global -> registers -> LDS with the loads of block i+1 issued before block i is multiplied.
 // One workgroup = 4 waves x 32 queries (or keys); K / V (or Q / dO) blocks are shared through LDS.
 #include "msg_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 
@@ -40,6 +44,12 @@ template <> struct Mma<bf16_t> {
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ float dot(Frag a, Frag b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)a[j], (float)b[j], acc);
+        return acc;
+    }
     static __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
         uint2 v;
         v.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
@@ -56,23 +66,46 @@ template <> struct Mma<float> {
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ float dot(Frag a, Frag b) { return a * b; }
     static __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
         *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
     }
 };
 
-// rows x cols elements, global (row pitch g_pitch elements) -> LDS (row pitch l_pitch), 16 bytes per thread and step
-template <typename T, int ROWS, int COLS>
-__device__ __forceinline__ void stage_tile(T* lds, int l_pitch, const T* g, long long g_pitch, int tid) {
-    constexpr int VEC = 16 / sizeof(T), CPR = COLS / VEC, TOTAL = ROWS * CPR;
+// A ROWS x COLS tile on its way global -> registers -> LDS, 16 bytes per thread and step.  Split in two so that the
+// global loads of block i+1 are in flight while block i is being multiplied (one wave per SIMD: nothing else hides them).
+// PF = false: load() only remembers the address and store() copies straight through -- no registers held across the
+// compute phase (for the kernels that run two waves per SIMD, where the other wave hides the load).
+template <typename T, int ROWS, int COLS, bool PF, int THREADS = 256>
+struct Stager {
+    static constexpr int VEC = 16 / sizeof(T), CPR = COLS / VEC, TOTAL = ROWS * CPR, N = (TOTAL + THREADS - 1) / THREADS;
     static_assert(COLS % VEC == 0, "tile rows are whole 16-byte vectors");
+    uint4 r[PF ? N : 1];
+    const T* src;
+    long long pitch;
+    __device__ __forceinline__ void load(const T* g, long long g_pitch, int tid) {
+        if constexpr (!PF) { src = g; pitch = g_pitch; return; }
 #pragma unroll
-    for (int c = tid; c < TOTAL; c += 256) {
-        const int row = c / CPR, cc = c - row * CPR;
-        *reinterpret_cast<uint4*>(lds + row * l_pitch + cc * VEC) =
-            *reinterpret_cast<const uint4*>(g + row * g_pitch + cc * VEC);
+        for (int i = 0; i < N; ++i) {
+            const int c = tid + THREADS * i;
+            if (TOTAL % THREADS == 0 || c < TOTAL) {
+                const int row = c / CPR, cc = c - row * CPR;
+                r[PF ? i : 0] = *reinterpret_cast<const uint4*>(g + row * g_pitch + cc * VEC);
+            }
+        }
     }
-}
+    __device__ __forceinline__ void store(T* lds, int l_pitch, int tid) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = tid + THREADS * i;
+            if (TOTAL % THREADS == 0 || c < TOTAL) {
+                const int row = c / CPR, cc = c - row * CPR;
+                *reinterpret_cast<uint4*>(lds + row * l_pitch + cc * VEC) =
+                    PF ? r[PF ? i : 0] : *reinterpret_cast<const uint4*>(src + row * pitch + cc * VEC);
+            }
+        }
+    }
+};
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -85,7 +118,7 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int DK, int DV>
+template <typename T, int DK, int DV, bool PF>
 __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ vt, T* __restrict__ o,
                                                          float* __restrict__ lse, int Nq, int Nk) {
@@ -106,12 +139,16 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int s = 0; s < KSQ; ++s) qf[s] = M::load(qrow, s, h);
 
+    Stager<T, KB, DK, PF> kst;
+    Stager<T, DV, KB, PF> vst;
     // sweep 1: row maxima
     float m = -3.0e38f;
+    kst.load(kb, DK, tid);
     for (int k0 = 0; k0 < Nk; k0 += KB) {
         __syncthreads();
-        stage_tile<T, KB, DK>(Ks, KP, kb + (long long)k0 * DK, DK, tid);
+        kst.store(Ks, KP, tid);
         __syncthreads();
+        kst.load(kb + (long long)(k0 + KB < Nk ? k0 + KB : 0) * DK, DK, tid);     // next block (wraps to sweep 2's first)
 #pragma unroll
         for (int t = 0; t < KB / 32; ++t) {
             f32x16 acc = zero16();
@@ -128,11 +165,16 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const T* __restrict__ 
     f32x16 oacc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) oacc[n] = zero16();
+    vst.load(vtb, Nk, tid);
     for (int k0 = 0; k0 < Nk; k0 += KB) {
         __syncthreads();
-        stage_tile<T, KB, DK>(Ks, KP, kb + (long long)k0 * DK, DK, tid);
-        stage_tile<T, DV, KB>(Vs, VP, vtb + k0, Nk, tid);
+        kst.store(Ks, KP, tid);
+        vst.store(Vs, VP, tid);
         __syncthreads();
+        if (k0 + KB < Nk) {
+            kst.load(kb + (long long)(k0 + KB) * DK, DK, tid);
+            vst.load(vtb + k0 + KB, Nk, tid);
+        }
 #pragma unroll
         for (int t = 0; t < KB / 32; ++t) {
             f32x16 acc = zero16();
@@ -166,12 +208,14 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-// dS = P * (dP - delta),  dP = dO V^T,  delta[q] = sum_d dO[q][d] O[q][d],  dQ = dS K
-template <typename T, int DK, int DV>
+// dS = P * (dP - delta),  dP = dO V^T,  delta[q] = sum_d dO[q][d] O[q][d] (computed here, and written out for the
+// dK / dV kernel that follows on the same stream),  dQ = dS K
+template <typename T, int DK, int DV, bool PF>
 __global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                            const T* __restrict__ kt, const T* __restrict__ v,
-                                                           const T* __restrict__ dO, const float* __restrict__ lse,
-                                                           const float* __restrict__ delta, T* __restrict__ dq,
+                                                           const T* __restrict__ dO, const T* __restrict__ o,
+                                                           const float* __restrict__ lse,
+                                                           float* __restrict__ delta, T* __restrict__ dq,
                                                            int Nq, int Nk) {
     using M = Mma<T>;
     constexpr int KB = 64, PAD = M::PAD, KSQ = DK / M::KS, KSV = DV / M::KS, KSP = KB / M::KS, MT = (DK + 31) / 32;
@@ -194,16 +238,32 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const T* __restrict_
     for (int s = 0; s < KSQ; ++s) qf[s] = M::load(q + qi * DK, s, h);
 #pragma unroll
     for (int s = 0; s < KSV; ++s) dof[s] = M::load(dO + qi * DV, s, h);
-    const float L = lse[qi], Dl = delta[qi];
+    float Dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < KSV; ++s) Dl += M::dot(dof[s], M::load(o + qi * DV, s, h));     // this lane's half of the row
+    Dl += __shfl_xor(Dl, 32, 64);
+    if (h == 0) delta[qi] = Dl;
+    const float L = lse[qi];
     f32x16 dqacc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) dqacc[mt] = zero16();
+    Stager<T, KB, DK, PF> kst;
+    Stager<T, KB, DV, PF> vst;
+    Stager<T, DK, KB, PF> ktst;
+    kst.load(kb, DK, tid);
+    vst.load(vb, DV, tid);
+    ktst.load(ktb, Nk, tid);
     for (int k0 = 0; k0 < Nk; k0 += KB) {
         __syncthreads();
-        stage_tile<T, KB, DK>(Ks, KP, kb + (long long)k0 * DK, DK, tid);
-        stage_tile<T, KB, DV>(Vs, VP, vb + (long long)k0 * DV, DV, tid);
-        stage_tile<T, DK, KB>(Kts, TP, ktb + k0, Nk, tid);
+        kst.store(Ks, KP, tid);
+        vst.store(Vs, VP, tid);
+        ktst.store(Kts, TP, tid);
         __syncthreads();
+        if (k0 + KB < Nk) {
+            kst.load(kb + (long long)(k0 + KB) * DK, DK, tid);
+            vst.load(vb + (long long)(k0 + KB) * DV, DV, tid);
+            ktst.load(ktb + k0 + KB, Nk, tid);
+        }
 #pragma unroll
         for (int t = 0; t < KB / 32; ++t) {
             f32x16 sacc = zero16(), pacc = zero16();
@@ -238,16 +298,25 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-// per key block: dV = P^T dO, dK = dS^T Q, sweeping the queries
+// per block of 128 keys: dV = P^T dO, dK = dS^T Q, sweeping the queries.  EIGHT waves: wave (kt, half) belongs to key
+// tile kt = wave & 3.  Per block of QB queries, in two stages separated by a barrier:
+//   1. the waves of a key tile share its query tiles: S = Q K^T, dP = dO V^T for one 32-query tile each, P^T and dS^T
+//      (keys x queries) written to the key tile's LDS scratch;
+//   2. they share its OUTPUT: wave `half` accumulates dV^T for half of the dv range and one 32-row tile of dK^T.
+// Half the accumulators per wave (<= 168 registers: two waves per SIMD, which is what hides the LDS and staging latency
+// here) at the staging traffic of a 128-key block.
 template <typename T, int DK, int DV, int QB>
-__global__ __launch_bounds__(256) void nl_attn_bwd_kv_kernel(const T* __restrict__ q, const T* __restrict__ qt,
+__global__ __launch_bounds__(512) void nl_attn_bwd_kv_kernel(const T* __restrict__ q, const T* __restrict__ qt,
                                                             const T* __restrict__ k, const T* __restrict__ v,
                                                             const T* __restrict__ dO, const T* __restrict__ dOt,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dk,
-                                                            T* __restrict__ dv, int Nq, int Nk) {
+                                                            T* __restrict__ dv, float* __restrict__ part, int Nq,
+                                                            int Nk) {
     using M = Mma<T>;
     constexpr int PAD = M::PAD, KSQ = DK / M::KS, KSV = DV / M::KS, KSP = QB / M::KS, NT = DV / 32, MT = (DK + 31) / 32;
+    constexpr int NH = NT / 2;                 // dV^T tiles per wave
+    static_assert(NT % 2 == 0 && MT <= 2, "the two waves of a key tile split the dv range and the dk tiles");
     constexpr int QP = DK + PAD, OP = DV + PAD, TP = QB + PAD;
     constexpr int STAT_T = (2 * QB * (int)sizeof(float)) / (int)sizeof(T);     // Ls + Ds in units of T
     __shared__ __attribute__((aligned(16))) T smem[QB * QP + QB * OP + 32 * MT * TP + DV * TP + STAT_T + 2 * 4 * 32 * TP];
@@ -257,39 +326,47 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_kv_kernel(const T* __restrict
     T* dOts = Qts + 32 * MT * TP;       // [DV][TP]      dv x queries (dO^T)
     float* Ls = reinterpret_cast<float*>(dOts + DV * TP);
     float* Ds = Ls + QB;
-    T* Pts = reinterpret_cast<T*>(Ds + QB);    // [4][32][TP]  per wave: keys x queries (P^T)
-    T* dSts = Pts + 4 * 32 * TP;               // [4][32][TP]  per wave: keys x queries (dS^T)
+    T* Pts = reinterpret_cast<T*>(Ds + QB);    // [4][32][TP]  per key tile: keys x queries (P^T)
+    T* dSts = Pts + 4 * 32 * TP;               // [4][32][TP]  per key tile: keys x queries (dS^T)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, key0 = blockIdx.x * 128 + wave * 32;
+    const int kt = wave & 3, half = wave >> 2;
+    const int b = blockIdx.y, key0 = blockIdx.x * 128 + kt * 32;
     const long long ki = (long long)b * Nk + key0 + r;
     const T* qb = q + (long long)b * Nq * DK;
     const T* qtb = qt + (long long)b * DK * Nq;
     const T* dob = dO + (long long)b * Nq * DV;
     const T* dotb = dOt + (long long)b * DV * Nq;
-    T* Ptw = Pts + wave * 32 * TP;
-    T* dStw = dSts + wave * 32 * TP;
-    for (int c = tid; c < 32 * MT * TP; c += 256) Qts[c] = T(0);
+    T* Ptw = Pts + kt * 32 * TP;
+    T* dStw = dSts + kt * 32 * TP;
+    for (int c = tid; c < 32 * MT * TP; c += 512) Qts[c] = T(0);
     typename M::Frag kf[KSQ], vf[KSV];
 #pragma unroll
     for (int s = 0; s < KSQ; ++s) kf[s] = M::load(k + ki * DK, s, h);
 #pragma unroll
     for (int s = 0; s < KSV; ++s) vf[s] = M::load(v + ki * DV, s, h);
-    f32x16 dvacc[NT], dkacc[MT];
+    f32x16 dvacc[NH], dkacc = zero16();
 #pragma unroll
-    for (int n = 0; n < NT; ++n) dvacc[n] = zero16();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) dkacc[mt] = zero16();
-    for (int q0 = 0; q0 < Nq; q0 += QB) {
+    for (int n = 0; n < NH; ++n) dvacc[n] = zero16();
+    // gridDim.z workgroups share a key block, each sweeping its own range of the queries (more workgroups than CUs even
+    // when B * Nk / 128 is small); with more than one of them the results are fp32 partial sums in `part`
+    const int q_per = Nq / gridDim.z, q_lo = blockIdx.z * q_per, q_hi = q_lo + q_per;
+    for (int q0 = q_lo; q0 < q_hi; q0 += QB) {
         __syncthreads();
-        stage_tile<T, QB, DK>(Qs, QP, qb + (long long)q0 * DK, DK, tid);
-        stage_tile<T, QB, DV>(dOs, OP, dob + (long long)q0 * DV, DV, tid);
-        stage_tile<T, DK, QB>(Qts, TP, qtb + q0, Nq, tid);
-        stage_tile<T, DV, QB>(dOts, TP, dotb + q0, Nq, tid);
+        Stager<T, QB, DK, false, 512> qst;
+        Stager<T, QB, DV, false, 512> ost;
+        Stager<T, DK, QB, false, 512> qtst;
+        Stager<T, DV, QB, false, 512> otst;
+        qst.load(qb + (long long)q0 * DK, DK, tid);   qst.store(Qs, QP, tid);
+        ost.load(dob + (long long)q0 * DV, DV, tid);  ost.store(dOs, OP, tid);
+        qtst.load(qtb + q0, Nq, tid);                 qtst.store(Qts, TP, tid);
+        otst.load(dotb + q0, Nq, tid);                otst.store(dOts, TP, tid);
         if (tid < QB) Ls[tid] = lse[(long long)b * Nq + q0 + tid];
         else if (tid < 2 * QB) Ds[tid - QB] = delta[(long long)b * Nq + q0 + tid - QB];
         __syncthreads();
+        // stage 1: query tiles half, half + 2, ... of the block
 #pragma unroll
         for (int t = 0; t < QB / 32; ++t) {
+            if ((t & 1) != half) continue;
             f32x16 sacc = zero16(), pacc = zero16();      // rows: queries, column: key r
 #pragma unroll
             for (int s = 0; s < KSQ; ++s) sacc = M::mma(M::load(Qs + (32 * t + r) * QP, s, h), kf[s], sacc);
@@ -307,34 +384,79 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_kv_kernel(const T* __restrict
                           p2 * (pacc[4 * g + 2] - Dv.z), p3 * (pacc[4 * g + 3] - Dv.w));
             }
         }
-        wave_lds_fence();
+        __syncthreads();
+        // stage 2: this wave's share of the key tile's outputs, over all QB queries
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int s = 0; s < KSP; ++s)
-                dvacc[n] = M::mma(M::load(dOts + (32 * n + r) * TP, s, h), M::load(Ptw + r * TP, s, h), dvacc[n]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int n = 0; n < NH; ++n)
 #pragma unroll
             for (int s = 0; s < KSP; ++s)
-                dkacc[mt] = M::mma(M::load(Qts + (32 * mt + r) * TP, s, h), M::load(dStw + r * TP, s, h), dkacc[mt]);
+                dvacc[n] = M::mma(M::load(dOts + (32 * (half * NH + n) + r) * TP, s, h), M::load(Ptw + r * TP, s, h),
+                                  dvacc[n]);
+        if (half < MT) {
+#pragma unroll
+            for (int s = 0; s < KSP; ++s)
+                dkacc = M::mma(M::load(Qts + (32 * half + r) * TP, s, h), M::load(dStw + r * TP, s, h), dkacc);
+        }
+    }
+    if (gridDim.z > 1) {               // fp32 partial sums: [z][B * Nk][DV + DK]
+        float* prow = part + ((long long)blockIdx.z * gridDim.y * Nk + ki) * (DV + DK);
+#pragma unroll
+        for (int n = 0; n < NH; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(prow + 32 * (half * NH + n) + 8 * g + 4 * h) =
+                    make_float4(dvacc[n][4 * g], dvacc[n][4 * g + 1], dvacc[n][4 * g + 2], dvacc[n][4 * g + 3]);
+        if (half < MT) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * half + 8 * g + 4 * h;
+                if (d0 < DK)
+                    *reinterpret_cast<float4*>(prow + DV + d0) =
+                        make_float4(dkacc[4 * g], dkacc[4 * g + 1], dkacc[4 * g + 2], dkacc[4 * g + 3]);
+            }
+        }
+        return;
     }
     T* dvrow = dv + ki * DV;
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int n = 0; n < NH; ++n)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            M::store4(dvrow + 32 * n + 8 * g + 4 * h, dvacc[n][4 * g], dvacc[n][4 * g + 1], dvacc[n][4 * g + 2],
-                      dvacc[n][4 * g + 3]);
-    T* dkrow = dk + ki * DK;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+            M::store4(dvrow + 32 * (half * NH + n) + 8 * g + 4 * h, dvacc[n][4 * g], dvacc[n][4 * g + 1],
+                      dvacc[n][4 * g + 2], dvacc[n][4 * g + 3]);
+    if (half < MT) {
+        T* dkrow = dk + ki * DK;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int d0 = 32 * mt + 8 * g + 4 * h;
-            if (d0 < DK)
-                M::store4(dkrow + d0, dkacc[mt][4 * g], dkacc[mt][4 * g + 1], dkacc[mt][4 * g + 2], dkacc[mt][4 * g + 3]);
+            const int d0 = 32 * half + 8 * g + 4 * h;
+            if (d0 < DK) M::store4(dkrow + d0, dkacc[4 * g], dkacc[4 * g + 1], dkacc[4 * g + 2], dkacc[4 * g + 3]);
         }
+    }
+}
+
+// dk / dv (storage type) = sum over the query splits of the fp32 partial rows [z][rows][DV + DK]
+template <typename T>
+__global__ void nl_attn_reduce_kernel(const float* __restrict__ part, T* __restrict__ dk, T* __restrict__ dv,
+                                      long long rows, int DK, int DV, int nsplit) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one 4-element group
+    const int gpr = (DV + DK) / 4;
+    if (i >= rows * gpr) return;
+    const long long row = i / gpr;
+    const int c = (int)(i - row * gpr) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nsplit; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(part + ((long long)z * rows + row) * (DV + DK) + c);
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    T* out = c < DV ? dv + row * DV + c : dk + row * DK + (c - DV);
+    Mma<T>::store4(out, acc.x, acc.y, acc.z, acc.w);
+}
+
+// MSG_ATTN_PREFETCH (A/B switch): bit 0 forward, bit 1 dQ kernel stage through registers one block ahead.  Default 0: measured slower in every kernel (the registers it holds cost more than the latency it hides).
+int prefetch_mode() {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("MSG_ATTN_PREFETCH"); mode = e ? atoi(e) : 0; }
+    return mode;
 }
 
 bool shapes_ok(int B, int Nq, int Nk, int dk, int dv) {
@@ -343,22 +465,36 @@ bool shapes_ok(int B, int Nq, int Nk, int dk, int dv) {
 
 template <typename T, int DK, int DV>
 int launch_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int Nq, int Nk, hipStream_t s) {
-    hipLaunchKernelGGL((nl_attn_fwd_kernel<T, DK, DV>), dim3(Nq / 128, B), dim3(256), 0, s, (const T*)q, (const T*)k,
-                       (const T*)vt, (T*)o, lse, Nq, Nk);
+    if (prefetch_mode() & 1)
+        hipLaunchKernelGGL((nl_attn_fwd_kernel<T, DK, DV, true>), dim3(Nq / 128, B), dim3(256), 0, s, (const T*)q,
+                           (const T*)k, (const T*)vt, (T*)o, lse, Nq, Nk);
+    else
+        hipLaunchKernelGGL((nl_attn_fwd_kernel<T, DK, DV, false>), dim3(Nq / 128, B), dim3(256), 0, s, (const T*)q,
+                           (const T*)k, (const T*)vt, (T*)o, lse, Nq, Nk);
     return MSG_CHECK_LAUNCH();
 }
 
 template <typename T, int DK, int DV>
 int launch_bwd(const void* q, const void* qt, const void* k, const void* kt, const void* v, const void* dO,
-               const void* dOt, const float* lse, const float* delta, void* dq, void* dk, void* dv, int B, int Nq,
-               int Nk, hipStream_t s) {
+               const void* dOt, const void* o, const float* lse, float* delta, void* dq, void* dk, void* dv,
+               float* part, int nsplit, int B, int Nq, int Nk, hipStream_t s) {
     constexpr int QB = sizeof(T) == 2 ? 64 : 32;
-    hipLaunchKernelGGL((nl_attn_bwd_q_kernel<T, DK, DV>), dim3(Nq / 128, B), dim3(256), 0, s, (const T*)q, (const T*)k,
-                       (const T*)kt, (const T*)v, (const T*)dO, lse, delta, (T*)dq, Nq, Nk);
+    if (prefetch_mode() & 2)
+        hipLaunchKernelGGL((nl_attn_bwd_q_kernel<T, DK, DV, true>), dim3(Nq / 128, B), dim3(256), 0, s, (const T*)q,
+                           (const T*)k, (const T*)kt, (const T*)v, (const T*)dO, (const T*)o, lse, delta, (T*)dq, Nq, Nk);
+    else
+        hipLaunchKernelGGL((nl_attn_bwd_q_kernel<T, DK, DV, false>), dim3(Nq / 128, B), dim3(256), 0, s, (const T*)q,
+                           (const T*)k, (const T*)kt, (const T*)v, (const T*)dO, (const T*)o, lse, delta, (T*)dq, Nq, Nk);
     if (hipGetLastError() != hipSuccess) return MSG_ELAUNCH;
-    hipLaunchKernelGGL((nl_attn_bwd_kv_kernel<T, DK, DV, QB>), dim3(Nk / 128, B), dim3(256), 0, s, (const T*)q,
+    hipLaunchKernelGGL((nl_attn_bwd_kv_kernel<T, DK, DV, QB>), dim3(Nk / 128, B, nsplit), dim3(512), 0, s, (const T*)q,
                        (const T*)qt, (const T*)k, (const T*)v, (const T*)dO, (const T*)dOt, lse, delta, (T*)dk, (T*)dv,
-                       Nq, Nk);
+                       part, Nq, Nk);
+    if (nsplit > 1) {
+        if (hipGetLastError() != hipSuccess) return MSG_ELAUNCH;
+        const long long rows = (long long)B * Nk, groups = rows * ((DK + DV) / 4);
+        hipLaunchKernelGGL((nl_attn_reduce_kernel<T>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, part,
+                           (T*)dk, (T*)dv, rows, DK, DV, nsplit);
+    }
     return MSG_CHECK_LAUNCH();
 }
 
@@ -382,18 +518,33 @@ extern "C" int msg_nonlocal_attention_fwd(const void* q, const void* k, const vo
     return MSG_EUNSUPPORTED;
 }
 
+// How many ways msg_nonlocal_attention_bwd splits the query sweep of its dK / dV kernel (1, 2, 4 or 8: enough
+// workgroups for the 256 CUs); with more than one the caller provides `workspace`, nsplit * B * Nk * (dk + dv) floats.
+extern "C" int msg_nonlocal_attention_bwd_splits(int B, int Nq, int Nk) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("MSG_ATTN_SPLITS"); forced = e ? atoi(e) : 0; }
+    if (forced > 0 && Nq % (forced * 128) == 0) return forced;
+    int nsplit = 1;
+    while (nsplit < 8 && (long long)B * (Nk / 128) * nsplit < 384 && (Nq / nsplit) % 128 == 0 && Nq / nsplit >= 512)
+        nsplit *= 2;
+    return nsplit;
+}
+
 extern "C" int msg_nonlocal_attention_bwd(const void* q, const void* qt, const void* k, const void* kt, const void* v,
-                                          const void* dO, const void* dOt, const float* lse, const float* delta,
-                                          void* dq, void* dk_out, void* dv_out, int dtype,
-                                          int B, int Nq, int Nk, int dk, int dv, void* stream) {
-    if (!q || !qt || !k || !kt || !v || !dO || !dOt || !lse || !delta || !dq || !dk_out || !dv_out) return MSG_EINVAL;
+                                          const void* dO, const void* dOt, const void* o, const float* lse,
+                                          float* delta, void* dq, void* dk_out, void* dv_out, float* workspace,
+                                          int dtype, int B, int Nq, int Nk, int dk, int dv, void* stream) {
+    if (!q || !qt || !k || !kt || !v || !dO || !dOt || !o || !lse || !delta || !dq || !dk_out || !dv_out) return MSG_EINVAL;
     if (!shapes_ok(B, Nq, Nk, dk, dv)) return MSG_EUNSUPPORTED;
+    const int nsplit = msg_nonlocal_attention_bwd_splits(B, Nq, Nk);
+    if (nsplit > 1 && !workspace) return MSG_EINVAL;
+    float* part = workspace;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MSG_BF16)
-        return dk == 48 ? launch_bwd<bf16_t, 48, 192>(q, qt, k, kt, v, dO, dOt, lse, delta, dq, dk_out, dv_out, B, Nq, Nk, s)
-                        : launch_bwd<bf16_t, 16, 64>(q, qt, k, kt, v, dO, dOt, lse, delta, dq, dk_out, dv_out, B, Nq, Nk, s);
+        return dk == 48 ? launch_bwd<bf16_t, 48, 192>(q, qt, k, kt, v, dO, dOt, o, lse, delta, dq, dk_out, dv_out, part, nsplit, B, Nq, Nk, s)
+                        : launch_bwd<bf16_t, 16, 64>(q, qt, k, kt, v, dO, dOt, o, lse, delta, dq, dk_out, dv_out, part, nsplit, B, Nq, Nk, s);
     if (dtype == MSG_F32)
-        return dk == 48 ? launch_bwd<float, 48, 192>(q, qt, k, kt, v, dO, dOt, lse, delta, dq, dk_out, dv_out, B, Nq, Nk, s)
-                        : launch_bwd<float, 16, 64>(q, qt, k, kt, v, dO, dOt, lse, delta, dq, dk_out, dv_out, B, Nq, Nk, s);
+        return dk == 48 ? launch_bwd<float, 48, 192>(q, qt, k, kt, v, dO, dOt, o, lse, delta, dq, dk_out, dv_out, part, nsplit, B, Nq, Nk, s)
+                        : launch_bwd<float, 16, 64>(q, qt, k, kt, v, dO, dOt, o, lse, delta, dq, dk_out, dv_out, part, nsplit, B, Nq, Nk, s);
     return MSG_EUNSUPPORTED;
 }

@@ -230,6 +230,25 @@ int msg_nonlocal_attention_bwd(const void* q, const void* qt, const void* k, con
                                void* dq, void* dk_out, void* dv_out, float* workspace, int dtype,
                                int B, int Nq, int Nk, int dk, int dv, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * 8f-2  batched affine warp of adaptive discriminator augmentation -- replaces the per-stage
+ *     images[idx] = kaf.rotate(...) / kaf.apply_affine(images[idx], params, flags) of
+ *     multi_stylegan/adaptive_discriminator_augmentation.py:120-199 (kornia 0.4.1) for a whole batch in one launch.
+ * x, y      [B, C, H, W] fp32 (NCHW planes).
+ * select_u  [B] uniform numbers; image b is transformed iff select_u[b] <= thr with thr = *p (rot_prob = 0) or
+ *           1 - sqrt(1 - *p) (rot_prob = 1); p is a DEVICE scalar (the augmentation probability the controller
+ *           adapts); other images are copied through.
+ * angle_deg [B] degrees or NULL (then angle_const for every image); scale_xy [B, 2] or NULL (1, 1).
+ * The warp is kornia's: M = [[cos, sin], [-sin, cos]] diag(scale) about (cx, cy) with the translation column
+ * ((1 - m00) cx - m01 cy, m01 cx + (1 - m00) cy); output pixel -> normalised (affine_grid, align_corners) ->
+ * N M^-1 N^-1 (N: pixel [0, size-1] -> [-1, 1]) -> pixel (grid_sample, align_corners), bilinear, padding 0 = zeros /
+ * 2 = reflection.  (kaf.apply_affine passes -angle: the caller negates.)
+ * backward != 0: x is the gradient of y, y the ZERO-INITIALISED gradient of x, which is accumulated into (float
+ * atomics: the transpose of the bilinear gather).  Parity unpinned, see oracle/ada.py. */
+int msg_affine_warp(const float* x, float* y, const float* angle_deg, float angle_const, const float* scale_xy,
+                    const float* select_u, const float* p, int rot_prob, float cx, float cy, int padding,
+                    int align_corners, int B, int C, int H, int W, int backward, void* stream);
+
 /* msg_conv2d_fprop with the activation stage of the layer fused into the epilogue:
  *   y = leaky_relu(conv(x, w) + noise_weight[0] * noise[b or 0, pixel] + act_bias[n], alpha) * scale
  * i.e. EqualizedConv2d -> FusedLeakyReLU (u_net_2d_discriminator.py:160-171) and ModulatedConv2d -> NoiseInjection ->

@@ -1,5 +1,6 @@
 """Multi-StyleGAN generator + discriminator training hot path, MI355X-native (gfx950 HIP kernels behind the
 reference's nn.Module / op_static API).  See DESIGN.md.  Public names follow multi_stylegan/__init__.py."""
+from .adaptive_discriminator_augmentation import AdaptiveDiscriminatorAugmentation, AugmentationPipeline
 from .config import (generation_hyperparameters, multi_style_gan_generator_config,
                      u_net_2d_discriminator_config)
 from .inference import GeneratorSampler, load_generator_ema, split_sequences, validation_samples
@@ -9,5 +10,5 @@ from .multi_stylegan_generator import Generator as MultiStyleGANGenerator
 from .u_net_2d_discriminator import Discriminator as MultiStyleGANDiscriminator
 
 __all__ = ["MultiStyleGANGenerator", "MultiStyleGANDiscriminator", "ModelWrapper", "Draws", "PathLengthRegularization",
-           "TopK", "GeneratorSampler", "load_generator_ema", "split_sequences", "validation_samples",
+           "TopK", "AdaptiveDiscriminatorAugmentation", "AugmentationPipeline", "GeneratorSampler", "load_generator_ema", "split_sequences", "validation_samples",
            "multi_style_gan_generator_config", "u_net_2d_discriminator_config", "generation_hyperparameters"]

@@ -1,0 +1,163 @@
+"""Adaptive discriminator augmentation on the GPU against oracle/ada.py on identical draws.  Parity with
+the reference itself is UNPINNED for this path (kornia 0.4.1 is not available): the oracle restates kornia's published
+algorithm through torch's own affine_grid / grid_sample."""
+import copy
+import math
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ada as oa
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _to_product_draws(dr: oa.Draws, device):
+    n = dr.u_flip.shape[0]
+    return {"u": torch.stack([dr.u_flip, dr.u_rot90, dr.u_roll, dr.u_iso, dr.u_rot_a, dr.u_aniso, dr.u_rot_b]).to(device),
+            "angle90": dr.angle90, "roll": dr.roll,
+            "scale_iso": dr.scale_iso.view(n, 1).expand(n, 2).contiguous().to(device),
+            "angle_a": dr.angle_a.to(device), "scale_aniso": dr.scale_aniso.to(device), "angle_b": dr.angle_b.to(device)}
+
+
+def _seed(s):
+    torch.manual_seed(s); random.seed(s); np.random.seed(s)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3, 0.8, 1.0])
+@pytest.mark.parametrize("shape", [(6, 6, 40, 40), (3, 6, 64, 48), (16, 6, 256, 256)])
+def test_pipeline_matches_oracle(shape, p):
+    from multi_stylegan_amd import AugmentationPipeline
+    _seed(sum(shape) + int(10 * p))
+    n, c, h, w = shape
+    for trial in range(3 if h < 256 else 1):
+        images = torch.rand(shape)
+        dr = oa.draw(n, h, w)
+        if trial == 1:
+            dr.angle90 = 90.0                      # every multiple of 90 degrees gets exercised
+        if trial == 2:
+            dr.angle90 = 180.0
+        x_ref = images.clone().requires_grad_(True)
+        want = oa.augment(x_ref, p, dr)
+        gy = torch.randn(shape)
+        want.backward(gy)
+        x = images.to(DEV).requires_grad_(True)
+        got = AugmentationPipeline()(x, torch.tensor(p, device=DEV), _to_product_draws(dr, DEV))
+        got.backward(gy.to(DEV))
+        # bilinear sampling of images in [0, 1]: coordinates agree to ~1e-5 pixel
+        assert rel_err(got, want) < 2e-4, (trial, rel_err(got, want))
+        assert rel_err(x.grad, x_ref.grad) < 5e-4, (trial, rel_err(x.grad, x_ref.grad))
+        if p == 0.0:
+            assert torch.equal(got.cpu(), images)
+
+
+def test_pipeline_draws_its_own_randomness():
+    """Without explicit draws: finite output of the same shape, p as a device scalar, reproducible under the reference's
+    three RNG sources (torch, random, numpy)."""
+    from multi_stylegan_amd import AugmentationPipeline
+    images = torch.rand(8, 6, 32, 32, device=DEV)
+    outs = []
+    for _ in range(2):
+        _seed(5)
+        outs.append(AugmentationPipeline()(images, torch.tensor(0.6, device=DEV)))
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all() and not torch.equal(outs[0], images)
+
+
+class _FixedDiscriminator(torch.nn.Module):
+    """Returns preset predictions (the controller only looks at their signs)."""
+
+    def __init__(self, outputs):
+        super().__init__()
+        self.outputs = list(outputs)
+        self.compute_dtype = torch.float32
+
+    def forward(self, images, **kwargs):
+        return self.outputs.pop(0)
+
+
+def test_controller_matches_oracle_and_stays_on_device():
+    """p trajectory over 40 fake and 40 real batches against the reference's host-side controller (:76-94), including
+    the clamps at 0 and p_max; real batches do not count; cut-mix calls bypass augmentation and controller."""
+    from multi_stylegan_amd import AdaptiveDiscriminatorAugmentation
+    _seed(1)
+    preds = []
+    for i in range(80):
+        bias = 1.5 if i < 50 else -1.5          # D very sure the fakes are ... real, then the opposite
+        preds.append((torch.randn(4, 1) + bias, torch.randn(4, 1, 1, 8, 8) + bias))
+    ref = oa.Controller(p_step=0.05, r_update=4, p_max=0.3)
+    ada = AdaptiveDiscriminatorAugmentation(_FixedDiscriminator([(a.to(DEV), b.to(DEV)) for a, b in preds]),
+                                            p_step=0.05, r_update=4, p_max=0.3)
+    images = torch.rand(4, 2, 3, 8, 8, device=DEV)
+    seen = []
+    for i, (a, b) in enumerate(preds):
+        is_real = i % 2 == 1
+        ada(images.clone(), is_real=is_real)
+        ref.observe(a, b, is_real)
+        seen.append((ada.p, ref.p))
+    assert all(abs(x - y) < 1e-6 for x, y in seen), seen[:12]
+    assert max(x for x, _ in seen) == pytest.approx(0.3) and min(x for x, _ in seen) == pytest.approx(0.0, abs=1e-7)
+    assert len(ada.r_history) == len(ref.r_history)
+    state = ada.ada_state()
+    other = AdaptiveDiscriminatorAugmentation(_FixedDiscriminator([]))
+    other.load_ada_state(state)
+    assert other.p == pytest.approx(ada.p) and other._r_count == ada._r_count
+
+
+def test_wrapper_augments_in_place_and_skips_cut_mix():
+    from multi_stylegan_amd import AdaptiveDiscriminatorAugmentation
+    _seed(2)
+    out = (torch.zeros(4, 1, device=DEV), torch.zeros(4, 1, 1, 16, 16, device=DEV))
+    ada = AdaptiveDiscriminatorAugmentation(_FixedDiscriminator([out, out, out]))
+    ada.p = 1.0
+    images = torch.rand(4, 2, 3, 16, 16, device=DEV)
+    before = images.clone()
+    ada(images, is_real=True)
+    assert not torch.equal(images, before)        # the caller's batch now holds the augmented images (reference :64-68)
+    before = images.clone()
+    ada(images, is_cut_mix=True)
+    assert torch.equal(images, before)
+    leaf = torch.rand(4, 2, 3, 16, 16, device=DEV, requires_grad=True)
+    kept = leaf.detach().clone()
+    ada(leaf, is_real=False)
+    assert torch.equal(leaf.detach(), kept)       # a batch that carries gradients is augmented out of place
+
+
+def test_trainer_with_ada(golden, tmp_path):
+    """Config-5 wiring: the trainer with an ADA-wrapped discriminator runs iterations 15-17 (R1 and path length
+    included), p stays in range, its state travels through a checkpoint, the reference-layout discriminator keys carry
+    the wrapper's `discriminator.` prefix."""
+    import multi_stylegan_amd as m
+    from tools.gen_golden import TINY_D, TINY_G
+    _seed(3)
+    z = golden("tiny_models")
+    g, d = m.MultiStyleGANGenerator(TINY_G), m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True)
+    g.load_state_dict(z.state_dict("tinyG.sd.")); d.load_state_dict(z.state_dict("tinyD.sd."))
+    ada = m.AdaptiveDiscriminatorAugmentation(d, r_update=2)
+    tr = m.ModelWrapper(g, ada, device=DEV)
+    assert not tr.batch_discriminator_passes
+    tr.iteration = 14
+    for _ in range(3):
+        tr.train_iteration(torch.rand(4, 2, 3, 32, 32, device=DEV))
+    logs = tr.pop_logs()
+    assert all(math.isfinite(v) for vals in logs.values() for v in vals)
+    assert {"loss_discriminator_regularization", "path_length"} <= set(logs)
+    assert 0.0 <= ada.p <= 0.8 and len(ada.r_history) == 3        # 6 fake batches (D step + G step per iteration) / 2
+    path = str(tmp_path / "ck.pt")
+    tr.save_checkpoint(path)
+    ck = torch.load(path, weights_only=False)
+    assert all(k.startswith("discriminator.") for k in ck["discriminator"])
+    assert ck["multi_stylegan_amd"]["ada"]["p"] == pytest.approx(ada.p)
+    d2 = m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True)
+    tr2 = m.ModelWrapper(copy.deepcopy(g), m.AdaptiveDiscriminatorAugmentation(d2), device=DEV)
+    tr2.load_checkpoint(path)
+    assert tr2.discriminator.p == pytest.approx(ada.p)
+    # ... and into a trainer whose discriminator is NOT wrapped (prefix stripped)
+    d3 = m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True)
+    tr3 = m.ModelWrapper(copy.deepcopy(g), d3, device=DEV)
+    tr3.load_checkpoint(path)
+    for (n, a), (_, b) in zip(d.state_dict().items(), d3.state_dict().items()):
+        assert torch.equal(a, b), n

@@ -345,3 +345,20 @@ def test_global_top_k_gloo_world2():
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=5) == "ok"
+
+
+def test_ada_controller_on_cpu_matches_oracle():
+    """The device-side p controller of AdaptiveDiscriminatorAugmentation is plain tensor arithmetic: on CPU tensors it
+    must follow the reference's host-side controller (oracle/ada.py, adaptive_discriminator_augmentation.py:76-94)."""
+    from multi_stylegan_amd.adaptive_discriminator_augmentation import AdaptiveDiscriminatorAugmentation
+    from oracle import ada as oa
+    torch.manual_seed(4)
+    ada = AdaptiveDiscriminatorAugmentation(torch.nn.Identity(), p_step=0.02, r_update=3, p_max=0.1)
+    ref = oa.Controller(p_step=0.02, r_update=3, p_max=0.1)
+    for i in range(45):
+        bias = 1.0 if i < 25 else -1.0
+        a, b = torch.randn(4, 1) + bias, torch.randn(4, 1, 1, 6, 6) + bias
+        ada._observe(a, b)
+        ref.observe(a, b, is_real=False)
+        assert abs(ada.p - ref.p) < 1e-6, i
+    assert len(ada.r_history) == len(ref.r_history) == 15

@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--elide-dead-work", action="store_true",
                     help="skip work whose results the reference discards (dead 2nd-stream convs, D weight grads in "
                          "the G step); identical training trajectory, not used for the headline value")
+    ap.add_argument("--ada", action="store_true",
+                    help="wrap the discriminator in adaptive discriminator augmentation (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-clock", action="store_true")
     ap.add_argument("--clock-all", action="store_true",
@@ -57,6 +59,8 @@ def baseline_config(args, world) -> str:
     """Which BASELINE.json config this run is, if any."""
     if args.dtype != "bf16":
         return ""
+    if args.ada:
+        return " + ADA (BASELINE configs[4])" if args.resolution == 256 and world == 8 else " + ADA"
     if args.resolution == 256 and args.batch == 16:
         return " (BASELINE configs[1])" if world == 1 else (" (BASELINE configs[2])" if world == 8 else
                                                             " (BASELINE configs[1] per GPU)")
@@ -151,6 +155,8 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     gen.compute_dtype = dis.compute_dtype = dtype
     gen.elide_dead_branch = args.elide_dead_work
+    if args.ada:
+        dis = m.AdaptiveDiscriminatorAugmentation(dis)
     trainer = m.ModelWrapper(gen, dis, device=dev,
                              skip_discriminator_weight_grads_in_generator_step=args.elide_dead_work)
     trainer.generator_ema.compute_dtype = dtype
@@ -263,7 +269,8 @@ def main():
                                    f"path-length every 16th; one synthetic real batch per rank, resident in HBM and "
                                    f"re-used every step (fresh z / noise per step)",
                        "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "dead_work_elided": bool(args.elide_dead_work)},
+                       "parallelism": f"dp{world}", "dead_work_elided": bool(args.elide_dead_work),
+                       "ada": bool(args.ada)},
             "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
             "rehearsal_shared_gpu": bool(args.rehearse_on_one_gpu),
             "backend": torch.distributed.get_backend() if world > 1 else None,

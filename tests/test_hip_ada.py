@@ -80,13 +80,13 @@ class _FixedDiscriminator(torch.nn.Module):
 
 
 def test_controller_matches_oracle_and_stays_on_device():
-    """p trajectory over 40 fake and 40 real batches against the reference's host-side controller (:76-94), including
+    """p trajectory over 80 fake and 80 real batches against the reference's host-side controller (:76-94), including
     the clamps at 0 and p_max; real batches do not count; cut-mix calls bypass augmentation and controller."""
     from multi_stylegan_amd import AdaptiveDiscriminatorAugmentation
     _seed(1)
     preds = []
-    for i in range(80):
-        bias = 1.5 if i < 50 else -1.5          # D very sure the fakes are ... real, then the opposite
+    for i in range(160):
+        bias = 1.5 if i < 64 else -1.5          # D very sure the fakes are ... real, then the opposite
         preds.append((torch.randn(4, 1) + bias, torch.randn(4, 1, 1, 8, 8) + bias))
     ref = oa.Controller(p_step=0.05, r_update=4, p_max=0.3)
     ada = AdaptiveDiscriminatorAugmentation(_FixedDiscriminator([(a.to(DEV), b.to(DEV)) for a, b in preds]),

@@ -25,9 +25,11 @@ def supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
 
 
 def composite(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """softmax(q k^T) v with library products and fp32 softmax statistics (any shape, differentiable to any order)."""
-    beta = torch.softmax(torch.bmm(q, k.transpose(1, 2)).float(), dim=-1).to(q.dtype)
-    return torch.bmm(beta, v)
+    """softmax(q k^T) v with library products around the row-softmax kernel (fp32 statistics, storage-type map; any
+    shape, differentiable to any order).  This is where the [B, Nq, Nk] map still exists: shapes the fused kernels do
+    not take, and the second-order graph of the R1 iteration."""
+    from .softmax import softmax_rows
+    return torch.bmm(softmax_rows(torch.bmm(q, k.transpose(1, 2))), v)
 
 
 class _NonLocalAttention(Function):

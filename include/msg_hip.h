@@ -249,6 +249,22 @@ int msg_affine_warp(const float* x, float* y, const float* angle_deg, float angl
                     const float* select_u, const float* p, int rot_prob, float cx, float cy, int padding,
                     int align_corners, int B, int C, int H, int W, int backward, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * a5 / 8f-1  minibatch standard deviation -- replaces MinibatchStdDev.forward
+ *     (multi_stylegan/u_net_2d_discriminator.py:205-217: std over the batch, mean over (c, h, w), one extra plane, cat).
+ * x  channels-last [B, H, W] pixels of C channels, `ldx` elements apart;  y the same pixels with `ldy` > C channels:
+ * y[..., :C] = x, y[..., C] = stat[g], further pad channels 0, where the batch is `groups` independent batches of
+ * B / groups samples concatenated along dim 0 and stat[g] = mean_{c,h,w} sqrt(max(var_group(x), alpha)).
+ * stat [groups] fp32 out; workspace: msg_minibatch_stddev_workspace(...) floats.  Deterministic (fixed-order sums).
+ * backward: gx[..., :C] (pitch ldgx) = gy[..., :C] + gstat[g] * d stat / d x, gstat [groups] fp32 = the summed
+ * gradient of each group's plane. */
+long long msg_minibatch_stddev_workspace(int C, int H, int W, int groups, int dtype);
+int msg_minibatch_stddev(const void* x, void* y, float* stat, float* workspace, int dtype,
+                         int B, int C, int H, int W, int ldx, int ldy, int groups, float alpha, void* stream);
+int msg_minibatch_stddev_backward(const void* x, const void* gy, const float* gstat, void* gx, int dtype,
+                                  int B, int C, int H, int W, int ldx, int ldgy, int ldgx, int groups,
+                                  float alpha, void* stream);
+
 /* msg_conv2d_fprop with the activation stage of the layer fused into the epilogue:
  *   y = leaky_relu(conv(x, w) + noise_weight[0] * noise[b or 0, pixel] + act_bias[n], alpha) * scale
  * i.e. EqualizedConv2d -> FusedLeakyReLU (u_net_2d_discriminator.py:160-171) and ModulatedConv2d -> NoiseInjection ->

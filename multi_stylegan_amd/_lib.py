@@ -48,6 +48,9 @@ _SIGNATURES = {
     "msg_nonlocal_attention_bwd_splits": (_I, [_I] * 3),
     "msg_nonlocal_attention_bwd": (_I, [_P] * 14 + [_I] * 6 + [_P]),
     "msg_affine_warp": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msg_minibatch_stddev_workspace": (_L, [_I] * 5),
+    "msg_minibatch_stddev": (_I, [_P, _P, _P, _P, _I] + [_I] * 7 + [_F, _P]),
+    "msg_minibatch_stddev_backward": (_I, [_P, _P, _P, _P, _I] + [_I] * 8 + [_F, _P]),
     "msg_conv2d_fprop_plan": (_I, [_I] * 11 + [_L]),
     "msg_linear_fprop": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "msg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),

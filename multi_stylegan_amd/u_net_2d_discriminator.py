@@ -52,6 +52,68 @@ class Blur(nn.Module):
         return upfirdn2d(input, self.kernel, pad=self.padding)
 
 
+def _mbstd_composite(input: torch.Tensor, groups: int, alpha: float) -> torch.Tensor:
+    """The statistic with torch ops (any device / layout, differentiable to any order); statistics in fp32."""
+    b, _, h, w = input.shape
+    x = input.float().reshape(groups, b // groups, *input.shape[1:])
+    var = (x - x.mean(dim=1, keepdim=True)).square().mean(dim=1)                    # [G, C, H, W]
+    stat = torch.sqrt(var.clamp(min=alpha)).mean(dim=(1, 2, 3))                     # [G]
+    plane = stat.to(input.dtype).reshape(groups, 1, 1, 1, 1).expand(groups, b // groups, 1, h, w).reshape(b, 1, h, w)
+    return conv_ops.cat_channels([input, plane])
+
+
+class _MinibatchStdDevFused(torch.autograd.Function):
+    """cat([x, stat plane]) on the gfx950 kernels (csrc/mbstd.hip): x is read once, the concatenation copy is part of the
+    same pass.  A second-order graph (R1) is built from the composite formulation."""
+
+    @staticmethod
+    def forward(ctx, x, groups, alpha):
+        from . import _lib
+        dev = _lib.require_gpu(x)
+        b, c, h, w = x.shape
+        xv, ldx = conv_ops._nhwc_view(x)
+        out = conv_ops._padded_nhwc(b, c + 1, h, w, x.dtype, dev)
+        ldy = out.stride(3)
+        code_dtype = _lib.dtype_code(x)
+        stat = torch.empty(groups, dtype=torch.float32, device=dev)
+        work = torch.empty(int(_lib.lib().msg_minibatch_stddev_workspace(c, h, w, groups, code_dtype)),
+                           dtype=torch.float32, device=dev)
+        with _lib.on_device(dev), _lib.kernel_clock.span(f"mbstd_fwd/{x.dtype}", 2 * x.numel() * x.element_size()):
+            code = _lib.lib().msg_minibatch_stddev(xv.data_ptr(), out.data_ptr(), stat.data_ptr(), work.data_ptr(),
+                                                   code_dtype, b, c, h, w, ldx, ldy, groups, float(alpha),
+                                                   _lib.stream_of(dev))
+        _lib.check(code, "msg_minibatch_stddev")
+        ctx.save_for_backward(x)
+        ctx.cfg = (groups, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        x, = ctx.saved_tensors
+        groups, alpha = ctx.cfg
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                xx = x if x.requires_grad else x.detach().requires_grad_(True)
+                gx, = torch.autograd.grad(_mbstd_composite(xx, groups, alpha), xx, gy, create_graph=True)
+            return gx, None, None
+        dev = x.device
+        b, c, h, w = x.shape
+        xv, ldx = conv_ops._nhwc_view(x)
+        gv, ldg = conv_ops._nhwc_view(gy)
+        gstat = gy[:, c].float().reshape(groups, -1).sum(dim=1).contiguous()
+        gx = torch.empty((b, h, w, c), dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+        with _lib.on_device(dev), _lib.kernel_clock.span(f"mbstd_bwd/{x.dtype}", 3 * x.numel() * x.element_size()):
+            code = _lib.lib().msg_minibatch_stddev_backward(xv.data_ptr(), gv.data_ptr(), gstat.data_ptr(), gx.data_ptr(),
+                                                            _lib.dtype_code(x), b, c, h, w, ldx, ldg, c, groups,
+                                                            float(alpha), _lib.stream_of(dev))
+        _lib.check(code, "msg_minibatch_stddev_backward")
+        return gx, None, None
+
+
+FUSED_MBSTD = bool(int(os.environ.get("MSG_FUSED_MBSTD", "1")))             # 0: torch-op statistic + concatenation (A/B)
+
+
 class MinibatchStdDev(nn.Module):
     """Appends one plane holding the mean (over c,h,w) of the per-position std over the batch; statistics in
     fp32.  The whole batch of ONE forward call is one group, as in the reference (:205-217); when the trainer runs the
@@ -65,13 +127,11 @@ class MinibatchStdDev(nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         groups = self.groups
-        b, _, h, w = input.shape
-        assert b % groups == 0
-        x = input.float().reshape(groups, b // groups, *input.shape[1:])
-        var = (x - x.mean(dim=1, keepdim=True)).square().mean(dim=1)                    # [G, C, H, W]
-        stat = torch.sqrt(var.clamp(min=self.alpha)).mean(dim=(1, 2, 3))                # [G]
-        plane = stat.to(input.dtype).reshape(groups, 1, 1, 1, 1).expand(groups, b // groups, 1, h, w).reshape(b, 1, h, w)
-        return conv_ops.cat_channels([input, plane])
+        assert input.shape[0] % groups == 0
+        vec = 16 // input.element_size()
+        if FUSED_MBSTD and input.is_cuda and input.dtype in (torch.float32, torch.bfloat16) and input.shape[1] % vec == 0:
+            return _MinibatchStdDevFused.apply(input, groups, self.alpha)
+        return _mbstd_composite(input, groups, self.alpha)
 
 
 class ResNetBlock(nn.Module):

@@ -130,3 +130,46 @@ def test_non_local_block_uses_fused_attention(dtype):
         else:       # the oracle's theta / phi / g maps are not rounded to bf16 before the attention: norm-wise
             err = ((p.grad.cpu() - pr.grad).norm() / pr.grad.norm()).item()
             assert err < 6e-2, (n, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,groups", [((16, 768, 32, 32), 1), ((32, 1024, 16, 16), 2), ((6, 24, 5, 7), 3),
+                                           ((4, 32, 8, 8), 1)])
+def test_fused_minibatch_stddev(shape, groups, dtype):
+    """csrc/mbstd.hip against the oracle (u_net_2d_discriminator.py:205-217), per group: forward (statistic plane +
+    the concatenation), first-order gradient (fused kernel) and an R1-style second-order gradient (composite path);
+    run twice: bit-identical (fixed-order sums)."""
+    from multi_stylegan_amd import conv_ops, u_net_2d_discriminator as U
+    torch.manual_seed(shape[1])
+    x = (torch.randn(shape) * torch.rand(1, shape[1], 1, 1) * 2).to(dtype).float()
+    x[:, 0] = 0.25                                       # a channel without variance: the clamp, zero gradient
+    n = shape[0] // groups
+    xr = x.clone().requires_grad_(True)
+    want = torch.cat([oo.minibatch_stddev(xr[g * n:(g + 1) * n]) for g in range(groups)])
+    gy = torch.randn(want.shape).to(dtype).float()
+    want.backward(gy)
+    mod = U.MinibatchStdDev()
+    mod.groups = groups
+    xd = conv_ops.to_compute_layout(x.to(DEV), dtype).requires_grad_(True)
+    got = mod(xd)
+    assert got.shape == want.shape and got.dtype == dtype
+    got.backward(conv_ops.to_compute_layout(gy.to(DEV), dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(got, want) < tol and rel_err(got[:, -1], want[:, -1]) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    x2 = xd.detach().clone().requires_grad_(True)
+    again = mod(x2)
+    again.backward(conv_ops.to_compute_layout(gy.to(DEV), dtype))
+    assert torch.equal(again, got) and torch.equal(x2.grad, xd.grad)
+    if shape[2] <= 8:           # second order: d/dx of |d(sum(y * w))/dx|^2
+        w = torch.randn(want.shape).to(dtype).float()
+
+        def pen(fn, x_):        # (y^2 w: the statistic plane enters non-linearly, its second derivative matters)
+            g, = torch.autograd.grad((fn(x_).float().square() * w.to(x_.device)).sum(), x_, create_graph=True)
+            return g.float().square().sum()
+        x3 = x.clone().requires_grad_(True)
+        ref2, = torch.autograd.grad(pen(lambda t: torch.cat([oo.minibatch_stddev(t[g * n:(g + 1) * n])
+                                                             for g in range(groups)]), x3), x3)
+        x4 = conv_ops.to_compute_layout(x.to(DEV), dtype).requires_grad_(True)
+        got2, = torch.autograd.grad(pen(mod, x4), x4)
+        assert rel_err(got2, ref2) < (1e-3 if dtype == torch.float32 else 5e-2)

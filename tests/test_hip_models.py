@@ -119,10 +119,12 @@ LOG_NAMES = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_disc
              "loss_pl": "loss_path_length_regularization", "cut_mix_aug": "loss_cut_mix_augmentation",
              "cut_mix_reg": "loss_cut_mix_regularization"}
 # fp32 path on the GPU against the reference-driven golden run.  Pre-clip gradients: 1e-3 of each tensor's largest
-# element (north star; measured: 1e-6 first order, 3e-4 for the second-order path-length step), global norm 1e-4,
+# element (north star; measured: 1e-6 first order; the second-order steps, whose float-atomic weight gradients pass
+# through a second differentiation, vary between runs, 1e-4 .. 3e-4 with rare excursions: they get 3e-3), global norm 1e-4,
 # parameter movement 5e-3 of the largest movement (measured 7e-4, most of it the fp16 storage of the fixtures), on
 # the elements whose gradient is above rounding noise (Adam with beta1 = 0 turns noise-level gradients into +-lr).
-STEP_TOL = {label: (1e-3, 1e-4, 5e-3) for label in ("d", "g", "r1", "pl", "cm_aug", "cm_reg")}
+STEP_TOL = {label: (1e-3, 1e-4, 5e-3) for label in ("d", "g", "cm_aug", "cm_reg")}
+STEP_TOL.update(r1=(3e-3, 1e-4, 5e-3), pl=(3e-3, 1e-4, 5e-3))
 
 
 def _golden_trainer(golden, **kw):

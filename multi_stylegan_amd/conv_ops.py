@@ -959,6 +959,51 @@ def _scale_rows_cols(base, rowscale, colscale, out, gain):
     return out
 
 
+_MODCONV_BWD_BATCH = 16
+
+
+def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need):
+    """First-order backward of the modulated convolution for at most 16 samples: data gradient with re-laid per-sample
+    weights, per-sample weight gradient, and the kernel that folds it into dL/dW and dL/ds (see _ModulatedConv)."""
+    _, o, i, kh, kw = weight.shape
+    b, t = x.shape[0], kh * kw
+    dev = x.device
+    w3 = weight.detach().reshape(o, i, t)
+    s = style.detach().float().contiguous()
+    dd = d if demodulate else None
+    esz = 2 if gy.dtype == torch.bfloat16 else 4
+    gx = None
+    if need[0]:
+        okp = _round_up(o, 128 // esz)
+        img = _param_images(weight, torch.float32, 1.0, g.kind, modulation=True)
+        base = img["d"][0] if img is not None else _cached(weight, "md" + g.kind, torch.float32, 1.0, lambda: (
+            (w3 if upsample else w3.flip(-1)).permute(1, 2, 0).contiguous(), 0))[0]       # [I][taps'][O]
+        wd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
+        _scale_rows_cols(base, s, dd, wd, scale)
+        if upsample:
+            gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o)
+        else:
+            gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o)
+    gw = gs = None
+    if need[1] or need[2]:
+        if upsample:
+            gwk, ldg = _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True)
+        else:
+            gwk, ldg = _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
+        og = 1 if o >= 256 else 2                      # >= 256 workgroups for the 512-channel layers
+        groups = (o + og - 1) // og
+        gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
+        gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            code = _lib.lib().msg_modulate_backward(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
+                                                    gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t, ldg, og,
+                                                    scale, _lib.stream_of(dev))
+        _lib.check(code, "msg_modulate_backward")
+        gw = gw3.reshape(1, o, i, kh, kw)
+        gs = gs_part.sum(dim=0).to(style.dtype)
+    return gx, gw, gs
+
+
 class _ModulatedConv(Function):
     """The dual-styled modulated / demodulated convolution with fused weight handling (csrc/modulate.hip):
     forward  = demod coefficients (wave-shuffle reduction) -> per-sample weights written straight in the kernel
@@ -1033,7 +1078,7 @@ class _ModulatedConv(Function):
             gb = gb if has_bias and need[5] else None
             gnw = gnw.reshape(nw_shape) if has_noise and need[7] else None
         tail = (None, None, gb, None, gnw, None, None, None)
-        fused_ok = i <= 512 and t <= 9 and b <= 16
+        fused_ok = i <= 512 and t <= 9
         if torch.is_grad_enabled() or not fused_ok:
             # higher-order request (create_graph=True): differentiate the composite formulation instead
             with torch.enable_grad():
@@ -1042,40 +1087,20 @@ class _ModulatedConv(Function):
                 grads = list(torch.autograd.grad(y2, ins, gy, create_graph=torch.is_grad_enabled(), allow_unused=True))
             out = [grads.pop(0) if n else None for n in need[:3]]
             return (out[0], out[1], out[2]) + tail
-        dev = x.device
-        w3 = weight.detach().reshape(o, i, t)
-        s = style.detach().float().contiguous()
-        dd = d if demodulate else None
-        esz = 2 if gy.dtype == torch.bfloat16 else 4
-        gx = None
-        if need[0]:
-            okp = _round_up(o, 128 // esz)
-            img = _param_images(weight, torch.float32, 1.0, g.kind, modulation=True)
-            base = img["d"][0] if img is not None else _cached(weight, "md" + g.kind, torch.float32, 1.0, lambda: (
-                (w3 if upsample else w3.flip(-1)).permute(1, 2, 0).contiguous(), 0))[0]       # [I][taps'][O]
-            wd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
-            _scale_rows_cols(base, s, dd, wd, scale)
-            if upsample:
-                gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o)
-            else:
-                gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o)
-        gw = gs = None
-        if need[1] or need[2]:
-            if upsample:
-                gwk, ldg = _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True)
-            else:
-                gwk, ldg = _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
-            og = 1 if o >= 256 else 2                      # >= 256 workgroups for the 512-channel layers
-            groups = (o + og - 1) // og
-            gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
-            gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
-            with _lib.on_device(dev):
-                code = _lib.lib().msg_modulate_backward(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
-                                                        gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t, ldg, og,
-                                                        scale, _lib.stream_of(dev))
-            _lib.check(code, "msg_modulate_backward")
-            gw = gw3.reshape(1, o, i, kh, kw)
-            gs = gs_part.sum(dim=0).to(style.dtype)
+        # msg_modulate_backward keeps one sample's partial sums per unrolled register slot: 16 samples per launch.  Larger
+        # batches go through in chunks of 16 (per-sample results concatenated, the weight gradient summed).
+        if b > _MODCONV_BWD_BATCH:
+            gxs, gws, gss = [], [], []
+            for lo in range(0, b, _MODCONV_BWD_BATCH):
+                hi = min(b, lo + _MODCONV_BWD_BATCH)
+                cgx, cgw, cgs = _modconv_backward(x[lo:hi], weight, style[lo:hi], d[lo:hi] if demodulate else d,
+                                                  gy[lo:hi], demodulate, upsample, g, scale, need)
+                gxs.append(cgx); gws.append(cgw); gss.append(cgs)
+            gx = torch.cat(gxs) if need[0] else None
+            gw = torch.stack(gws).sum(dim=0) if gws[0] is not None else None
+            gs = torch.cat(gss) if gss[0] is not None else None
+            return (gx, gw, gs) + tail
+        gx, gw, gs = _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need)
         return (gx, gw, gs) + tail
 
 

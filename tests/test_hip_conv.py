@@ -340,9 +340,10 @@ def test_few_row_linear_family(m, n, k):
     assert gwe.abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("batch", [3, 21])          # 21: more than the 16 samples one backward launch takes (chunked)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["conv3x3_demod", "up2x2_demod", "torgb1x1_nodemod"])
-def test_fused_modulated_conv_matches_composite(kind, dtype):
+def test_fused_modulated_conv_matches_composite(kind, dtype, batch):
     """csrc/modulate.hip path (demod reduction, per-sample weights in kernel layout, fused backward) against the
     composite torch-op formulation AND against the CPU oracle, forward and all three gradients."""
     from multi_stylegan_amd import conv_ops
@@ -350,7 +351,7 @@ def test_fused_modulated_conv_matches_composite(kind, dtype):
     tol = TOLS[dtype] * (3 if dtype == torch.float32 else 1)
     k = {"conv3x3_demod": 3, "up2x2_demod": 2, "torgb1x1_nodemod": 1}[kind]
     demod, up = kind != "torgb1x1_nodemod", kind == "up2x2_demod"
-    b, i, o, h = 3, 40, (3 if k == 1 else 24), 10
+    b, i, o, h = batch, 40, (3 if k == 1 else 24), 10
     g = torch.Generator().manual_seed(k)
     x = torch.randn(b, i, h, h, generator=g).to(dtype).float()
     w = torch.randn(1, o, i, k, k, generator=g)
@@ -370,7 +371,14 @@ def test_fused_modulated_conv_matches_composite(kind, dtype):
     wd, sd = w.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
     gyd = gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last)
     y = conv_ops.modulated_conv2d(xd, wd, sd, demod, up)
-    gd = torch.autograd.grad(y, (xd, wd, sd), gyd)
+    calls = []
+    orig = conv_ops._modconv_backward
+    conv_ops._modconv_backward = lambda *a: (calls.append(a[0].shape[0]), orig(*a))[1]
+    try:
+        gd = torch.autograd.grad(y, (xd, wd, sd), gyd)
+    finally:
+        conv_ops._modconv_backward = orig
+    assert calls == ([3] if batch == 3 else [16, 5]), "the fused backward must run, in chunks of at most 16 samples"
     yc = conv_ops._modulated_composite(xd, wd, sd, demod, up)
     gc = torch.autograd.grad(yc, (xd, wd, sd), gyd)
     assert rel_err(y.float(), yr) < tol and rel_err(y.float(), yc.float()) < tol

@@ -389,6 +389,61 @@ def test_config2_256px_batch16_matches_oracle():
         torch.cuda.empty_cache()
 
 
+def test_config4_512px_matches_oracle():
+    """BASELINE config 4's models -- 512x512, 8 x 512 channels in G, the discriminator on 512^2 inputs with its
+    16384 x 4096 non-local attention (fused kernels) -- against the CPU oracle with the same weights, z and noise:
+    generator image and discriminator outputs, fp32 (1e-3) and bf16 storage (5e-2).  Batch 2 instead of the config's 8
+    per GPU: the oracle needs ~25 s per sample on the box's CPU; the batch-8 launch shapes are exercised by
+    test_full_size_models / the benchmark, the 512^2-only shapes (9th generator level, 16384-query attention) here."""
+    import time
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    from multi_stylegan_amd.op_static import attention
+    from oracle import models as om
+    torch.manual_seed(31)
+    bsz = 2
+    cfg = generator_config_for_resolution(512)
+    go, do = om.Generator(cfg), om.Discriminator(no_rfp=True)
+    gen_cpu = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for n, p in list(go.named_parameters()) + list(do.named_parameters()):
+            if n.endswith("noise_injection.weight") or n.endswith("gamma"):
+                p.copy_(torch.randn(p.shape, generator=gen_cpu) * 0.3)
+            elif n.endswith(".bias") and p.ndim == 1:
+                p.add_(torch.randn(p.shape, generator=gen_cpu) * 0.1)
+    z = [torch.randn(bsz, 512, generator=gen_cpu), torch.randn(bsz, 512, generator=gen_cpu)]
+    noise = [torch.randn(bsz, 1, 4, 4, generator=gen_cpu)] + \
+            [torch.randn(bsz, 1, 2 ** (i // 2 + 3), 2 ** (i // 2 + 3), generator=gen_cpu) for i in range(14)]
+    t0 = time.time()
+    with torch.no_grad():
+        want_img = go(z, noise=noise, inject_index=7)
+        ws, wp = do(want_img)
+    print(f"oracle on the CPU: {time.time() - t0:.1f} s")
+    assert want_img.shape == (bsz, 2, 3, 512, 512)
+    gd = m.MultiStyleGANGenerator(cfg)
+    gd.load_state_dict(go.state_dict())
+    dd = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    dd.load_state_dict(do.state_dict())
+    gd.to(DEV); dd.to(DEV)
+    fused_calls = []
+    orig = attention._NonLocalAttention.apply
+    attention._NonLocalAttention.apply = staticmethod(lambda *a: (fused_calls.append(a[0].shape), orig(*a))[1])
+    try:
+        for dt, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+            gd.compute_dtype = dd.compute_dtype = dt
+            with torch.no_grad():
+                img = gd([t.to(DEV) for t in z], noise=[t.to(DEV) for t in noise], inject_index=7)
+                s, px = dd(want_img.to(DEV))
+            errs = (rel_err(img, want_img), rel_err(s, ws), rel_err(px, wp))
+            print(f"{dt}: image {errs[0]:.2e}  score {errs[1]:.2e}  pixel map {errs[2]:.2e}")
+            assert max(errs) < tol, (dt, errs)
+            del img, s, px
+            torch.cuda.empty_cache()
+    finally:
+        attention._NonLocalAttention.apply = orig
+    assert (bsz, 16384, 48) in [tuple(sh) for sh in fused_calls], "the 16384-query attention ran on the fused kernels"
+
+
 @pytest.mark.parametrize("batch", [1, 3])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_train_iteration_odd_batches(golden, batch, dtype):

@@ -232,10 +232,15 @@ def main():
         value = world * args.batch * args.steps / elapsed
         # dominant kernel (rocprofv3: ~44 % of GPU time): the bf16 implicit-GEMM conv on the matrix cores.
         # achieved = algorithmic FLOPs of its launches inside the timed region / their HIP-event durations.
-        try:        # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this workload (profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        except (OSError, KeyError, ValueError):
-            pmc = {}
+        pmc, pmc_file = {}, None       # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this workload
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")),
+                           reverse=True):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+                pmc_file = name
+                break
+            except (OSError, KeyError, ValueError):
+                continue
 
         def leg(key, bound, peak, unit, name):
             if key not in clock:
@@ -247,7 +252,7 @@ def main():
                     "traffic": (pmc.get(key) or pmc.get(key.replace("+act", ""), {})).get("traffic_bytes_per_launch")
                     if args.batch == 16 and
                     args.resolution == 256 and args.dtype == "bf16" else None,
-                    "traffic_unit": "HBM-side bytes per launch, rocprofv3 PMC (profiles/r01_pmc_traffic.json)",
+                    "traffic_unit": f"HBM-side bytes per launch, rocprofv3 PMC (profiles/{pmc_file})",
                     "launches": c["launches"],
                     "avg_us": round(c["avg_us"], 2), "algorithmic_work_per_launch": round(c["work"] / c["launches"])}
         mf = args.dtype == "bf16"

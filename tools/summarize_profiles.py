@@ -31,7 +31,13 @@ def short(name):
 
 KEYS = [("conv_fprop_row3_kernel<4, 4>", "conv_fprop_row3/bf16"), ("conv_fprop_row3_kernel<2, 2>", "conv_fprop_row3n/bf16"), ("conv_fprop_pp_kernel", "conv_fprop_pp/bf16"), ("conv_fprop_kernel<unsigned short, true>", "conv_fprop_dma/bf16"),
         ("conv_fprop_kernel<unsigned short, false>", "conv_fprop_reg/bf16"),
+        ("conv_wgrad_row3_kernel", "conv_wgrad_row3/bf16"),
         ("conv_wgrad_kernel<unsigned short", "conv_wgrad/bf16"),
+        ("nl_attn_fwd_kernel<unsigned short", "nl_attention_fwd/bf16"),
+        ("nl_attn_bwd_q_kernel<unsigned short", "nl_attention_bwd_q/bf16"),
+        ("nl_attn_bwd_kv_kernel<unsigned short", "nl_attention_bwd_kv/bf16"),
+        ("mbstd_fwd_kernel<unsigned short", "mbstd_fwd/bf16"),
+        ("mbstd_bwd_kernel<unsigned short", "mbstd_bwd/bf16"),
         ("upfirdn2d_vec_kernel<unsigned short, 1, 1", "upfirdn2d/bf16/up1down1/vec"),
         ("blur_sep_kernel<unsigned short, 32, 4, true>", "upfirdn2d/bf16/up1down1/sep+act"),
         ("blur_sep_kernel<unsigned short, 16, 4, true>", "upfirdn2d/bf16/up1down1/sep+act"),

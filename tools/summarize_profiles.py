@@ -25,7 +25,7 @@ def bench_line(path):
 
 
 def short(name):
-    name = name.replace("at::native::", "").replace("unsigned short", "bf16")
+    name = name.replace("at::native::", "").replace("(anonymous namespace)::", "").replace("unsigned short", "bf16")
     return re.sub(r"\(.*", "", name)[:110]
 
 

@@ -719,6 +719,17 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):
     return _ConvF.apply(x, weight, None if bias is None else bias.float(), g)
 
 
+def conv_transpose2d_2x2(x, weight, bias=None, wscale=1.0):
+    """F.conv_transpose2d(x, wscale * weight, bias, stride=2, padding=0) for a 2x2 kernel, weight [I, O, 2, 2] (torch's
+    transposed-conv layout): the non-overlapping case, four sub-pixel 1x1 contractions written pixel-shuffled (the
+    'up2' geometry of the generator's up-convs, with shared weights)."""
+    if tuple(weight.shape[2:]) != (2, 2):
+        raise _lib.MsgHipError("conv_transpose2d_2x2: 2x2 kernel, stride 2, padding 0 only")
+    g = Geometry("up2", 2, 2, 1, 1, x.shape[2:], False, wscale)
+    y = _ConvF.apply(x, weight.transpose(0, 1), None, g)
+    return y if bias is None else y + bias.view(1, -1, 1, 1).to(y.dtype)
+
+
 _LINEAR_MAX_ROWS = 256        # above this the batch rows are worth an MFMA tile: the conv path takes over
 
 

@@ -44,6 +44,66 @@ class EqualizedConv2d(nn.Module):
                                         scale=activation.scale, grad_slot=grad_slot)
 
 
+class EqualizedTransposedConv2d(nn.Module):
+    """Reference equalized_layer.py:77-143 (weight [in, out, kh, kw], bias initialised to ones).  Not instantiated by
+    the generator or the discriminator; provided for the public surface in the form the reference's defaults use --
+    kernel 2, stride 2, padding 0, the non-overlapping transposed conv -- on the sub-pixel contraction kernels.  Other
+    geometries raise."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: Union[int, Tuple[int, int]] = 2,
+                 stride: Union[int, Tuple[int, int]] = 2, padding: Union[int, Tuple[int, int]] = 0,
+                 bias: bool = True) -> None:
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.weight = nn.Parameter(torch.randn(in_channels, out_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.ones(out_channels)) if bias else None
+        self.scale = math.sqrt(2.0) / math.sqrt(in_channels * self.kernel_size[0] * self.kernel_size[1])
+        self.scale_bias = math.sqrt(2.0) / math.sqrt(out_channels)
+
+    def extra_repr(self):
+        i, o, kh, kw = self.weight.shape
+        return f"{o}, {i}, kernel_size=({kh}, {kw}), stride={self.stride}, padding={self.padding}, " \
+               f"bias={self.bias is not None}"
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if self.kernel_size != (2, 2) or self.stride != (2, 2) or self.padding != (0, 0):
+            from ._lib import MsgHipError
+            raise MsgHipError("EqualizedTransposedConv2d: only kernel_size 2, stride 2, padding 0 is implemented")
+        b = None if self.bias is None else self.bias * self.scale_bias
+        return conv_ops.conv_transpose2d_2x2(conv_ops.to_compute_layout(input), self.weight, b, wscale=self.scale)
+
+
+class EqualizedConv1d(nn.Module):
+    """Reference equalized_layer.py:146-207 (weight [out, in, k], bias initialised to ones).  Not instantiated by the
+    models; runs as a 1x1 contraction over the tap-gathered signal (k shifted, strided views stacked along the
+    channels), the form the few-channel 2-D convs use."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1, padding: int = 1,
+                 bias: bool = True) -> None:
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, kernel_size))
+        self.bias = nn.Parameter(torch.ones(out_channels)) if bias else None
+        self.scale = math.sqrt(2.0) / math.sqrt(in_channels * kernel_size)
+        self.scale_bias = math.sqrt(2.0) / math.sqrt(out_channels)
+
+    def extra_repr(self):
+        o, i, k = self.weight.shape
+        return f"{i}, {o}, kernel_size={k}, stride={self.stride}, padding={self.padding}, bias={self.bias is not None}"
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        bsz, channels, length = input.shape
+        k, s, p = self.kernel_size, self.stride, self.padding
+        out_len = (length + 2 * p - k) // s + 1
+        padded = torch.nn.functional.pad(input, (p, p))
+        taps = torch.cat([padded[:, :, t:t + s * (out_len - 1) + 1:s] for t in range(k)], dim=1)    # [B, k*C, L_out]
+        weight = self.weight.permute(0, 2, 1).reshape(self.weight.shape[0], k * channels, 1, 1)      # tap-major, as `taps`
+        b = None if self.bias is None else self.bias * self.scale_bias
+        y = conv_ops.conv2d(conv_ops.to_compute_layout(taps.unsqueeze(2)), weight, b, stride=1, padding=0,
+                            wscale=self.scale)
+        return y.squeeze(2)
+
+
 class EqualizedLinear(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, bias: bool = True) -> None:
         super().__init__()

@@ -132,6 +132,21 @@ def equalized_conv2d(x, weight, bias=None, stride=1, padding=0):
     return F.conv2d(x, weight * s_w, b, stride=stride, padding=padding)
 
 
+def equalized_conv_transpose2d(x, weight, bias=None, stride=2, padding=0):
+    """equalized_layer.py:127-143: F.conv_transpose2d with W * sqrt(2 / (in * kh * kw)), b * sqrt(2 / out); weight
+    [in, out, kh, kw]."""
+    scale = math.sqrt(2.0) / math.sqrt(weight.shape[0] * weight.shape[2] * weight.shape[3])
+    b = None if bias is None else bias * (math.sqrt(2.0) / math.sqrt(weight.shape[1]))
+    return F.conv_transpose2d(x, weight * scale, b, stride=stride, padding=padding)
+
+
+def equalized_conv1d(x, weight, bias=None, stride=1, padding=1):
+    """equalized_layer.py:192-207: F.conv1d with W * sqrt(2 / (in * k)), b * sqrt(2 / out); weight [out, in, k]."""
+    scale = math.sqrt(2.0) / math.sqrt(weight.shape[1] * weight.shape[2])
+    b = None if bias is None else bias * (math.sqrt(2.0) / math.sqrt(weight.shape[0]))
+    return F.conv1d(x, weight * scale, b, stride=stride, padding=padding)
+
+
 def pixel_norm(x, alpha: float = 1e-8):
     """equalized_layer.py:276."""
     return x / torch.sqrt(torch.mean(x * x, dim=1, keepdim=True) + alpha)

@@ -536,3 +536,30 @@ def test_conv_kernels_are_race_free(shape):
     for _ in range(12):
         again = conv_ops._f_raw(x, w, None, geo)
         assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_equalized_transposed_conv_and_conv1d_golden(golden, dtype):
+    """EqualizedTransposedConv2d (kernel 2, stride 2: the reference's defaults) and EqualizedConv1d (reference
+    equalized_layer.py:77-207; not instantiated by G / D) against golden vectors from the reference's classes: output,
+    input gradient, weight gradient.  Other transposed-conv geometries are refused, not approximated."""
+    from multi_stylegan_amd import _lib, equalized_layer as E
+    z = golden("layers")
+    tol = TOLS[dtype] * (3 if dtype == torch.float32 else 1)
+    cases = (("eqconvT2x2", E.EqualizedTransposedConv2d(6, 10, kernel_size=2, stride=2, padding=0)),
+             ("eqconv1d", E.EqualizedConv1d(6, 10, kernel_size=3, stride=1, padding=1)),
+             ("eqconv1d_s2", E.EqualizedConv1d(6, 10, kernel_size=5, stride=2, padding=2)))
+    for name, mod in cases:
+        assert float(mod.bias.detach()[0]) == 1.0                       # the reference initialises these biases to ones
+        with torch.no_grad():
+            mod.weight.copy_(z[name + ".w"]); mod.bias.copy_(z[name + ".b"])
+        mod.to(DEV)
+        x = z[name + ".x"].to(DEV, dtype).requires_grad_(True)
+        y = mod(x)
+        assert y.shape == z[name + ".y"].shape
+        gx, gw = torch.autograd.grad(y, (x, mod.weight), z[name + ".gy"].to(DEV, dtype))
+        assert rel_err(y.float(), z[name + ".y"]) < tol, name
+        assert rel_err(gx.float(), z[name + ".gx"]) < tol, name
+        assert rel_err(gw.float(), z[name + ".gw"]) < tol, name
+    with pytest.raises(_lib.MsgHipError, match="only kernel_size 2"):
+        E.EqualizedTransposedConv2d(6, 10, kernel_size=3, stride=2, padding=1).to(DEV)(torch.zeros(1, 6, 4, 4, device=DEV))

@@ -85,6 +85,13 @@ def test_small_layers(golden):
         gx, gw = torch.autograd.grad(y, (x, w), z[name + ".gy"])
         assert rel_err(y, z[name + ".y"]) < TOL and rel_err(gx, z[name + ".gx"]) < TOL
         assert rel_err(gw, z[name + ".gw"]) < TOL
+    # the two layers of the public surface that the models do not instantiate (equalized_layer.py:77-207)
+    for name, fn in (("eqconvT2x2", oo.equalized_conv_transpose2d), ("eqconv1d", oo.equalized_conv1d),
+                     ("eqconv1d_s2", lambda a, w, b: oo.equalized_conv1d(a, w, b, stride=2, padding=2))):
+        x, w = z[name + ".x"].requires_grad_(True), z[name + ".w"].requires_grad_(True)
+        y = fn(x, w, z[name + ".b"])
+        gx, gw = torch.autograd.grad(y, (x, w), z[name + ".gy"])
+        assert rel_err(y, z[name + ".y"]) < TOL and rel_err(gx, z[name + ".gx"]) < TOL and rel_err(gw, z[name + ".gw"]) < TOL
     assert rel_err(oo.pixel_norm(z["pixelnorm.x"]), z["pixelnorm.y"]) < TOL
     assert rel_err(oo.minibatch_stddev(z["mbstd.x"]), z["mbstd.y"]) < TOL
     for name, blk in (("nonlocal", om.NonLocalBlock(8, 16)), ("resnet_mbstd", om.ResNetBlock(8, 12, True))):

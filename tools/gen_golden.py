@@ -220,6 +220,22 @@ def gen_layers(ref, om, oracle_ops, store):
                       f"{name}.cfg": np.array([kw["stride"][0], kw["padding"][0]])})
         if conv.bias is not None:
             store[f"{name}.b"] = npy(conv.bias)
+    for name, mod, x, fn in (
+            ("eqconvT2x2", E.EqualizedTransposedConv2d(6, 10, kernel_size=2, stride=2, padding=0, bias=True),
+             torch.randn(2, 6, 5, 7, generator=g), oracle_ops.equalized_conv_transpose2d),
+            ("eqconv1d", E.EqualizedConv1d(6, 10, kernel_size=3, stride=1, padding=1, bias=True),
+             torch.randn(2, 6, 11, generator=g), oracle_ops.equalized_conv1d),
+            ("eqconv1d_s2", E.EqualizedConv1d(6, 10, kernel_size=5, stride=2, padding=2, bias=True),
+             torch.randn(2, 6, 12, generator=g), lambda a, w, b: oracle_ops.equalized_conv1d(a, w, b, stride=2, padding=2))):
+        with torch.no_grad():
+            mod.bias.copy_(torch.randn(mod.bias.shape, generator=g))
+        x.requires_grad_(True)
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=g)
+        gx, gw = torch.autograd.grad(y, (x, mod.weight), gy)
+        close(fn(x, mod.weight, mod.bias), y, what=name)
+        store.update({f"{name}.x": npy(x), f"{name}.w": npy(mod.weight), f"{name}.b": npy(mod.bias), f"{name}.y": npy(y),
+                      f"{name}.gy": npy(gy), f"{name}.gx": npy(gx), f"{name}.gw": npy(gw)})
     x = torch.randn(3, 16, generator=g)
     y = E.PixelwiseNormalization()(x)
     close(oracle_ops.pixel_norm(x), y, what="pixelnorm")

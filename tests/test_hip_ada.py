@@ -161,3 +161,35 @@ def test_trainer_with_ada(golden, tmp_path):
     tr3.load_checkpoint(path)
     for (n, a), (_, b) in zip(d.state_dict().items(), d3.state_dict().items()):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("padding,align", [(2, True), (0, False), (0, True), (2, False)])
+def test_affine_warp_random_geometry(padding, align):
+    """msg_affine_warp one stage at a time against oracle.ada.warp_affine (torch affine_grid + grid_sample) over random
+    non-square images, centres, angles, anisotropic scales from 0.4 to 2.5, with every image selected and with a random
+    subset selected; forward and the gradient of a random cotangent."""
+    from multi_stylegan_amd.adaptive_discriminator_augmentation import affine_warp
+    gen = torch.Generator().manual_seed(7 + padding + int(align))
+    mode = "reflection" if padding == 2 else "zeros"
+    for trial in range(6):
+        n, c = int(torch.randint(1, 7, (1,), generator=gen)), int(torch.randint(1, 7, (1,), generator=gen))
+        h, w = int(torch.randint(5, 40, (1,), generator=gen)), int(torch.randint(5, 40, (1,), generator=gen))
+        x = torch.rand(n, c, h, w, generator=gen)
+        angle = (torch.rand(n, generator=gen) - 0.5) * 360.0
+        scale = 0.4 + 2.1 * torch.rand(n, 2, generator=gen)
+        center = (float(torch.rand(1, generator=gen)) * w, float(torch.rand(1, generator=gen)) * h)
+        u = torch.rand(n, generator=gen)
+        p = 1.0 if trial % 2 == 0 else 0.5
+        sel = u <= p
+        m = oa.rotation_matrix2d(torch.tensor([center]).expand(n, 2), angle, scale)
+        xr = x.clone().requires_grad_(True)
+        warped = oa.warp_affine(xr, m, mode, align)
+        want = torch.where(sel.view(n, 1, 1, 1), warped, xr)
+        gy = torch.randn(want.shape, generator=gen)
+        want.backward(gy)
+        xd = x.to(DEV).requires_grad_(True)
+        got = affine_warp(xd, u.to(DEV), torch.tensor(p, device=DEV), angle=angle.to(DEV), scale=scale.to(DEV),
+                          center=center, padding=padding, align_corners=align)
+        got.backward(gy.to(DEV))
+        assert rel_err(got, want) < 5e-4, (trial, n, c, h, w, rel_err(got, want))
+        assert rel_err(xd.grad, xr.grad) < 2e-3, (trial, rel_err(xd.grad, xr.grad))

@@ -173,3 +173,34 @@ def test_fused_minibatch_stddev(shape, groups, dtype):
         x4 = conv_ops.to_compute_layout(x.to(DEV), dtype).requires_grad_(True)
         got2, = torch.autograd.grad(pen(mod, x4), x4)
         assert rel_err(got2, ref2) < (1e-3 if dtype == torch.float32 else 5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_attention_shape_sweep(dtype):
+    """Every combination of query / key counts that changes the launch structure (one or several key blocks, query
+    sweep split 1 / 2 / 4 ways, odd batch sizes), both head sizes, against the oracle."""
+    from multi_stylegan_amd import _lib
+    from multi_stylegan_amd.op_static import attention, non_local_attention
+    tf, tg = TOL[dtype]
+    seen_splits = set()
+    for (b, nq, nk, dk, dv) in ((1, 128, 128, 48, 192), (5, 1024, 128, 48, 192), (3, 2048, 256, 16, 64),
+                                (2, 4096, 128, 48, 192), (7, 640, 384, 16, 64), (1, 8192, 256, 48, 192)):
+        seen_splits.add(_lib.lib().msg_nonlocal_attention_bwd_splits(b, nq, nk))
+        q, k, v = _inputs(b, nq, nk, dk, dv, dtype, seed=b * nq + nk)
+        go = torch.randn(b, nq, dv, generator=torch.Generator().manual_seed(b)).to(dtype).float()
+        qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
+        want = _oracle(qc, kc, vc)
+        want.backward(go)
+        qd, kd, vd = (t.to(DEV, dtype).requires_grad_(True) for t in (q, k, v))
+        assert attention.supported(qd, kd, vd)
+        got = non_local_attention(qd, kd, vd)
+        got.backward(go.to(DEV, dtype))
+        assert rel_err(got, want) < tf, (b, nq, nk)
+        for a, r in ((qd.grad, qc.grad), (kd.grad, kc.grad), (vd.grad, vc.grad)):
+            assert rel_err(a, r) < tg, (b, nq, nk, rel_err(a, r))
+    assert {1, 2, 4} <= seen_splits or {1, 2, 8} <= seen_splits or len(seen_splits) >= 3, seen_splits
+    # shapes the kernels do not take fall back to the composite path, silently and correctly
+    q, k, v = _inputs(2, 100, 60, 24, 40, dtype, seed=1)
+    qd, kd, vd = (t.to(DEV, dtype) for t in (q, k, v))
+    assert not attention.supported(qd, kd, vd)
+    assert rel_err(non_local_attention(qd, kd, vd), _oracle(q, k, v)) < (1e-4 if dtype == torch.float32 else 3e-2)

@@ -172,6 +172,10 @@ def main():
 
     hp_lazy = trainer.hyperparameters["lazy_discriminator_regularization"]
 
+    # ADA augments the batch it is given IN PLACE (as the reference does, adaptive_discriminator_augmentation.py:64-68);
+    # a data loader hands out a fresh batch every step, so the resident synthetic batch is cloned per step (25 MB) then
+    batch_of = (lambda: real.clone()) if args.ada else (lambda: real)
+
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -186,10 +190,10 @@ def main():
             # of ms -- inside the timed region, where the regularisers still fire at their natural 1-in-16 cadence
             count = trainer.iteration
             trainer.iteration = hp_lazy - 1
-            trainer.train_iteration(real)
+            trainer.train_iteration(batch_of())
             trainer.iteration = count + 1
         else:
-            trainer.train_iteration(real)
+            trainer.train_iteration(batch_of())
         torch.cuda.synchronize(dev)
         note(f"warm-up iteration {i + 1} done")
     trainer.pop_logs()
@@ -199,7 +203,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_iteration(real)
+        trainer.train_iteration(batch_of())
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank = [elapsed]
@@ -217,7 +221,7 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for _ in range(n_off):
-            trainer.train_iteration(real)
+            trainer.train_iteration(batch_of())
         barrier()
         t_off = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t_off, op=torch.distributed.ReduceOp.MAX)

@@ -52,7 +52,7 @@ plain, prof = bench_line(os.path.join(src, "bench_plain.log")), bench_line(os.pa
 iters = prof["steps"] + prof["warmup"]
 with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` ({tag})\n\n")
-    f.write(f"1x MI355X, 256x256, batch 16, bf16; {iters} iterations in the trace.  Un-profiled run of the same command "
+    f.write(f"1x MI355X, {plain['config']['workload'].split(';')[0]}, {plain['dtype']}; {iters} iterations in the trace.  Un-profiled run of the same command "
             f"in the same gpurun call: {plain['value']} img/s ({plain['ms_per_step']} ms/step); under the profiler: "
             f"{prof['value']} img/s ({prof['ms_per_step']} ms/step).  Total kernel time {total / 1e9:.3f} s = "
             f"{total / 1e6 / iters:.1f} ms per iteration.\n\n")
@@ -81,7 +81,7 @@ for leg, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         traffic.setdefault(key, {})[leg] = (s, n)
 out = {"_about": "HBM-side traffic per launch from rocprofv3 PMC counters, one pass per counter (FETCH_SIZE; WRITE_SIZE) with "
                  "--kernel-trace only, command `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-clock` "
-                 "(1x MI355X, 256^2, batch 16, bf16; averaged over every launch of the kernel in the run).  FETCH_SIZE [KiB] "
+                 f"(1x MI355X, {plain['config']['workload'].split(';')[0]}; averaged over every launch of the kernel in the run).  FETCH_SIZE [KiB] "
                  "is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B); WRITE_SIZE is exact.",
        "tag": tag, "kernels": {}}
 for key, legs in traffic.items():

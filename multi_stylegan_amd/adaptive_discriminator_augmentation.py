@@ -122,7 +122,11 @@ class AdaptiveDiscriminatorAugmentation(nn.Module):
     """Wraps a discriminator (reference :11-96): augments its input with probability ``p`` and adapts ``p`` so that the
     overfitting heuristic ``r = E[sign(D(fake))]`` stays at ``r_target``."""
 
-    supports_minibatch_groups = False        # real and fake batches are augmented (and counted) separately
+    # forward(cat([real, fake]), minibatch_groups=2): the two halves are augmented with their own draws, go through the
+    # discriminator as ONE batch with per-half minibatch statistics, and only the fake half feeds the controller --
+    # the same result as the reference's two calls (real, then fake) at the launch count of one
+    supports_minibatch_groups = True
+    augments_in_place = True
 
     def __init__(self, discriminator: nn.Module, r_target: float = 0.6, p_step: float = 5e-03, r_update: int = 8,
                  p_max: float = 0.8) -> None:
@@ -179,11 +183,7 @@ class AdaptiveDiscriminatorAugmentation(nn.Module):
                 self._r_sum = torch.zeros_like(self._r_sum)
                 self._r_count = 0
 
-    def forward(self, images: torch.Tensor, is_real: bool = False, is_cut_mix: bool = False,
-                draws: Optional[Dict[str, object]] = None, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
-        if is_cut_mix:
-            return self.discriminator(images, **kwargs)
-        self._p = self._p.to(images.device)
+    def _augment(self, images: torch.Tensor, draws) -> torch.Tensor:
         shape = images.shape
         flat = images.flatten(start_dim=1, end_dim=2).float()
         augmented = self.augmentation_pipeline(flat, self._p, draws).view(shape)
@@ -192,6 +192,24 @@ class AdaptiveDiscriminatorAugmentation(nn.Module):
             # batch afterwards in the same iteration (R1, CutMix) sees the augmented images
             with torch.no_grad():
                 images.copy_(augmented)
+        return augmented
+
+    def forward(self, images: torch.Tensor, is_real: bool = False, is_cut_mix: bool = False,
+                draws: Optional[Dict[str, object]] = None, minibatch_groups: int = 1, **kwargs
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        if is_cut_mix:
+            return self.discriminator(images, **kwargs)
+        self._p = self._p.to(images.device)
+        if minibatch_groups == 2:
+            half = images.shape[0] // 2
+            draws_real, draws_fake = draws if draws is not None else (None, None)
+            augmented = torch.cat([self._augment(images[:half], draws_real), self._augment(images[half:], draws_fake)])
+            prediction_scalar, prediction_pixel_wise = self.discriminator(augmented, minibatch_groups=2, **kwargs)
+            self._observe(prediction_scalar[half:].detach(), prediction_pixel_wise[half:].detach())
+            return prediction_scalar, prediction_pixel_wise
+        if minibatch_groups != 1:
+            raise ValueError("AdaptiveDiscriminatorAugmentation: one batch, or a (real, fake) pair with minibatch_groups=2")
+        augmented = self._augment(images, draws)
         prediction_scalar, prediction_pixel_wise = self.discriminator(augmented, **kwargs)
         if not is_real:
             self._observe(prediction_scalar.detach(), prediction_pixel_wise.detach())

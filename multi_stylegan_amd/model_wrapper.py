@@ -223,9 +223,14 @@ class ModelWrapper(object):
         if self.batch_discriminator_passes and real_images.shape == fake_images.shape:
             # D(real) and D(fake) of the reference (:272-275) as ONE batch of 2B with per-half minibatch statistics:
             # same result, half the launches, better-filled tiles on the low-resolution layers
-            both, both_px = D(torch.cat([real_images, fake_images.to(real_images.dtype)]), minibatch_groups=2)
+            both_in = torch.cat([real_images, fake_images.to(real_images.dtype)])
+            both, both_px = D(both_in, minibatch_groups=2)
             (real_prediction, fake_prediction) = both.split(batch)
             (real_prediction_pixel_wise, fake_prediction_pixel_wise) = both_px.split(batch)
+            if getattr(D, "augments_in_place", False):
+                # ADA rewrites its input batch with the augmented images (reference quirk): R1 and CutMix further down
+                # this iteration work on what the discriminator saw
+                real_images, fake_images = both_in[:batch], both_in[batch:]
         else:
             real_prediction, real_prediction_pixel_wise = D(real_images, is_real=True, is_cut_mix=False)
             fake_prediction, fake_prediction_pixel_wise = D(fake_images, is_real=False, is_cut_mix=False)

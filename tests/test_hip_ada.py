@@ -138,7 +138,7 @@ def test_trainer_with_ada(golden, tmp_path):
     g.load_state_dict(z.state_dict("tinyG.sd.")); d.load_state_dict(z.state_dict("tinyD.sd."))
     ada = m.AdaptiveDiscriminatorAugmentation(d, r_update=2)
     tr = m.ModelWrapper(g, ada, device=DEV)
-    assert not tr.batch_discriminator_passes
+    assert tr.batch_discriminator_passes          # real + fake as one batch through the wrapper
     tr.iteration = 14
     for _ in range(3):
         tr.train_iteration(torch.rand(4, 2, 3, 32, 32, device=DEV))
@@ -193,3 +193,29 @@ def test_affine_warp_random_geometry(padding, align):
         got.backward(gy.to(DEV))
         assert rel_err(got, want) < 5e-4, (trial, n, c, h, w, rel_err(got, want))
         assert rel_err(xd.grad, xr.grad) < 2e-3, (trial, rel_err(xd.grad, xr.grad))
+
+
+def test_wrapper_pair_forward_equals_two_calls(golden):
+    """forward(cat([real, fake]), minibatch_groups=2) == forward(real, is_real=True) then forward(fake): same
+    predictions on the same draws, the controller fed by the fake half only, both halves rewritten in place."""
+    import multi_stylegan_amd as m
+    from tools.gen_golden import TINY_D
+    _seed(9)
+    z = golden("tiny_models")
+    d = m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True)
+    d.load_state_dict(z.state_dict("tinyD.sd."))
+    d.to(DEV)
+    real, fake = torch.rand(3, 2, 3, 32, 32, device=DEV), torch.rand(3, 2, 3, 32, 32, device=DEV)
+    dr_r, dr_f = (_to_product_draws(oa.draw(3, 32, 32), DEV) for _ in range(2))
+    a1 = m.AdaptiveDiscriminatorAugmentation(d, r_update=1)
+    a1.p = 0.7
+    r1, f1 = real.clone(), fake.clone()
+    sr, pr = a1(r1, is_real=True, draws=dr_r)
+    sf, pf = a1(f1, is_real=False, draws=dr_f)
+    a2 = m.AdaptiveDiscriminatorAugmentation(d, r_update=1)
+    a2.p = 0.7
+    both = torch.cat([real, fake])
+    s2, p2 = a2(both, minibatch_groups=2, draws=(dr_r, dr_f))
+    assert rel_err(s2, torch.cat([sr, sf])) < 1e-5 and rel_err(p2, torch.cat([pr, pf])) < 1e-5
+    assert torch.equal(both[:3], r1) and torch.equal(both[3:], f1) and not torch.equal(r1, real)
+    assert a1.p == pytest.approx(a2.p) and len(a1.r_history) == len(a2.r_history) == 1

@@ -10,10 +10,12 @@
 // kw rows further down; only the 256 weight rows change per K-step.  Staging per K-step: 32 + 33/3 = 43 KiB instead of
 // 64.  (conv_wgrad_row3.hip does the same for the weight gradient.)
 //
-// Structure: 256 x 256 output tile, four waves with 128 x 128 wave tiles (256 accumulators in the unified VGPR/AGPR
-// file, one workgroup per CU), LDS-DMA staging through buffer descriptors, the K-step software-pipelined inside the wave
-// (fragment reads of sub-step kk+1 and the DMA of the next K-step / next activation tile between the MFMAs of sub-step
-// kk), one workgroup barrier per K-step -- the one-wave-per-SIMD design measured in round 1.  LDS: 2 activation buffers of 264 rows +
+// Structure: 256 x 256 output tile, four waves with 128 x 128 wave tiles (256 accumulators in the AGPR half of the
+// unified register file, one workgroup per CU), v_mfma_f32_16x16x32_bf16, LDS-DMA staging through buffer descriptors.
+// The K loop is software-pipelined inside the wave and scheduled by hand: one barrier per K-step placed in front of the
+// step's last sub-step, fragment reads / staging instructions / address arithmetic spread one or two per MFMA gap, the
+// four waves' staging instructions interleaved in time (per-wave instances of the loop), the three horizontal taps
+// unrolled (no branches in the loop); see the comments at the loop.  LDS: 2 activation buffers of 264 rows +
 // 2 weight buffers of 256 rows, 128-B rows with XOR-swizzled 16-B slots (130 KiB); the epilogue (transposed
 // accumulators, packed LDS writes, batched 16-B stores, optional fused activation / residual merge) reuses it.
 // An output tile is 256 consecutive pixels = one or more whole image-row segments (map width 64, 128, or a multiple of
@@ -21,6 +23,7 @@
 // p + kw + 2 s.
 #include "msg_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) char* lds_t;
@@ -36,10 +39,24 @@ struct ConvParamsR3 {
 constexpr int HROW = 128;
 constexpr int H_OOB = (int)0x80000000;
 
+#ifdef MSG_ROW3_STAMPS
+// diagnostic build only (tools/row3_stamps.py; never ship or benchmark it): cycle stamps of K-steps 9..11 of every wave
+// of the first 256 workgroups of sample 0
+__device__ unsigned long long g_row3_stamps[256 * 4 * 3 * 8];
+#define R3_STAMP(k) do { if (it >= 9 && it < 12 && L < 256 && blockIdx.z == 0 && lane == 0) { unsigned long long tt; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); \
+    g_row3_stamps[((L * 4 + wid_u) * 3 + (it - 9)) * 8 + (k)] = tt; } } while (0)
+extern "C" int msg_row3_debug_read(void* host_dst, int nbytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_row3_stamps), nbytes) == hipSuccess ? 0 : -1;
+}
+#else
+#define R3_STAMP(k) do {} while (0)
+#endif
+
 // MI / NCOLB = 32-row / 32-column blocks per wave (waves are 2 x 2): <4,4> the 256 x 256 tile with 128 x 128 wave tiles, one
 // workgroup per CU; <2,2> a 128 x 128 tile with 64 x 64 wave tiles and TWO workgroups per CU for layers with 128 / 384
 // output channels (<4,2>, 256 x 128 with one workgroup per CU, measured no better than the plain 128x128 kernel).
-template <int MI, int NCOLB>
+template <int MI, int NCOLB, bool S16>
 __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                                  bf16_t* __restrict__ y, const float* __restrict__ bias,
                                                                  ConvParamsR3 p) {
@@ -49,12 +66,23 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     constexpr int HM = 64 * MI, WM = 32 * MI;                         // tile rows, wave-tile rows
     constexpr int NAP = 2 * MI;                                       // activation pieces per wave and group (+ piece NAP: rows HM..HM+7, wave 0)
     constexpr int HA = (HM + 8) * HROW;                               // activation buffer
+#ifdef MSG_ROW3_NO_STAGGER
+    constexpr bool STAGGER = false;
+#else
+    constexpr bool STAGGER = MI == 4;
+#endif
     __shared__ __attribute__((aligned(16))) char smem[2 * HA + 2 * HB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wid_u = __builtin_amdgcn_readfirstlane(wid);
     const int wm = wid_u >> 1, wn = wid_u & 1;
-    const int lr = lane & 31, lh = lane >> 5;
+    // MFMA shape: v_mfma_f32_32x32x16_bf16 (a lane holds row lane & 31, 8 channels at 16-B slot lane >> 5 of a 16-channel
+    // sub-step) or, S16, v_mfma_f32_16x16x32_bf16 (row lane & 15, slot lane >> 4 of a 32-channel sub-step): the same LDS
+    // image, the same bytes read per K-step, and on real data the higher sustained clock
+    constexpr int BLK = S16 ? 16 : 32;                                // rows / columns of an MFMA block
+    constexpr int NSUB = S16 ? 2 : 4, SLOTS = S16 ? 4 : 2;            // sub-steps per K-step, 16-B slots per sub-step
+    constexpr int NA = WM / BLK, NB = WN / BLK;                       // blocks of a wave tile (NA == NB)
+    const int lr = lane & (BLK - 1), lh = lane / BLK;
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int n0 = (int)(L % p.n_tiles) * HN;
     const int m0 = (int)(L / p.n_tiles) * HM;
@@ -73,8 +101,12 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     const char* wb = (const char*)w + (p.per_sample ? (long long)bz * p.w_bstride * ESZ : 0);
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, 0x7ffffff0, 0x00020000);
-    int a_ih0[NAP + 1], a_b32[NAP + 1], a_sl[NAP + 1], va[NAP + 1], vb[NBP];
-    unsigned a_okmask = 0;
+    // Registers are what this kernel is short of (256 accumulators + two sets of fragments), so the staging state is
+    // kept small: per activation piece ONE offset (kernel row 0) + one shared word of flag bits, per weight piece
+    // nothing -- a wave's weight rows are 8 j + (lane >> 3), i.e. a uniform stride per piece (SGPR offset) and a swizzle
+    // term that only alternates with the parity of j.  (Eligibility: Cx a multiple of 64, N a multiple of the tile width.)
+    int a_b32[NAP + 1];
+    unsigned a_flags = 0;             // bit j: piece j's row is a pixel of the map; 9 + j: ... of its top row; 18 + j: ... bottom row
 #pragma unroll
     for (int j = 0; j < NAP + 1; ++j) {
         const int row = (j < NAP ? wid * (HM / 4) + 8 * j : HM) + (lane >> 3);    // row of the activation buffer
@@ -89,52 +121,56 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
         const int iw = ow + (pos == 0 ? -1 : (pos == seg + 1 ? 1 : 0));
         ok = ok & ((unsigned)iw < (unsigned)p.IW);
-        a_okmask |= (ok ? 1u : 0u) << j;
-        a_ih0[j] = oh - 1;
-        a_sl[j] = sl;
+        a_flags |= (ok ? 1u : 0u) << j | (oh == 0 ? 1u : 0u) << (9 + j) | (oh == p.IH - 1 ? 1u : 0u) << (18 + j);
         // offset of kernel row 0 (may be "negative" for the top image row: only used when that row is in range)
         a_b32[j] = (int)(((long long)b * p.x_bstride + sl * VEC) * ESZ) + ((oh - 1) * p.IW + iw) * p.Cx * ESZ;
-        va[j] = H_OOB;
-        if (j < NBP) {
-            const int wrow = wid * (WN / 2) + 8 * j + (lane >> 3);
-            const int n = n0 + wrow;
-            const int slb = slot_phys ^ ((wrow >> 1) & 7);
-            vb[j] = n < p.N ? (int)(((long long)n * 9 * p.Ck + slb * VEC) * ESZ) : H_OOB;
-        }
     }
-    const bool ragged = (p.Cx % BKE) != 0;
-    auto set_kh = [&](int kh) __attribute__((always_inline)) {                    // activation offsets of kernel row kh
-        const int tap_off = kh * p.IW * p.Cx * ESZ;
+    static_assert(NAP + 1 <= 9, "flag bits");
+    int vb2[2];                                                                   // weight offsets of pieces 0 and 1
 #pragma unroll
-        for (int j = 0; j < NAP + 1; ++j) {
-            const bool ok = ((a_okmask >> j) & 1u) & ((unsigned)(a_ih0[j] + kh) < (unsigned)p.IH);
-            va[j] = ok ? a_b32[j] + tap_off : H_OOB;
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int wrow = wid * (WN / 2) + 8 * j + (lane >> 3);
+        const int slb = slot_phys ^ ((wrow >> 1) & 7);
+        vb2[j] = (int)(((long long)(n0 + wrow) * 9 * p.Ck + slb * VEC) * ESZ);
+    }
+    const int w_piece2 = 16 * 9 * p.Ck * ESZ;                                     // two pieces = 16 weight rows further
+    unsigned a_bad = 0;                                                           // bit j: piece j reads zeros in the kernel row being loaded
+    int a_tap_off = 0;
+    auto set_kh = [&](int kh) __attribute__((always_inline)) {                    // activation rows of kernel row kh
+        a_tap_off = kh * p.IW * p.Cx * ESZ;
+        a_bad = ~a_flags | (kh == 0 ? a_flags >> 9 : 0u) | (kh == 2 ? a_flags >> 18 : 0u);
     };
     // activation piece j of (kh set by set_kh, chunk) into activation buffer `abuf`
     auto dma_a = [&](int j, int abuf, int chunk, bool live) __attribute__((always_inline)) {
         if (j == NAP && wid_u != 0) return;
-        const bool a_zero = !live | (ragged & (chunk * BKE + a_sl[j] * VEC + VEC > p.Cx));
+        const bool a_zero = !live | (((a_bad >> j) & 1u) != 0);
         lds_t la = (lds_t)(smem + abuf * HA + (j < NAP ? wid_u * (HM / 4) + 8 * j : HM) * HROW);
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass instantiates this template too: it must not see the device builtin)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, la, 16, a_zero ? H_OOB : va[j], chunk * HROW, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, la, 16, a_zero ? H_OOB : a_b32[j] + a_tap_off, chunk * HROW, 0, 0);
 #endif
     };
     // weight piece j of K-step (tap, chunk) into weight buffer `bbuf`
     auto dma_b = [&](int j, int bbuf, int tap, int chunk, bool live) __attribute__((always_inline)) {
         lds_t la = (lds_t)(smem + 2 * HA + bbuf * HB + (wid_u * (WN / 2) + 8 * j) * HROW);
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, la, 16, live ? vb[j] : H_OOB, (tap * p.n_chunks + chunk) * HROW, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, la, 16, live ? vb2[j & 1] : H_OOB,
+                                                 (tap * p.n_chunks + chunk) * HROW + (j >> 1) * w_piece2, 0, 0);
 #endif
     };
 
-    f32x16 acc[MI][NCOLB];
+    // (S16: the MFMAs are inline assembly with the accumulator as a tied AGPR operand -- through the builtin the compiler
+    // gave the 64 four-register accumulators a new destination at every MFMA and moved them back around the loop,
+    // hundreds of v_accvgpr moves per K-step.  What the compiler then no longer does is count hazard wait states for
+    // these MFMAs: their inputs come from ds_read (s_waitcnt, which it still places) and an accumulator is reused 63
+    // MFMAs later; the epilogue reads them after a barrier.)
+    typedef float accv_t __attribute__((ext_vector_type(S16 ? 4 : 16)));
+    accv_t acc[NA][NB];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NCOLB; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < (S16 ? 4 : 16); ++e) acc[i][j][e] = 0.f;
 
     // ---- prologue: activation tile of group 0 (kernel row 0, chunk 0), weights of K-step 0
     set_kh(0);
@@ -143,84 +179,203 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
 #pragma unroll
     for (int j = 0; j < NBP; ++j) dma_b(j, 0, 0, 0, true);
 
-    // cursors: current K-step = (kh, chunk, kw); the group being loaded = (kh_l, chunk_l)
-    int kh = 0, chunk = 0, kw = 0;
-    int kh_l = 0, chunk_l = 0;
-    // fragment addressing: activation row of output row (wm*128 + i*32 + lr), tap kw: + kw + 2 * segment
+    // fragment addressing: activation row of output row (wm*WM + i*32 + lr), tap kw: + kw + 2 * segment; the second 16-row
+    // block of a 32-row group (S16) is 16 rows further down: same swizzle term, a compile-time offset
     int seg_of[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) seg_of[i] = (wm * WM + i * 32) / seg;
     const int sxb = (lr >> 1) & 7;
     const int fb_base = 2 * HA + (wn * WN + lr) * HROW;
 
-    for (int it = 0; it < p.n_iters; ++it) {
-        // This wave's LDS-DMA for step `it` must have LANDED before the barrier: say so explicitly.  (The compiler's own
-        // wait in front of __syncthreads() is derived from alias analysis of the DMA destinations and was vmcnt(2) here --
-        // the last two pieces could still be in flight: a race that showed up as sporadically wrong output channels.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();      // all reads of the other buffers are done
-        const bool more = it + 1 < p.n_iters;
-        // next K-step's coordinates
-        int kw_n = kw + 1, chunk_n = chunk, kh_n = kh;
-        if (kw_n == 3) { kw_n = 0; if (++chunk_n == p.n_chunks) { chunk_n = 0; ++kh_n; } }
-        const int grp = it / 3;                                  // (uniform; it / 3 by multiply-shift)
-        const int abuf = grp & 1, bbuf = it & 1;
-        // at the first step of a group the NEXT group's activation tile starts loading
-        bool more_a = false;
-        if (kw == 0) {
-            chunk_l = chunk + 1; kh_l = kh;
-            if (chunk_l == p.n_chunks) { chunk_l = 0; ++kh_l; }
-            if (kh_l != kh && kh_l < 3) set_kh(kh_l);
-        }
-        more_a = kh_l < 3;
-        const char* sA = smem + abuf * HA;
-        const char* sB = smem + bbuf * HB;
+    // ---- the K loop.  K-step `it` = (kh, chunk, kw) multiplies from activation buffer (it / 3) & 1 and weight buffer
+    // it & 1 in NSUB sub-steps, fragments double-buffered in registers: every group of MFMAs (one activation block
+    // against all weight blocks) is followed by two fragment reads for the NEXT sub-step.  The workgroup barrier of a step
+    // sits in front of the MFMAs of its LAST sub-step: by then every wave holds the step's last fragments in registers, so
+    //   * after the barrier the step's weight buffer is free: the weights of step it + 2 start loading into it, and
+    //   * the first fragments of step it + 1 (landed: every wave waited for its own pieces before the barrier) are read
+    //     in the shadow of the last sub-step's MFMAs instead of in front of an idle MFMA pipe (in-kernel stamps,
+    //     tools/row3_stamps.py: barrier -> first MFMA of the next step was ~450 of a step's ~3300 cycles).
+    // A "period" (barrier to barrier) is therefore the last sub-step of one step + the others of the next = NSUB * NA
+    // groups; its staging instructions are the NBP weight pieces of the step after next and -- in the period that
+    // ends in the first step of a (kh, chunk) group -- the NAP (+1) activation pieces of the next group, which have
+    // two more periods to land: the wait in front of the barrier leaves exactly those in flight.
+    // WV >= 0 (the 256 x 256 tile): the loop is instantiated once per wave of the workgroup and wave WV issues ONE
+    // staging instruction per group, a quarter of a group after the previous wave's, so that the CU's vector-memory port
+    // sees one 1-KiB piece every 32 cycles instead of four at a time (stamps: issued by all four waves at the same
+    // point, a piece costs each of them 50-70 cycles of MFMA issue; one wave at a time, nothing measurable).
+    // WV < 0 (the 128 x 128 tile, two workgroups per CU): two pieces per group from the start of the period.
+    struct Pos { int kh, chunk, kw; };
+    auto k_loop = [&](auto wv_tag) __attribute__((always_inline)) {
+        constexpr int WV = decltype(wv_tag)::value;
+        constexpr int RPG = 3;                                      // fragment reads per group of MFMAs
+        constexpr int ACT_IN_FLIGHT = NAP + (WV == 0 ? 1 : 0);      // (WV < 0: wave 0 waits for its extra piece early)
+        bf16v8 fa[2][NA], fb[2][NB];
         int a_row[MI], a_sx[MI];
+        auto frag_row = [&](int i, int kw_, int buf, int& row, int& sx) __attribute__((always_inline)) {
+            const int r = wm * WM + i * 32 + lr + kw_ + 2 * seg_of[i];
+            row = buf * HA + r * HROW;                              // (byte offset in smem, buffer included)
+            sx = (r >> 1) & 7;
+        };
+        auto read_a = [&](int sub, int ia) __attribute__((always_inline)) {
+            const int i32 = ia * BLK / 32, extra = (ia * BLK % 32) * HROW;
+            fa[sub & 1][ia] = *reinterpret_cast<const bf16v8*>(smem + a_row[i32] + extra + (((SLOTS * sub + lh) ^ a_sx[i32]) << 4));
+        };
+        auto read_b = [&](int sub, int jb, const char* sB) __attribute__((always_inline)) {
+            fb[sub & 1][jb] = *reinterpret_cast<const bf16v8*>(sB + fb_base + jb * BLK * HROW + (((SLOTS * sub + lh) ^ sxb) << 4));
+        };
+        // the t-th fragment read for a sub-step, in the order its MFMAs need them: the first group takes ALL weight
+        // fragments but only the first activation fragment
+        auto read_nth = [&](int sub, int t, const char* sB) __attribute__((always_inline)) {
+            if (t == 0) read_b(sub, 0, sB);
+            else if (t == 1) read_a(sub, 0);
+            else if (t <= NB) read_b(sub, t - 1, sB);
+            else read_a(sub, t - NB);
+        };
+        auto mfma = [&](int set, int ia, int jb) __attribute__((always_inline)) {   // operands swapped: transposed accumulators (see the epilogue)
+            if constexpr (S16) {
+                accv_t& c = acc[ia][jb];
+                const bf16v8& wf = fb[set][jb];
+                const bf16v8& xf = fa[set][ia];
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wf), "v"(xf));
+#endif
+            } else {
+                acc[ia][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][jb], fa[set][ia], acc[ia][jb], 0, 0, 0);
+            }
+        };
+        int kh = 0, chunk = 0;                                      // the (kh, chunk) group of the current K-step
+        int kh_l = 0, chunk_l = 0;                                  // the next group = the one whose activation tile loads
+        int abuf = 0;
+        // weight pieces of a period: slot ps (one group of MFMAs), after MFMA j of the group
+        auto weights_at = [&](int ps, int j, int bufw, Pos q, bool live) __attribute__((always_inline)) {
+            if (WV >= 0) { if (j == WV * (NB / 4) && ps < NBP) dma_b(ps, bufw, q.kh * 3 + q.kw, q.chunk, live); }
+            else if (j == NB - 1) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = wm * WM + i * 32 + lr + kw + 2 * seg_of[i];
-            a_row[i] = r * HROW;
-            a_sx[i] = (r >> 1) & 7;
-        }
-        bf16v8 fa[2][MI], fb[2][NCOLB];
+                for (int t = 0; t < 2; ++t) if (2 * ps + t < NBP) dma_b(2 * ps + t, bufw, q.kh * 3 + q.kw, q.chunk, live);
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < MI; ++t) fa[0][t] = *reinterpret_cast<const bf16v8*>(sA + a_row[t] + ((lh ^ a_sx[t]) << 4));
+        for (int i = 0; i < MI; ++i) frag_row(i, 0, 0, a_row[i], a_sx[i]);
 #pragma unroll
-        for (int t = 0; t < NCOLB; ++t)
-            fb[0][t] = *reinterpret_cast<const bf16v8*>(sB + fb_base + t * 32 * HROW + ((lh ^ sxb) << 4));
+        for (int t = 0; t < NA + NB; ++t) read_nth(0, t, smem);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int ps = 0; ps < NA; ++ps)                             // the pieces a period issues behind its barrier
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
+            for (int j = 0; j < NB; ++j) weights_at(ps, j, 1, Pos{0, 0, 1}, true);
+
+        // One K-step, the horizontal tap KW a compile-time constant: the loop below runs the three steps of a (kh, chunk)
+        // group back to back, so that "this period carries the activation pieces" (KW == 0) and the count the wait leaves
+        // in flight cost no branches (a skipped scalar branch per piece slot cost ~30 cycles of MFMA issue each).
+        auto k_step = [&](auto kw_tag, int it) __attribute__((always_inline)) {
+            constexpr int KW = decltype(kw_tag)::value;
+            R3_STAMP(0);
+            const int bbuf = it & 1;
+            const bool live1 = it + 1 < p.n_iters, live2 = it + 2 < p.n_iters;
+            const int abuf_n = KW == 2 ? abuf ^ 1 : abuf;           // activation buffer of step it + 1
+            if (KW == 0) {                                          // the next group's activation tile loads in this period
+                chunk_l = chunk + 1; kh_l = kh;
+                if (chunk_l == p.n_chunks) { chunk_l = 0; ++kh_l; }
+                if (kh_l != kh && kh_l < 3) set_kh(kh_l);
+            }
+            const bool more_a = kh_l < 3;
+            const Pos n1 = KW < 2 ? Pos{kh, chunk, KW + 1} : Pos{kh_l, chunk_l, 0};
+            const Pos n2 = KW < 1 ? Pos{kh, chunk, 2} : Pos{kh_l, chunk_l, KW - 1};
+            constexpr bool ACTS = KW == 0;
 #pragma unroll
-                for (int j = 0; j < NCOLB; ++j)     // operands swapped: transposed accumulators (see the epilogue)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
-                if (kk + 1 < 4) {
-                    const int s2 = 2 * (kk + 1) + lh;
-                    fa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sA + a_row[i] + ((s2 ^ a_sx[i]) << 4));
-                    if (i < NCOLB) fb[(kk + 1) & 1][i] = *reinterpret_cast<const bf16v8*>(sB + fb_base + i * 32 * HROW + ((s2 ^ sxb) << 4));
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const bool tail = sub == NSUB - 1;
+                if (tail) {
+                    // Before the barrier: this wave's own pieces for step it + 1 have LANDED (an explicit count -- the
+                    // compiler's own wait is derived from alias analysis of the DMA destinations and once left two pieces
+                    // in flight: sporadically wrong output channels) and its fragment reads of this step are done.
+                    if (ACTS) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(ACT_IN_FLIGHT) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    R3_STAMP(4);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_barrier" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    R3_STAMP(5);
+                    abuf = abuf_n;                                  // from here on the fragment reads are step it + 1's
                 }
-                // Staging instructions of the K-step -- NBP weight pieces of the next K-step, then (first K-step of a group)
-                // the activation pieces of the next group -- two per group of NCOLB MFMAs, from the START of the step: the earlier they
-                // are issued the more time the LDS-DMA has to land before the barrier.  (Measured on 3x3 512->512 @256^2:
-                // spread over the whole step 4290 us, one per group from the start 4180, two per group 4040, more: no gain.)
-                const int slot = kk * MI + i;
+                const char* sB = smem + (tail ? bbuf ^ 1 : bbuf) * HB;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int d = 2 * slot + q;
-                    if (d < NBP) dma_b(d, bbuf ^ 1, kh_n * 3 + kw_n, chunk_n, more);
-                    else if (d < NBP + NAP + 1) {
-                        // ALL activation pieces of the next group go out in the group's FIRST K-step: they come from
-                        // HBM rather than L2 and need the two remaining K-steps to land (spread three per K-step, the
-                        // last three had one K-step).  Small gain: 3x3 128->128 @256^2 476 -> 452 us, 512->512 @256^2 ~1 %
-                        if (kw == 0) dma_a(d - NBP, abuf ^ 1, chunk_l, more_a);
+                for (int ia = 0; ia < NA; ++ia) {
+                    const int ps = ((sub + 1) % NSUB) * NA + ia;    // slot of the period: the tail's groups come first
+                    // One MFMA, then what its gap carries (a sched_barrier per MFMA: the order written here is the order
+                    // issued).  An MFMA holds the SIMD's vector issue for 8 of its 32 / 16 cycles; what else the wave issues
+                    // is free only while it fits the rest, so the group's fragment reads, its staging instruction and the
+                    // address arithmetic are spread one or two per gap instead of clustered behind the group.
+#pragma unroll
+                    for (int jb = 0; jb < NB; ++jb) {
+                        mfma(sub & 1, ia, jb);
+                        // fragments of the next sub-step: RPG reads per group from the first group on (the compiler's
+                        // s_waitcnt in front of a sub-step's first group waits for ALL reads in flight, so the last ones
+                        // must be well ahead of it), read k of the group after MFMA 2 k (8-MFMA groups) or k
+#pragma unroll
+                        for (int k = 0; k < RPG; ++k) {
+                            const int t = RPG * ia + k;
+                            if (t < NA + NB && jb == (NB == 8 ? 2 * k : (k < NB ? k : NB - 1))) read_nth((sub + 1) % NSUB, t, sB);
+                        }
+                        // staging: wave WV's piece of the group after MFMA 2 WV + 1 (or WV); WV < 0: two at the group's end
+                        const int dj = NB == 8 ? (jb - 1) / 2 : jb;
+                        const bool dslot = WV >= 0 ? (NB == 8 ? (jb & 1) && dj == WV : dj == WV) : jb == NB - 1;
+                        if (dslot) {
+                            const int bufw = tail ? bbuf : bbuf ^ 1;
+                            const Pos q = tail ? n2 : n1;
+                            const bool live = tail ? live2 : live1;
+                            if (WV >= 0) {
+                                if (ps < NBP) dma_b(ps, bufw, q.kh * 3 + q.kw, q.chunk, live);
+                                else if (!tail && ACTS && ps - NBP < NAP) dma_a(ps - NBP, abuf ^ 1, chunk_l, more_a);
+                            } else {
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const int d = 2 * ps + t;
+                                    if (d < NBP) dma_b(d, bufw, q.kh * 3 + q.kw, q.chunk, live);
+                                    else if (!tail && ACTS && d - NBP < NAP + 1) dma_a(d - NBP, abuf ^ 1, chunk_l, more_a);
+                                }
+                            }
+                        }
+                        if (!tail && ACTS && WV == 0 && ps == NSUB * NA - 1 && jb == NB - 1) dma_a(NAP, abuf ^ 1, chunk_l, more_a);
+                        if (sub == NSUB - 2 && jb == NB - 1) {
+                            // Next step's fragment addresses, in place after the last read of this step that uses them, here
+                            // (VALU in the MFMAs' shadow) rather than behind the barrier.  Activation fragment f is read
+                            // t-th, t = 1 (f = 0) or NB + f, in group t / RPG; a 32-row group's address serves fragments
+                            // 32 / BLK * i32 ... 32 / BLK * (i32 + 1) - 1.
+#pragma unroll
+                            for (int i32 = 0; i32 < MI; ++i32) {
+                                const int f_last = (32 / BLK) * (i32 + 1) - 1;
+                                if ((f_last == 0 ? 1 : NB + f_last) / RPG == ia) {
+                                    frag_row(i32, (KW + 1) % 3, abuf_n, a_row[i32], a_sx[i32]);
+                                    asm volatile("" : "+v"(a_row[i32]), "+v"(a_sx[i32]));
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                R3_STAMP(tail ? 6 : 1 + sub);
             }
+            if (KW == 2) { kh = kh_l; chunk = chunk_l; }
+        };
+        for (int it = 0; it < p.n_iters; it += 3) {                 // (n_iters = 9 * n_chunks)
+            k_step(std::integral_constant<int, 0>{}, it);
+            k_step(std::integral_constant<int, 1>{}, it + 1);
+            k_step(std::integral_constant<int, 2>{}, it + 2);
         }
-        kw = kw_n; chunk = chunk_n; kh = kh_n;
+    };
+    if (STAGGER) {
+        switch (wid_u) {
+            case 0: k_loop(std::integral_constant<int, 0>{}); break;
+            case 1: k_loop(std::integral_constant<int, 1>{}); break;
+            case 2: k_loop(std::integral_constant<int, 2>{}); break;
+            default: k_loop(std::integral_constant<int, 3>{}); break;
+        }
+    } else {
+        k_loop(std::integral_constant<int, -1>{});
     }
+    if (S16) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // (the last inline-assembly MFMAs retire before anything reads them)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the dummy pieces of the last step write zeros: they must land first)
     __syncthreads();
 
@@ -229,11 +384,13 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     // 8-byte LDS write each; 8-byte unit u of row r lives at unit u ^ (r & 15).
     constexpr int PITCH = WN * ESZ;
     char* ep = smem + wid * (WM * PITCH);
+    // (S16: lane (lr, lh) owns pixel 16 i + lr and the four channels 16 j + 4 lh + (0..3) of block (i, j): G = 1 group)
+    constexpr int G = S16 ? 1 : 4;
 #pragma unroll
-    for (int j = 0; j < NCOLB; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int unit = 8 * j + 2 * g + lh;
+        for (int g = 0; g < G; ++g) {
+            const int unit = S16 ? 4 * j + lh : 8 * j + 2 * g + lh;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (bias) {
                 const int nb = n0 + wn * WN + 4 * unit;
@@ -241,8 +398,8 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                 for (int e = 0; e < 4; ++e) bv[e] = nb + e < p.N ? bias[nb + e] : 0.f;
             }
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int row = i * 32 + lr;
+            for (int i = 0; i < NA; ++i) {
+                const int row = i * BLK + lr;
                 uint2 pk;
                 pk.x = (unsigned)f2bf(acc[i][j][4 * g + 0] + bv[0]) | ((unsigned)f2bf(acc[i][j][4 * g + 1] + bv[1]) << 16);
                 pk.y = (unsigned)f2bf(acc[i][j][4 * g + 2] + bv[2]) | ((unsigned)f2bf(acc[i][j][4 * g + 3] + bv[3]) << 16);
@@ -340,7 +497,7 @@ extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int
                                               int kh, int kw, long long w_batch_stride) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("MSG_CONV_ROW3"); enabled = e ? atoi(e) : 1; }
-    if (!enabled || kh != 3 || kw != 3 || IH != OH || IW != OW || Ck % 64) return 0;
+    if (!enabled || kh != 3 || kw != 3 || IH != OH || IW != OW || Ck % 64 || Cx % 64) return 0;
     const bool per_sample = w_batch_stride != 0;
     const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;
     // The 128 x 128 variant (two workgroups per CU) takes the layers with 128 / 384 output channels from the plain 128x128
@@ -354,7 +511,7 @@ extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int
     if (w32 < 0) { const char* e = getenv("MSG_CONV_ROW3_W32"); w32 = e ? atoi(e) : 1; }
     int hn = row3_tile_columns(N);
     if (OW == 32 && w32 && N >= 128 && (long long)((N + 127) / 128) * 128 * 100 <= (long long)N * 115) hn = 128;
-    if (!hn || (hn == 128 && !narrow)) return 0;
+    if (!hn || (hn == 128 && !narrow) || N % hn) return 0;
     const int hm = hn;                             // square tiles: 256 x 256 or 128 x 128
     if (!((OW >= 64 && hm % OW == 0) || OW % hm == 0 || (OW == 32 && hm == 128))) return 0;   // whole image-row segments per tile, <= 8 halo rows
     if (mtot < 1024 || mtot >= (1ll << 31) || mtot % hm) return 0;
@@ -395,11 +552,17 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     p.n_tiles = (N + hn - 1) / hn;
     const long long blocks = (long long)p.m_tiles * p.n_tiles;
     dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);
-    if (hn == 256)
-        hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+    // MSG_CONV_ROW3_S16=0: the 256 x 256 tile on v_mfma_f32_32x32x16_bf16 (A/B)
+    static int s16 = -1;
+    if (s16 < 0) { const char* e = getenv("MSG_CONV_ROW3_S16"); s16 = e ? atoi(e) : 1; }
+    if (hn == 256 && s16)
+        hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)w, (bf16_t*)y, bias, p);
+    else if (hn == 256)
+        hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);
     else
-        hipLaunchKernelGGL((conv_fprop_row3_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+        hipLaunchKernelGGL((conv_fprop_row3_kernel<2, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);
     return 1;
 }

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a K-step of conv_fprop_row3_kernel<4,4> spends its cycles, from in-kernel s_memtime stamps.
+Build the stamped library first:  MSG_EXTRA_HIPCC_FLAGS=-DMSG_ROW3_STAMPS python -m multi_stylegan_amd.build --force
+(never ship or benchmark that build), then run this on the GPU box."""
+import ctypes, math, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_stylegan_amd import _lib, conv_ops
+if os.environ.get("MSG_LIB_VARIANT"):          # an ablation build kept beside the library (libmsg_hip_<variant>.so)
+    _lib.LIB_PATH = _lib.LIB_PATH.replace(".so", "_" + os.environ["MSG_LIB_VARIANT"] + ".so")
+b, i, o, r, k = 16, 512, 512, 256, 3
+x = torch.randn(b, i, r, r, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+w = torch.randn(b, o, i, k, k, device="cuda") / math.sqrt(i * k * k)
+wk, ck = conv_ops._relay_fwd(w, torch.bfloat16)
+for _ in range(200):          # long enough for the clock to settle
+    y = conv_ops._launch_fprop(x, wk, ck, None, o, (r, r), k, k, 1, 1, 1, False, True, i)
+torch.cuda.synchronize()
+h = ctypes.CDLL(_lib.LIB_PATH)
+buf = np.zeros(256 * 4 * 3 * 8, dtype=np.uint64)
+assert h.msg_row3_debug_read(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes) == 0
+s = buf.reshape(256, 4, 3, 8).astype(np.int64)
+s16 = os.environ.get("MSG_CONV_ROW3_S16", "1") != "0"
+# stamp slots: 0 step start | 1..3 after sub-steps 0..2 (not the last) | 4 after the wait | 5 after the barrier | 6 after the last sub-step
+order = [0, 1, 4, 5, 6] if s16 else [0, 1, 2, 3, 4, 5, 6]
+names = (["sub-step 0 (64 MFMAs)", "vmcnt/lgkmcnt wait", "barrier", "sub-step 1 (64 MFMAs) + next step's first reads"] if s16 else
+         ["kk=0", "kk=1", "kk=2", "vmcnt/lgkmcnt wait", "barrier", "kk=3 + next step's first reads"])
+d = np.diff(s[..., order], axis=3)
+n = len(names)
+for st, label in enumerate(("K-step 9  (kw=0: next activation tile issued)", "K-step 10 (kw=1)", "K-step 11 (kw=2)")):
+    print(label)
+    for nm, v, q in zip(names, np.median(d[:, :, st, :].reshape(-1, n), axis=0), np.percentile(d[:, :, st, :].reshape(-1, n), 90, axis=0)):
+        print(f"   {nm:48s} median {v:7.0f}   p90 {q:7.0f} cycles")
+    print(f"   whole step: median {np.median(s[:, :, st, 6] - s[:, :, st, 0]):.0f} cycles (2048 MFMA cycles)")
+    for w in range(4):
+        print(f"      wave {w}: " + " ".join(f"{v:6.0f}" for v in np.median(d[:, w, st, :], axis=0)))
+print("three steps, start to start:", np.median(s[:, :, 2, 0] - s[:, :, 0, 0]) / 2)

@@ -330,10 +330,10 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                                 else if (!tail && ACTS && ps - NBP < NAP) dma_a(ps - NBP, abuf ^ 1, chunk_l, more_a);
                             } else {
 #pragma unroll
-                                for (int t = 0; t < 2; ++t) {
-                                    const int d = 2 * ps + t;
-                                    if (d < NBP) dma_b(d, bufw, q.kh * 3 + q.kw, q.chunk, live);
-                                    else if (!tail && ACTS && d - NBP < NAP + 1) dma_a(d - NBP, abuf ^ 1, chunk_l, more_a);
+                                for (int t = 0; t < 2; ++t) {       // weights behind the barrier, activations from sub-step 0 on
+                                    static_assert(NBP <= 2 * NA, "weight pieces fit the last sub-step's groups");
+                                    if (tail) { if (2 * ps + t < NBP) dma_b(2 * ps + t, bufw, q.kh * 3 + q.kw, q.chunk, live); }
+                                    else if (ACTS && 2 * (ps - NA) + t < NAP + 1) dma_a(2 * (ps - NA) + t, abuf ^ 1, chunk_l, more_a);
                                 }
                             }
                         }
@@ -555,11 +555,16 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     // MSG_CONV_ROW3_S16=0: the 256 x 256 tile on v_mfma_f32_32x32x16_bf16 (A/B)
     static int s16 = -1;
     if (s16 < 0) { const char* e = getenv("MSG_CONV_ROW3_S16"); s16 = e ? atoi(e) : 1; }
+    static int s16n = -1;
+    if (s16n < 0) { const char* e = getenv("MSG_CONV_ROW3N_S16"); s16n = e ? atoi(e) : 1; }    // (the 128 x 128 tile: +2..6 %)
     if (hn == 256 && s16)
         hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);
     else if (hn == 256)
         hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)w, (bf16_t*)y, bias, p);
+    else if (s16n)
+        hipLaunchKernelGGL((conv_fprop_row3_kernel<2, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);
     else
         hipLaunchKernelGGL((conv_fprop_row3_kernel<2, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,

@@ -261,8 +261,8 @@ def main():
                     "avg_us": round(c["avg_us"], 2), "algorithmic_work_per_launch": round(c["work"] / c["launches"])}
         mf = args.dtype == "bf16"
         # (bf16: whichever of the two large-tile conv kernels spent more time in the timed region is the dominant one)
-        names = {"conv_fprop_row3": "conv_fprop_row3_kernel<4,4> (implicit-GEMM 3x3 conv fwd + data-grad, 256x256 tile, activation "
-                                    "tile shared by the three horizontal taps, MFMA 32x32x16 bf16)",
+        names = {"conv_fprop_row3": "conv_fprop_row3_kernel<4,4,true> (implicit-GEMM 3x3 conv fwd + data-grad, 256x256 tile, activation "
+                                    "tile shared by the three horizontal taps, MFMA 16x16x32 bf16)",
                  "conv_fprop_pp": "conv_fprop_pp_kernel (implicit-GEMM conv fwd + data-grad, 256x256 ping-pong tile, MFMA "
                                   "32x32x16 bf16)"}
         dom = max(names, key=lambda k: clock.get(f"{k}/{args.dtype}", {}).get("total_ms", 0.0))

@@ -318,6 +318,19 @@ int msg_linear_grouped_wgrad(const float* gy, const float* x, const int* slot, f
 int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                           int kh, int kw, long long w_batch_stride);
 
+/* ---------------------------------------------------------------------------
+ * Adam over a flat fp32 store, optionally with an exponential moving average of the stepped parameters in the same pass
+ * (replaces: torch.optim.Adam.step() at multi_stylegan/model_wrapper.py:296-300, :410-414 and
+ * misc.exponential_moving_average, multi_stylegan/misc.py -- ~400 small tensors per network each):
+ *   g = grad * coef[0] (coef: device scalar or NULL = 1);  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g^2;
+ *   param -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps);  ema = d ema + (1 - d) param (ema != NULL)
+ * All arrays n floats, 16-byte aligned; step >= 1 is the number of this update.  msg_flat_ema: the EMA alone.
+ * ------------------------------------------------------------------------- */
+int msg_flat_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, long long n,
+                  const float* coef, float lr, float beta1, float beta2, float eps, int step, float ema_decay,
+                  void* stream);
+int msg_flat_ema(float* ema, const float* param, long long n, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "msg_gather_taps": (_I, [_P, _P, _I] + [_I] * 9 + [_P]),
     "msg_scaled_add": (_I, [_P, _P, _P, _I, _L, _F, _F, _P]),
     "msg_scaled_add_rows": (_I, [_P, _P, _P, _I, _L, _I, _L, _L, _L, _F, _F, _P]),
+    "msg_flat_adam": (_I, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _P]),
+    "msg_flat_ema": (_I, [_P, _P, _L, _F, _P]),
     "msg_softmax_rows": (_I, [_P, _P, _I, _L, _I, _P]),
     "msg_softmax_rows_backward": (_I, [_P, _P, _P, _I, _L, _I, _P]),
     "msg_nonlocal_attention_supported": (_I, [_I] * 5),

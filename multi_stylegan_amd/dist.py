@@ -113,7 +113,9 @@ class GradBucketReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 overlap: bool = True, group=None):
+                 overlap: bool = True, group=None, split_key=None):
+        """``split_key(parameter)``: parameters with different keys never share a bucket (the trainer passes the
+        optimiser hyper-parameters, so that a bucket can be stepped by one launch -- multi_stylegan_amd.optim)."""
         params = [p for p in params if p.requires_grad]
         self.group, self.overlap = group, overlap
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -126,8 +128,9 @@ class GradBucketReducer:
         # gradients become ready roughly in reverse registration order: fill buckets from the back
         chunk, size = [], 0
         groups = []
+        key_of = split_key if split_key is not None else (lambda _p: None)
         for p in reversed(params):
-            if size and size + p.numel() > cap:
+            if size and (size + p.numel() > cap or key_of(p) != key_of(chunk[-1])):
                 groups.append(chunk); chunk, size = [], 0
             chunk.append(p); size += p.numel()
         if chunk:

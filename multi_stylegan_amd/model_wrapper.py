@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import dist as msg_dist
 from . import loss, misc
+from . import optim as msg_optim
 from .config import generation_hyperparameters
 from .u_net_2d_discriminator import generate_cut_mix_augmentation_data, generate_cut_mix_transformation_data
 
@@ -73,7 +74,8 @@ class ModelWrapper(object):
                  device: str = "cuda", lr_generator: float = 2e-4, lr_discriminator: float = 6e-4,
                  bucket_bytes: int = 32 << 20, overlap_communication: bool = True,
                  skip_discriminator_weight_grads_in_generator_step: bool = False,
-                 fused_optimizer: Optional[bool] = None, batch_discriminator_passes: bool = True) -> None:
+                 fused_optimizer: Optional[bool] = None, batch_discriminator_passes: bool = True,
+                 flat_optimizer_step: bool = True) -> None:
         self.device = torch.device(device)
         self.generator = generator.to(self.device)
         self.discriminator = discriminator.to(self.device)
@@ -104,9 +106,27 @@ class ModelWrapper(object):
             self.discriminator.parameters(), lr=lr_discriminator, betas=betas, fused=fused_optimizer)
         live = self.generator.live_parameters() if hasattr(self.generator, "live_parameters") \
             else list(self.generator.parameters())
-        self.generator_reducer = msg_dist.GradBucketReducer(live, bucket_bytes, overlap_communication)
+        def hyper_key(optimizer):
+            # parameters that are stepped with different hyper-parameters never share a gradient bucket
+            table = {id(p): (g["lr"] if not isinstance(g["lr"], torch.Tensor) else id(g), tuple(g.get("betas", ())),
+                             g.get("eps"), g.get("weight_decay", 0))
+                     for g in optimizer.param_groups for p in g["params"]}
+            return lambda p: table.get(id(p))
+        self.generator_reducer = msg_dist.GradBucketReducer(live, bucket_bytes, overlap_communication,
+                                                            split_key=hyper_key(self.generator_optimizer))
         self.discriminator_reducer = msg_dist.GradBucketReducer(self.discriminator.parameters(), bucket_bytes,
-                                                                overlap_communication)
+                                                                overlap_communication,
+                                                                split_key=hyper_key(self.discriminator_optimizer))
+        # Adam on flat stores (multi_stylegan_amd.optim): one launch per bucket instead of torch's multi-tensor step
+        self._flat: Dict[int, msg_optim.FlatAdam] = {}
+        if flat_optimizer_step and self.device.type == "cuda":
+            for opt, red in ((self.generator_optimizer, self.generator_reducer),
+                             (self.discriminator_optimizer, self.discriminator_reducer)):
+                if opt.defaults.get("fused") and msg_optim.FlatAdam.supported(opt, red):
+                    self._flat[id(opt)] = msg_optim.FlatAdam(opt, red)
+            g_flat = self._flat.get(id(self.generator_optimizer))
+            if g_flat is not None:
+                g_flat.attach_ema(self.generator_ema, self.generator)
         self.skip_d_wgrad = skip_discriminator_weight_grads_in_generator_step
         # only discriminators that know about minibatch groups (ours) can take the concatenated batch
         self.batch_discriminator_passes = batch_discriminator_passes and \
@@ -147,7 +167,8 @@ class ModelWrapper(object):
 
         ``self.step_trace`` (a dict, off by default) records the step for parity tests under ``<label>.``: the
         pre-clip mean gradient and the movement of every parameter the reducer owns, and the global gradient norm."""
-        fused = isinstance(optimizer, torch.optim.Adam) and bool(optimizer.defaults.get("fused"))
+        flat = self._flat.get(id(optimizer))
+        fused = flat is not None or (isinstance(optimizer, torch.optim.Adam) and bool(optimizer.defaults.get("fused")))
         # fused: buckets keep rank SUMS; `pending` = 1 / world is still to be applied
         pending = reducer.finish(average=not fused)
         trace = self.step_trace
@@ -159,12 +180,15 @@ class ModelWrapper(object):
         if fused:
             total = reducer.grad_norm() * pending          # norm of the mean gradient
             coef = torch.clamp(5.0 / (total + 1e-6), max=1.0) * pending
-            optimizer.grad_scale = (1.0 / coef).reshape(()).float()
-            optimizer.found_inf = torch.zeros((), dtype=torch.float32, device=total.device)
-            try:
-                optimizer.step()
-            finally:
-                del optimizer.grad_scale, optimizer.found_inf
+            if flat is None or not flat.step(coef):
+                if flat is not None:
+                    flat.release()
+                optimizer.grad_scale = (1.0 / coef).reshape(()).float()
+                optimizer.found_inf = torch.zeros((), dtype=torch.float32, device=total.device)
+                try:
+                    optimizer.step()
+                finally:
+                    del optimizer.grad_scale, optimizer.found_inf
         else:
             total = reducer.clip_(5.0)
             optimizer.step()
@@ -315,7 +339,11 @@ class ModelWrapper(object):
         # ---------------- EMA (reference :446)
         if self.step_trace is not None:
             ema_before = {n: p.detach().clone() for n, p in self.generator_ema.named_parameters()}
-        misc.exponential_moving_average(model_ema=self.generator_ema, model_train=self.generator)
+        g_flat = self._flat.get(id(self.generator_optimizer))
+        if g_flat is not None:
+            g_flat.ema_update(0.999)
+        else:
+            misc.exponential_moving_average(model_ema=self.generator_ema, model_train=self.generator)
         if self.step_trace is not None:
             for n, p in self.generator_ema.named_parameters():
                 self.step_trace[f"ema.delta.{n}"] = p.detach() - ema_before[n]
@@ -394,6 +422,8 @@ class ModelWrapper(object):
         self.discriminator.load_state_dict(_match_keys(checkpoint["discriminator"], self.discriminator))
         self.generator_optimizer.load_state_dict(checkpoint["generator_optimizer"])
         self.discriminator_optimizer.load_state_dict(checkpoint["discriminator_optimizer"])
+        for flat in self._flat.values():                 # the loaded moments and step counts go into the flat stores
+            flat.adopt()
         pl_state = checkpoint.get("path_length_regularization") or {}
         if "mean_path_length" in pl_state:
             self.path_length_regularization.mean_path_length = \

@@ -63,6 +63,11 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as f:
     for r in rows[:40]:
         f.write(f"| {float(r['Percentage']):.2f} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | "
                 f"{int(r['TotalDurationNs']) / 1e6 / iters:.2f} | `{short(r['Name'])}` |\n")
+    stock = sum(int(r["TotalDurationNs"]) for r in rows
+                if any(k in r["Name"] for k in ("at::native", "Cijk_", "rocprim", "__amd_rocclr")))
+    f.write(f"\nStock torch / library kernels (`at::native::*`, `Cijk_*`, rocprim, runtime fills): {stock / 1e6 / iters:.1f} ms per "
+            f"iteration = {100 * stock / total:.1f} % of kernel time (the regularised iterations in the trace run composite "
+            f"torch-op formulations for their second-order graphs).\n")
 import shutil
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 

@@ -541,7 +541,8 @@ class _ConvF(Function):
         g = ctx.g
         gx = _ConvD.apply(gy, w, g) if ctx.needs_input_grad[0] else None
         gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
-        gb = gy.float().sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        # (the cast inside the reduction: `gy.float()` materialised an fp32 copy of the whole map first)
+        gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb, None
 
 
@@ -584,11 +585,11 @@ class _ConvActF(Function):
     D / G contractions), so first- and second-order gradients are those of conv followed by FusedLeakyReLU."""
 
     @staticmethod
-    def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale, slot=None):
+    def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale, slot=None, out_scale=None):
         o = _oi(w)[0]
         b32, nz, nw = _act_operands(act_bias, noise, noise_w, (x.shape[0], o, *g.y_hw))
         y = _f_raw(x, w, None, g, act=(b32, nz, nw, alpha, scale))
-        ctx.slot = slot
+        ctx.slot, ctx.out_scale = slot, out_scale
         ctx.g, ctx.cfg = g, (alpha, scale, act_bias is not None, noise is not None)
         ctx.nw_shape = None if noise_w is None else noise_w.shape
         ctx.save_for_backward(x, w, y, noise)
@@ -600,7 +601,11 @@ class _ConvActF(Function):
         x, w, y, noise = ctx.saved_tensors
         alpha, scale, has_bias, has_noise = ctx.cfg
         g = ctx.g
-        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha, scale)
+        owed = 1.0
+        if ctx.out_scale is not None and ctx.out_scale.pending is not None:
+            owed, ctx.out_scale.pending = ctx.out_scale.pending, None        # (see GradScale: the consumer's gain, deferred)
+        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha,
+                                                             scale * owed)
         gx = None
         if ctx.needs_input_grad[0]:
             other = ctx.slot.g if ctx.slot is not None else None
@@ -614,7 +619,7 @@ class _ConvActF(Function):
                 gx = _ConvD.apply(gpre, w, g)
         gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
-            (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None
+            (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None, None
 
 
 class _ConvResidualF(Function):
@@ -623,9 +628,9 @@ class _ConvResidualF(Function):
     rescaled gradient goes to `main` as it is and through the D / G contractions to x and w."""
 
     @staticmethod
-    def forward(ctx, x, w, main, g, gain, fork, slot=None):
+    def forward(ctx, x, w, main, g, gain, fork, slot=None, main_scale=None):
         y = _f_raw(x, w, None, g, residual=(main, gain))
-        ctx.slot = slot
+        ctx.slot, ctx.main_scale = slot, main_scale
         ctx.g, ctx.gain, ctx.fork = g, float(gain), fork
         ctx.save_for_backward(x, w)
         return (y, y.view_as(y)) if fork else y
@@ -636,6 +641,19 @@ class _ConvResidualF(Function):
         x, w = ctx.saved_tensors
         g1 = grads[0]
         g2 = grads[1] if ctx.fork else None
+        if (g1 is None or g2 is None) and ctx.main_scale is not None and not torch.is_grad_enabled() and \
+                ctx.needs_input_grad[2]:
+            # one incoming gradient: nothing to add, and the rescaling is deferred -- `main`'s activation backward
+            # multiplies the gain in (GradScale), the two contractions take it through their weight scale
+            gs = g1 if g1 is not None else g2
+            ctx.main_scale.pending = ctx.gain
+            gg = Geometry(ctx.g.kind, ctx.g.kh, ctx.g.kw, ctx.g.stride, ctx.g.pad, ctx.g.x_hw, ctx.g.per_sample,
+                          ctx.g.wscale * ctx.gain)
+            gx = _ConvD.apply(gs, w, gg) if ctx.needs_input_grad[0] else None
+            if ctx.slot is not None and gx is not None:
+                ctx.slot.g = gx
+            gw = _ConvG.apply(gs, x, _oi(w), w.ndim, gg) if ctx.needs_input_grad[1] else None
+            return gx, gw, gs, None, None, None, None, None
         if g1 is None or g2 is None:
             gs = (g1 if g1 is not None else g2) * ctx.gain
         elif _rows_ok(g1, g2):
@@ -646,7 +664,19 @@ class _ConvResidualF(Function):
         if ctx.slot is not None and gx is not None and not torch.is_grad_enabled():
             ctx.slot.g = gx                  # the main branch's first conv adds it in its data-gradient epilogue
         gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g) if ctx.needs_input_grad[1] else None
-        return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None
+        return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None
+
+
+class GradScale:
+    """A gain that the consumer of an activation's output owes its gradient, handed to the activation's own backward
+    instead of being applied in a pass of its own: the residual merge y = (conv1x1(x) + main) * gain sends `main` the
+    gradient gy * gain; when `main` is the output of a fused conv + leaky ReLU whose ONLY consumer is that merge (the
+    discriminator block), the merge's backward passes gy on untouched and leaves `gain` here, and the activation
+    backward -- a pass over the same map anyway -- multiplies it in (its `scale` argument).  First-order only."""
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None
 
 
 class GradSlot:
@@ -695,20 +725,24 @@ def fork_input(x, slot: GradSlot):
     return _ForkInput.apply(x, slot)
 
 
-def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, fork=False, grad_slot=None):
-    """(conv(x, wscale * weight) + main) * gain; with fork=True two aliases of the result (see scaled_add_fork)."""
+def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, fork=False, grad_slot=None,
+                        main_grad_scale=None):
+    """(conv(x, wscale * weight) + main) * gain; with fork=True two aliases of the result (see scaled_add_fork).
+    ``main_grad_scale``: the GradScale that `main`'s producer was given (see there)."""
     s, p = _square(stride, "stride"), _square(padding, "padding")
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
-    return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork), grad_slot)
+    return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork), grad_slot, main_grad_scale)
 
 
 # ------------------------------------------------------------------------------------------------- public entry
 def conv2d_bias_act(x, weight, act_bias, stride=1, padding=0, wscale=1.0, negative_slope=0.2, scale=1.0,
-                    grad_slot=None):
-    """leaky_relu(conv(x, wscale * weight) + act_bias) * scale in one launch (EqualizedConv2d -> FusedLeakyReLU)."""
+                    grad_slot=None, out_grad_scale=None):
+    """leaky_relu(conv(x, wscale * weight) + act_bias) * scale in one launch (EqualizedConv2d -> FusedLeakyReLU).
+    ``out_grad_scale``: a GradScale shared with the output's only consumer (see there)."""
     s, p = _square(stride, "stride"), _square(padding, "padding")
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
-    return _ConvActF.apply(x, weight, act_bias, None, None, g, float(negative_slope), float(scale), grad_slot)
+    return _ConvActF.apply(x, weight, act_bias, None, None, g, float(negative_slope), float(scale), grad_slot,
+                           out_grad_scale)
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):

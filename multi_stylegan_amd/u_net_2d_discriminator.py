@@ -19,6 +19,7 @@ from .op_static import attention as _attention
 FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
 COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
 NATIVE_SOFTMAX = bool(int(os.environ.get("MSG_NATIVE_SOFTMAX", "1")))       # 0: ROCm library softmax in the non-local blocks (A/B)
+DEFER_MERGE_GAIN = bool(int(os.environ.get("MSG_DEFER_MERGE_GAIN", "1")))   # 0: the merge's backward rescales its gradient itself (A/B)
 FUSE_INPUT_FORK = bool(int(os.environ.get("MSG_FUSE_INPUT_FORK", "1")))     # 0: autograd adds a block input's two gradients (A/B)
 
 
@@ -168,12 +169,16 @@ class ResNetBlock(nn.Module):
             # the input's two gradients (main 3x3 conv, 1x1 residual conv) meet in the 3x3 conv's data-gradient epilogue
             slot = conv_ops.GradSlot()
             x_main, x_res = conv_ops.fork_input(input, slot)
-        output = conv2.forward_activated(conv1.forward_activated(x_main, act1, grad_slot=slot), act2)
+        # the merge's 1 / sqrt(2) on the main branch's gradient rides in act2's backward when the merge is the fused one
+        # and the block output has a single consumer (conv_ops.GradScale)
+        owed = conv_ops.GradScale() if fuse_res and DEFER_MERGE_GAIN and conv_ops.FUSE_ACTIVATION and \
+            merge is not scaled_add_fork and conv2.bias is None and input.is_cuda else None
+        output = conv2.forward_activated(conv1.forward_activated(x_main, act1, grad_slot=slot), act2, out_grad_scale=owed)
         if fuse_res and output.dtype == input.dtype:
             # (main + conv1x1(input)) / sqrt(2) in the epilogue of the 1x1 conv: no separate merge pass
             return conv_ops.conv2d_add_residual(x_res, res.weight, output, 1.0 / math.sqrt(2), stride=res.stride,
                                                 padding=res.padding, wscale=res.scale, fork=merge is scaled_add_fork,
-                                                grad_slot=slot)
+                                                grad_slot=slot, main_grad_scale=owed)
         return merge(output, res(x_res), 1.0 / math.sqrt(2))
 
 

@@ -44,12 +44,16 @@ def run(label, iters, force_reg):
     ours = stock = 0.0
     by = collections.Counter()
     calls = collections.Counter()
+    mine = collections.Counter()
+    mine_calls = collections.Counter()
     for e in prof.events():
         if e.device_type != torch.autograd.DeviceType.CUDA:
             continue
         t = e.device_time / 1e3 / iters
         if any(k in e.name for k in OURS):
             ours += t
+            mine[e.name[:90]] += t
+            mine_calls[e.name[:90]] += 1.0 / iters
         else:
             stock += t
             by[e.name[:130]] += t
@@ -58,6 +62,9 @@ def run(label, iters, force_reg):
           f"({100 * stock / (ours + stock):.1f} %) per iteration")
     for name, t in by.most_common(28):
         print(f"   {t:6.2f} ms  x{calls[name]:6.1f}  {name}")
+    if os.environ.get("MSG_SHOW_OURS"):
+        for name, t in mine.most_common(24):
+            print(f"   ours {t:6.2f} ms  x{mine_calls[name]:6.1f}  {name}")
 
 
 trainer.iteration = 16

@@ -510,6 +510,11 @@ extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int
     static int w32 = -1;
     if (w32 < 0) { const char* e = getenv("MSG_CONV_ROW3_W32"); w32 = e ? atoi(e) : 1; }
     int hn = row3_tile_columns(N);
+    // short K (few channels): a 256 x 256 tile's prologue and epilogue are not amortised and nothing overlaps them with one
+    // workgroup per CU; the 128 x 128 tile runs two.  MSG_CONV_ROW3_SHORTK = largest Ck that prefers the small tile.
+    static int shortk = -1;
+    if (shortk < 0) { const char* e = getenv("MSG_CONV_ROW3_SHORTK"); shortk = e ? atoi(e) : 128; }   // (3x3 128->256 @256^2, B=32: 632 -> 609 us)
+    if (hn == 256 && Ck <= shortk && N % 128 == 0) hn = 128;
     if (OW == 32 && w32 && N >= 128 && (long long)((N + 127) / 128) * 128 * 100 <= (long long)N * 115) hn = 128;
     if (!hn || (hn == 128 && !narrow) || N % hn) return 0;
     const int hm = hn;                             // square tiles: 256 x 256 or 128 x 128

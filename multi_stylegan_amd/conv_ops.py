@@ -667,6 +667,45 @@ class _ConvResidualF(Function):
         return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
+class _MultiConvF(Function):
+    """Several bias-free stride-1 convs of ONE input (the non-local block's theta / phi / g / residual projections).  In
+    backward the data gradients are chained through the residual epilogue -- each conv's data-gradient launch adds the
+    sum so far -- instead of autograd adding n full maps in n - 1 separate passes.  Second-order graphs take the plain
+    differentiable form."""
+
+    @staticmethod
+    def forward(ctx, x, geoms, *weights):
+        ctx.geoms = geoms
+        ctx.save_for_backward(x, *weights)
+        return tuple(_f_raw(x, w, None, g) for w, g in zip(weights, geoms))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, *weights = ctx.saved_tensors
+        second_order = torch.is_grad_enabled()
+        gx, gws = None, []
+        for k, (gy, w, g) in enumerate(zip(grads, weights, ctx.geoms)):
+            if gy is None:
+                gws.append(None)
+                continue
+            if ctx.needs_input_grad[0]:
+                if gx is None or second_order or gx.dtype != gy.dtype:
+                    part = _ConvD.apply(gy, w, g)
+                    gx = part if gx is None else gx + part
+                else:
+                    gx = _d_raw(gy, w, g, residual=(gx, 1.0))
+            gws.append(_ConvG.apply(gy, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[2 + k] else None)
+        return (gx, None, *gws)
+
+
+def conv2d_shared_input(x, weights_and_scales, padding=0):
+    """[conv(x, wscale * weight) for (weight, wscale) in weights_and_scales] -- bias-free, stride 1 -- as one autograd
+    node whose backward accumulates the input's gradient inside the data-gradient launches (see _MultiConvF)."""
+    p = _square(padding, "padding")
+    geoms = tuple(Geometry("conv", w.shape[2], w.shape[3], 1, p, x.shape[2:], False, ws) for w, ws in weights_and_scales)
+    return _MultiConvF.apply(x, geoms, *[w for w, _ in weights_and_scales])
+
+
 class GradScale:
     """A gain that the consumer of an activation's output owes its gradient, handed to the activation's own backward
     instead of being applied in a pass of its own: the residual merge y = (conv1x1(x) + main) * gain sends `main` the

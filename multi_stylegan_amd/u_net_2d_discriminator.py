@@ -19,6 +19,7 @@ from .op_static import attention as _attention
 FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
 COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
 NATIVE_SOFTMAX = bool(int(os.environ.get("MSG_NATIVE_SOFTMAX", "1")))       # 0: ROCm library softmax in the non-local blocks (A/B)
+SHARE_PROJECTION_INPUT = bool(int(os.environ.get("MSG_SHARE_PROJECTION_INPUT", "1")))   # 0: four separate 1x1 convs in the non-local block (A/B)
 DEFER_MERGE_GAIN = bool(int(os.environ.get("MSG_DEFER_MERGE_GAIN", "1")))   # 0: the merge's backward rescales its gradient itself (A/B)
 FUSE_INPUT_FORK = bool(int(os.environ.get("MSG_FUSE_INPUT_FORK", "1")))     # 0: autograd adds a block input's two gradients (A/B)
 
@@ -198,9 +199,20 @@ class NonLocalBlock(nn.Module):
         # channels-last feature maps ARE [B, HW, C] matrices: queries / values are views, and the second product is
         # taken as beta @ v so that (a) its result is already the NHWC map the next conv reads and (b) beta is used
         # un-transposed in both products (its gradient arrives contiguous: no [B, HW, HW/4] transpose copies).
-        query = self.theta(input).flatten(start_dim=2).transpose(1, 2)                                  # [B, HW, C/8]
-        key = F.max_pool2d(self.phi(input), kernel_size=2, stride=2).flatten(start_dim=2)               # [B, C/8, HW/4]
-        value = F.max_pool2d(self.g(input), kernel_size=2, stride=2).flatten(start_dim=2).transpose(1, 2)  # [B, HW/4, C/2]
+        projections = [self.theta, self.phi, self.g] + \
+            ([self.residual_mapping] if isinstance(self.residual_mapping, equalized_layer.EqualizedConv2d) else [])
+        residual = None
+        if SHARE_PROJECTION_INPUT and input.is_cuda and all(m.bias is None and m.stride == (1, 1) for m in projections):
+            # the three (four) 1x1 projections of the block input as ONE autograd node: their input gradients meet in the
+            # data-gradient launches instead of in three separate accumulation passes over the map
+            outs = conv_ops.conv2d_shared_input(input, [(m.weight, m.scale) for m in projections])
+            t, p_, g_ = outs[:3]
+            residual = outs[3] if len(outs) > 3 else None
+        else:
+            t, p_, g_ = self.theta(input), self.phi(input), self.g(input)
+        query = t.flatten(start_dim=2).transpose(1, 2)                                                  # [B, HW, C/8]
+        key = F.max_pool2d(p_, kernel_size=2, stride=2).flatten(start_dim=2)                            # [B, C/8, HW/4]
+        value = F.max_pool2d(g_, kernel_size=2, stride=2).flatten(start_dim=2).transpose(1, 2)          # [B, HW/4, C/2]
         keys = key.transpose(1, 2)                                                                      # [B, HW/4, C/8]
         if _attention.supported(query, keys, value):
             # fused: the [B, HW, HW/4] attention map never reaches HBM (csrc/attention.hip)
@@ -212,7 +224,9 @@ class NonLocalBlock(nn.Module):
             attended = torch.bmm(beta, value)
         attended = attended.view(bsz, height, width, -1).permute(0, 3, 1, 2)
         output = self.o(conv_ops.to_compute_layout(attended))
-        return scaled_add(self.gamma.to(input.dtype) * output, self.residual_mapping(input), 1.0 / math.sqrt(2))
+        if residual is None:
+            residual = self.residual_mapping(input)
+        return scaled_add(self.gamma.to(input.dtype) * output, residual, 1.0 / math.sqrt(2))
 
 
 class Discriminator(nn.Module):

@@ -121,10 +121,14 @@ LOG_NAMES = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_disc
 # fp32 path on the GPU against the reference-driven golden run.  Pre-clip gradients: 1e-3 of each tensor's largest
 # element (north star; measured: 1e-6 first order; the second-order steps, whose float-atomic weight gradients pass
 # through a second differentiation, vary between runs, 1e-4 .. 3e-4 with rare excursions: they get 3e-3), global norm 1e-4,
-# parameter movement 5e-3 of the largest movement (measured 7e-4, most of it the fp16 storage of the fixtures), on
+# parameter movement 1.5e-2 of the largest movement (typically 7e-4, most of it the fp16 storage of the fixtures), on
 # the elements whose gradient is above rounding noise (Adam with beta1 = 0 turns noise-level gradients into +-lr).
-STEP_TOL = {label: (1e-3, 1e-4, 5e-3) for label in ("d", "g", "cm_aug", "cm_reg")}
-STEP_TOL.update(r1=(3e-3, 1e-4, 5e-3), pl=(3e-3, 1e-4, 5e-3))
+# Movement tolerance 1.5e-2: Adam normalises by sqrt(v), and from iteration 16 on v carries the second-order steps, whose
+# float-atomic weight gradients differ by up to 3e-3 between runs -- one run in ~ten showed 9e-3 on one tensor of a
+# first-order step at 5e-3.  (A trainer that skips or doubles a step, does not clip or mishandles the EMA is off by O(1):
+# test_train_iteration_check_catches_a_broken_trainer.)
+STEP_TOL = {label: (1e-3, 1e-4, 1.5e-2) for label in ("d", "g", "cm_aug", "cm_reg")}
+STEP_TOL.update(r1=(3e-3, 1e-4, 1.5e-2), pl=(3e-3, 1e-4, 1.5e-2))
 
 
 def _golden_trainer(golden, **kw):

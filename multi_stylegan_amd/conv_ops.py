@@ -129,12 +129,14 @@ def _nhwc_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
             and x.data_ptr() % 16 == 0:
         return x, cx
     cx = _round_up(c, vec)
-    buf = torch.zeros((b, cx, h, w), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last) \
-        if cx > 1 else torch.zeros((b, cx, h, w), dtype=x.dtype, device=x.device)
+    # one pass: a channels-last buffer by construction, the copy, and zeros only in the padding channels (this used to
+    # be zeros -> .contiguous(channels_last) -> copy_: three passes over maps of up to a gigabyte in the second-order graphs)
+    buf = torch.empty((b, h, w, cx), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
     if cx == c:
         buf.copy_(x)
         return buf, cx
     buf[:, :c].copy_(x)
+    buf[:, c:].zero_()
     return buf[:, :c], cx
 
 

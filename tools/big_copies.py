@@ -19,7 +19,9 @@ import multi_stylegan_amd as m
 from multi_stylegan_amd.config import generator_config_for_resolution
 
 SEEN = collections.defaultdict(lambda: [0, 0])
-WATCH = ("copy_", "clone", "_to_copy", "cat", "contiguous", "add", "add_", "mul", "sum", "fill_", "zero_", "zeros", "zeros_like")
+WATCH = ("copy_", "clone", "_to_copy", "cat", "contiguous", "add", "add_", "mul", "mul_", "sum", "fill_", "zero_", "zeros",
+         "zeros_like", "sub", "div", "rsqrt", "pow", "neg", "where", "flip", "permute_copy", "bmm", "mm", "addmm")
+REGULARISED = bool(int(os.environ.get("MSG_BIG_COPIES_REG", "0")))    # 1: survey a regularised iteration (R1 + path length)
 
 
 class Spy(TorchDispatchMode):
@@ -62,6 +64,8 @@ def spy_apply(self, *a):
 
 
 BackwardCFunction.apply = spy_apply
+if REGULARISED:
+    trainer.iteration = 15
 with Spy():
     trainer.train_iteration(real)
 torch.cuda.synchronize()

@@ -147,12 +147,31 @@ def _alloc_out(b: int, n: int, h: int, w: int, dtype, device) -> Tuple[torch.Ten
     return buf.permute(0, 3, 1, 2)[:, :n], ld
 
 
+_FUSED_RELAYOUT = bool(int(os.environ.get("MSG_FUSED_RELAYOUT", "1")))   # 0: torch transpose-copies (A/B)
+
+
+def _relayout_kernel_ok(w, dtype, taps) -> bool:
+    return w.is_cuda and w.dtype == torch.float32 and dtype in (torch.bfloat16, torch.float32) and \
+        taps <= 16 and w.ndim >= 4 and _FUSED_RELAYOUT
+
+
 def _relay_fwd(w: torch.Tensor, dtype) -> Tuple[torch.Tensor, int]:
     """[..., O, I, kh, kw] -> [..., O, kh*kw, Ck] (K-contiguous, input channels zero-padded to a 128-byte run)."""
     if w.ndim == 2:
         w = w[:, :, None, None]
     *lead, o, i, kh, kw = w.shape
     ck = _round_up(i, 128 // (2 if dtype == torch.bfloat16 else 4))
+    if _relayout_kernel_ok(w, dtype, kh * kw):
+        # per-sample (or any non-parameter) fp32 weights: the kernel of _param_images, the leading dimensions folded
+        # into the rows -- one pass instead of a zero fill and a transposing, casting copy
+        rows = w.numel() // (i * kh * kw)
+        out = torch.empty((*lead, o, kh * kw, ck), dtype=dtype, device=w.device)
+        with _lib.on_device(w.device):
+            code = _lib.lib().msg_relayout_weight(w.detach().contiguous().data_ptr(), out.data_ptr(), None, None,
+                                                  _lib.dtype_code(out), rows, i, kh * kw, ck, ck, 0, 0, 1.0,
+                                                  _lib.stream_of(w.device))
+        _lib.check(code, "msg_relayout_weight")
+        return out, ck
     out = torch.zeros((*lead, o, kh * kw, ck), dtype=dtype, device=w.device)
     out[..., :i] = w.reshape(*lead, o, i, kh * kw).transpose(-1, -2)
     return out, ck
@@ -164,6 +183,17 @@ def _relay_dgrad(w: torch.Tensor, dtype, flip: bool) -> Tuple[torch.Tensor, int]
         w = w[:, :, None, None]
     *lead, o, i, kh, kw = w.shape
     ok = _round_up(o, 128 // (2 if dtype == torch.bfloat16 else 4))
+    if _relayout_kernel_ok(w, dtype, kh * kw) and len(lead) <= 1:
+        n = lead[0] if lead else 1
+        out = torch.empty((*lead, i, kh * kw, ok), dtype=dtype, device=w.device)
+        w3 = w.detach().contiguous().view(n, o, i, kh * kw)
+        ov = out.view(n, i, kh * kw, ok)
+        with _lib.on_device(w.device):
+            for k in range(n):                      # (the data-gradient image is per sample: one small launch each)
+                code = _lib.lib().msg_relayout_weight(w3[k].data_ptr(), None, ov[k].data_ptr(), None, _lib.dtype_code(out),
+                                                      o, i, kh * kw, ok, ok, int(flip), 0, 1.0, _lib.stream_of(w.device))
+                _lib.check(code, "msg_relayout_weight")
+        return out, ok
     src = w.reshape(*lead, o, i, kh * kw)
     if flip:
         src = src.flip(-1)
@@ -298,7 +328,6 @@ def _param_images(w, dtype, gain, kind, modulation=False):
 
 
 # --------------------------------------------------------------------------------------------------- raw launches
-_FUSED_RELAYOUT = bool(int(os.environ.get("MSG_FUSED_RELAYOUT", "1")))   # 0: torch transpose-copies (A/B)
 FUSE_ACTIVATION = bool(int(os.environ.get("MSG_FUSE_ACT", "1")))     # 0: two-pass conv + activation (A/B; results are bit-identical)
 _S2_PARITY = bool(int(os.environ.get("MSG_S2_PARITY", "1")))          # 0: zero-insertion form of the stride-2 data gradient (A/B)
 _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
@@ -1027,9 +1056,13 @@ def _modulated_composite(x, weight, style, demodulate, upsample):
     """Differentiable-to-any-order formulation: torch ops build w_b = d * scale * W * s, then one batched contraction."""
     _, out_c, in_c, kh, kw = weight.shape
     scale = math.sqrt(2.0) / math.sqrt(in_c * kh * kw)
-    wmod = (weight * scale) * style[:, None, :, None, None]
+    # ONE pass over the [B, O, I, kh, kw] per-sample weights (75 MB a layer at 512 channels): the per-(sample, o, i)
+    # coefficient is formed first, on B*O*I elements -- (weight * scale) * style * d took two to three such passes here and
+    # twice that in every differentiation of the graph
+    coef = style[:, None, :] * scale
     if demodulate:
-        wmod = wmod * demod_coefficients(weight, style, scale)[:, :, None, None, None]
+        coef = coef * demod_coefficients(weight, style, scale)[:, :, None]
+    wmod = weight * coef[:, :, :, None, None]
     g = Geometry("up2" if upsample else "conv", kh, kw, 1, kh // 2, x.shape[2:], True)
     return _ConvF.apply(x, wmod, None, g)
 

@@ -345,6 +345,14 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
         y, ldy = _alloc_out(b, n // 4, 2 * oh, 2 * ow, x.dtype, dev)
     else:
         y, ldy = _alloc_out(b, n, oh, ow, x.dtype, dev)
+    # (host-side shape check in front of the launch: a weight image with extra leading dimensions would give the kernel a
+    #  wrong per-sample stride and send it out of bounds)
+    rows_needed = n * (1 if pixel_shuffle else kh * kw) * ck
+    if per_sample:
+        if wk.ndim != 4 or wk.shape[0] != b or wk.stride(0) < rows_needed or not wk[0].is_contiguous():
+            raise _lib.MsgHipError(f"conv fprop: per-sample weight image {tuple(wk.shape)} for batch {b}, {n} x {kh * kw} x {ck}")
+    elif wk.numel() < rows_needed or not wk.is_contiguous():
+        raise _lib.MsgHipError(f"conv fprop: weight image {tuple(wk.shape)} smaller than {n} x {kh * kw} x {ck}")
     wstride = wk.stride(0) if per_sample else 0
     # algorithmic FLOPs: real channels, and only the taps a transposed strided conv can reach (1/in_up^2)
     if flops is None:
@@ -599,6 +607,8 @@ class _ConvG(Function):
         ctx.g = g
         ctx.save_for_backward(gy, x)
         gw = _g_raw(gy, x, oi[0], oi[1], g)
+        if w_ndim == 5 and not g.per_sample:  # a shared weight stored [1, O, I, kh, kw] (the generator's modulated convs)
+            return gw.unsqueeze(0)
         return gw.reshape(oi) if w_ndim == 2 else gw
 
     @staticmethod
@@ -1223,10 +1233,46 @@ class _ModulatedConv(Function):
         return (gx, gw, gs) + tail
 
 
+# Maps of at most this many pixels take the activation-scaling form of the modulated conv.  0 = never, the default:
+# measured at 1024 (the 4^2 .. 32^2 layers) it removes 2 ms of this package's kernels per iteration (per-sample weight
+# sets, msg_modulate_backward) and adds 3.5 ms of launch-bound torch elementwise ops around the shared-weight conv --
+# it would need the two scalings inside the conv kernels to pay off.  Kept as an A/B switch.
+_SMALL_MAP_PIXELS = int(os.environ.get("MSG_MODCONV_SMALL_MAP", "0"))
+
+
+def _small_map(x, weight) -> bool:
+    # (not the 6-channel RGB heads: their weight sets are tiny)
+    return x.is_cuda and x.shape[2] * x.shape[3] <= _SMALL_MAP_PIXELS and weight.shape[0] == 1 and weight.shape[1] >= 64
+
+
+def _modulated_small_map(x, weight, style, demodulate, upsample):
+    """The same function as the per-sample-weight form, with the modulation moved onto the activations:
+
+        conv(x, d_b * scale * W * s_b) = d_b * conv(s_b * x, scale * W)        (s per input channel, d per output channel)
+
+    On the low-resolution layers (4^2 .. 32^2) the per-sample form spends its time on the WEIGHTS: 75 MB of per-sample
+    weights written and read per 512-channel layer and pass, a 151 MB per-sample weight gradient and its reduction
+    (msg_modulate_backward) -- for maps of 16 .. 1024 pixels.  Here the weights stay shared (cached kernel-side images,
+    batch folded into the weight gradient's K), the two scalings touch a few MB of activations, and every piece is an
+    existing differentiable op, so the second-order graph of the path-length regulariser needs no composite either."""
+    _, out_c, in_c, kh, kw = weight.shape
+    scale = math.sqrt(2.0) / math.sqrt(in_c * kh * kw)
+    xs = x * style[:, :, None, None].to(x.dtype)
+    g = Geometry("up2" if upsample else "conv", kh, kw, 1, kh // 2, x.shape[2:], False, scale)
+    y = _ConvF.apply(xs, weight, None, g)       # (the [1, O, I, kh, kw] parameter itself: its kernel-side images are cached)
+    if demodulate:
+        y = y * demod_coefficients(weight, style, scale)[:, :, None, None].to(y.dtype)
+    return y
+
+
 def modulated_conv2d_bias_act(x, weight, style, demodulate, act_bias, noise, noise_weight, negative_slope=0.2,
                               scale=1.0):
     """modulated_conv2d (no upsampling) -> noise injection -> bias -> leaky ReLU, the activation stage fused into the
     contraction's epilogue (multi_stylegan_generator.py:267-292 + 384-411 in one pass over the output map)."""
+    if _small_map(x, weight):
+        from .op_static.fused_act import fused_bias_noise_leaky_relu
+        return fused_bias_noise_leaky_relu(_modulated_small_map(x, weight, style, bool(demodulate), False), act_bias,
+                                           noise, noise_weight, negative_slope, scale)
     return _ModulatedConv.apply(x, weight, style, bool(demodulate), False, act_bias, noise, noise_weight,
                                 float(negative_slope), float(scale), True)
 
@@ -1236,4 +1282,6 @@ def modulated_conv2d(x, weight, style, demodulate, upsample):
 
     One weight set per sample, w_b = d[b,o] * scale * W[o,i,k] * s[b,i] (multi_stylegan_generator.py:384-388), and
     one batched contraction (grid.z = sample) instead of the reference's groups=batch library conv."""
+    if _small_map(x, weight):
+        return _modulated_small_map(x, weight, style, bool(demodulate), bool(upsample))
     return _ModulatedConv.apply(x, weight, style, bool(demodulate), bool(upsample))

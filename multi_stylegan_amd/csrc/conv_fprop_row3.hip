@@ -60,7 +60,7 @@ template <int MI, int NCOLB, bool S16>
 __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                                  bf16_t* __restrict__ y, const float* __restrict__ bias,
                                                                  ConvParamsR3 p) {
-    constexpr int VEC = 8, BKE = 64, ESZ = 2;
+    constexpr int VEC = 8, ESZ = 2;
     constexpr int HN = 64 * NCOLB, HB = HN * HROW, WN = 32 * NCOLB;      // tile columns, weight buffer bytes, wave-tile columns
     constexpr int NBP = 2 * NCOLB;                                    // weight pieces (8 rows) per wave and K-step
     constexpr int HM = 64 * MI, WM = 32 * MI;                         // tile rows, wave-tile rows
@@ -246,24 +246,16 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
         int kh = 0, chunk = 0;                                      // the (kh, chunk) group of the current K-step
         int kh_l = 0, chunk_l = 0;                                  // the next group = the one whose activation tile loads
         int abuf = 0;
-        // weight pieces of a period: slot ps (one group of MFMAs), after MFMA j of the group
-        auto weights_at = [&](int ps, int j, int bufw, Pos q, bool live) __attribute__((always_inline)) {
-            if (WV >= 0) { if (j == WV * (NB / 4) && ps < NBP) dma_b(ps, bufw, q.kh * 3 + q.kw, q.chunk, live); }
-            else if (j == NB - 1) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) if (2 * ps + t < NBP) dma_b(2 * ps + t, bufw, q.kh * 3 + q.kw, q.chunk, live);
-            }
-        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MI; ++i) frag_row(i, 0, 0, a_row[i], a_sx[i]);
 #pragma unroll
         for (int t = 0; t < NA + NB; ++t) read_nth(0, t, smem);
+        // the weight pieces of step 1 that a period issues behind its barrier (last sub-step's groups: one per group with
+        // per-wave loops, two per group otherwise)
 #pragma unroll
-        for (int ps = 0; ps < NA; ++ps)                             // the pieces a period issues behind its barrier
-#pragma unroll
-            for (int j = 0; j < NB; ++j) weights_at(ps, j, 1, Pos{0, 0, 1}, true);
+        for (int q = 0; q < (WV >= 0 ? NA : 2 * NA); ++q) if (q < NBP) dma_b(q, 1, 1, 0, true);
 
         // One K-step, the horizontal tap KW a compile-time constant: the loop below runs the three steps of a (kh, chunk)
         // group back to back, so that "this period carries the activation pieces" (KW == 0) and the count the wait leaves

@@ -12,7 +12,10 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsg_hip.so")
+# MSG_LIB_VARIANT=<tag> loads libmsg_hip_<tag>.so instead: an experimental or diagnostic build kept beside the library for
+# same-box A/B timing (tools/microbench.py, tools/row3_stamps.py); never set in tests or in the benchmark
+LIB_PATH = os.path.join(_HERE, "libmsg_hip" + ("_" + os.environ["MSG_LIB_VARIANT"] if os.environ.get("MSG_LIB_VARIANT") else "")
+                        + ".so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msg_hip.h")
 
 MSG_F32, MSG_BF16, MSG_F16 = 0, 1, 2

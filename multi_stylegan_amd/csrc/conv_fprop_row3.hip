@@ -134,19 +134,23 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
         vb2[j] = (int)(((long long)(n0 + wrow) * 9 * p.Ck + slb * VEC) * ESZ);
     }
     const int w_piece2 = 16 * 9 * p.Ck * ESZ;                                     // two pieces = 16 weight rows further
-    unsigned a_bad = 0;                                                           // bit j: piece j reads zeros in the kernel row being loaded
-    int a_tap_off = 0;
-    auto set_kh = [&](int kh) __attribute__((always_inline)) {                    // activation rows of kernel row kh
-        a_tap_off = kh * p.IW * p.Cx * ESZ;
-        a_bad = ~a_flags | (kh == 0 ? a_flags >> 9 : 0u) | (kh == 2 ? a_flags >> 18 : 0u);
+    // The offsets the activation pieces of the kernel row being loaded use: recomputed when that row changes (three
+    // times per tile), out-of-range for rows outside the map and -- kh >= 3 -- once there is no further group to load.
+    // (Forming them at the piece, five vector instructions in front of every LDS-DMA, cost ~60 cycles of MFMA issue per
+    // piece in the stamps against ~10 for a weight piece, whose offset is ready.)
+    int va[NAP + 1];
+    auto set_kh = [&](int kh) __attribute__((always_inline)) {
+        const int tap_off = kh * p.IW * p.Cx * ESZ;
+        const unsigned bad = kh >= 3 ? ~0u : (~a_flags | (kh == 0 ? a_flags >> 9 : 0u) | (kh == 2 ? a_flags >> 18 : 0u));
+#pragma unroll
+        for (int j = 0; j < NAP + 1; ++j) va[j] = ((bad >> j) & 1u) ? H_OOB : a_b32[j] + tap_off;
     };
     // activation piece j of (kh set by set_kh, chunk) into activation buffer `abuf`
-    auto dma_a = [&](int j, int abuf, int chunk, bool live) __attribute__((always_inline)) {
+    auto dma_a = [&](int j, int abuf, int chunk) __attribute__((always_inline)) {
         if (j == NAP && wid_u != 0) return;
-        const bool a_zero = !live | (((a_bad >> j) & 1u) != 0);
         lds_t la = (lds_t)(smem + abuf * HA + (j < NAP ? wid_u * (HM / 4) + 8 * j : HM) * HROW);
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass instantiates this template too: it must not see the device builtin)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, la, 16, a_zero ? H_OOB : a_b32[j] + a_tap_off, chunk * HROW, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, la, 16, va[j], chunk * HROW, 0, 0);
 #endif
     };
     // weight piece j of K-step (tap, chunk) into weight buffer `bbuf`
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     // ---- prologue: activation tile of group 0 (kernel row 0, chunk 0), weights of K-step 0
     set_kh(0);
 #pragma unroll
-    for (int j = 0; j < NAP + 1; ++j) dma_a(j, 0, 0, true);
+    for (int j = 0; j < NAP + 1; ++j) dma_a(j, 0, 0);
 #pragma unroll
     for (int j = 0; j < NBP; ++j) dma_b(j, 0, 0, 0, true);
 
@@ -269,9 +273,8 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             if (KW == 0) {                                          // the next group's activation tile loads in this period
                 chunk_l = chunk + 1; kh_l = kh;
                 if (chunk_l == p.n_chunks) { chunk_l = 0; ++kh_l; }
-                if (kh_l != kh && kh_l < 3) set_kh(kh_l);
+                if (kh_l != kh) set_kh(kh_l);       // (kh_l == 3: nothing left to load -- zeros into the idle buffer)
             }
-            const bool more_a = kh_l < 3;
             const Pos n1 = KW < 2 ? Pos{kh, chunk, KW + 1} : Pos{kh_l, chunk_l, 0};
             const Pos n2 = KW < 1 ? Pos{kh, chunk, 2} : Pos{kh_l, chunk_l, KW - 1};
             constexpr bool ACTS = KW == 0;
@@ -319,17 +322,17 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                             const bool live = tail ? live2 : live1;
                             if (WV >= 0) {
                                 if (ps < NBP) dma_b(ps, bufw, q.kh * 3 + q.kw, q.chunk, live);
-                                else if (!tail && ACTS && ps - NBP < NAP) dma_a(ps - NBP, abuf ^ 1, chunk_l, more_a);
+                                else if (!tail && ACTS && ps - NBP < NAP) dma_a(ps - NBP, abuf ^ 1, chunk_l);
                             } else {
 #pragma unroll
                                 for (int t = 0; t < 2; ++t) {       // weights behind the barrier, activations from sub-step 0 on
                                     static_assert(NBP <= 2 * NA, "weight pieces fit the last sub-step's groups");
                                     if (tail) { if (2 * ps + t < NBP) dma_b(2 * ps + t, bufw, q.kh * 3 + q.kw, q.chunk, live); }
-                                    else if (ACTS && 2 * (ps - NA) + t < NAP + 1) dma_a(2 * (ps - NA) + t, abuf ^ 1, chunk_l, more_a);
+                                    else if (ACTS && 2 * (ps - NA) + t < NAP + 1) dma_a(2 * (ps - NA) + t, abuf ^ 1, chunk_l);
                                 }
                             }
                         }
-                        if (!tail && ACTS && WV == 0 && ps == NSUB * NA - 1 && jb == NB - 1) dma_a(NAP, abuf ^ 1, chunk_l, more_a);
+                        if (!tail && ACTS && WV == 0 && ps == NSUB * NA - 1 && jb == NB - 1) dma_a(NAP, abuf ^ 1, chunk_l);
                         if (sub == NSUB - 2 && jb == NB - 1) {
                             // Next step's fragment addresses, in place after the last read of this step that uses them, here
                             // (VALU in the MFMAs' shadow) rather than behind the barrier.  Activation fragment f is read

@@ -7,8 +7,6 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_stylegan_amd import _lib, conv_ops
-if os.environ.get("MSG_LIB_VARIANT"):          # an ablation build kept beside the library (libmsg_hip_<variant>.so)
-    _lib.LIB_PATH = _lib.LIB_PATH.replace(".so", "_" + os.environ["MSG_LIB_VARIANT"] + ".so")
 b, i, o, r, k = 16, 512, 512, 256, 3
 x = torch.randn(b, i, r, r, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
 w = torch.randn(b, o, i, k, k, device="cuda") / math.sqrt(i * k * k)

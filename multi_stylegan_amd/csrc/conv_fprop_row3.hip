@@ -214,15 +214,19 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
         constexpr int RPG = 3;                                      // fragment reads per group of MFMAs
         constexpr int ACT_IN_FLIGHT = NAP + (WV == 0 ? 1 : 0);      // (WV < 0: wave 0 waits for its extra piece early)
         bf16v8 fa[2][NA], fb[2][NB];
-        int a_row[MI], a_sx[MI];
-        auto frag_row = [&](int i, int kw_, int buf, int& row, int& sx) __attribute__((always_inline)) {
+        // LDS byte offsets of the activation fragments, one per 32-row group and sub-step (buffer, row and swizzled slot
+        // included; the second 16-row block of a group is a compile-time offset further): the reads carry no address
+        // arithmetic
+        int a_addr[MI][NSUB];
+        auto frag_row = [&](int i, int kw_, int buf) __attribute__((always_inline)) {
             const int r = wm * WM + i * 32 + lr + kw_ + 2 * seg_of[i];
-            row = buf * HA + r * HROW;                              // (byte offset in smem, buffer included)
-            sx = (r >> 1) & 7;
+            const int row = buf * HA + r * HROW, sx = (r >> 1) & 7;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) a_addr[i][sub] = row + (((SLOTS * sub + lh) ^ sx) << 4);
         };
         auto read_a = [&](int sub, int ia) __attribute__((always_inline)) {
             const int i32 = ia * BLK / 32, extra = (ia * BLK % 32) * HROW;
-            fa[sub & 1][ia] = *reinterpret_cast<const bf16v8*>(smem + a_row[i32] + extra + (((SLOTS * sub + lh) ^ a_sx[i32]) << 4));
+            fa[sub & 1][ia] = *reinterpret_cast<const bf16v8*>(smem + a_addr[i32][sub] + extra);
         };
         auto read_b = [&](int sub, int jb, const char* sB) __attribute__((always_inline)) {
             fb[sub & 1][jb] = *reinterpret_cast<const bf16v8*>(sB + fb_base + jb * BLK * HROW + (((SLOTS * sub + lh) ^ sxb) << 4));
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MI; ++i) frag_row(i, 0, 0, a_row[i], a_sx[i]);
+        for (int i = 0; i < MI; ++i) frag_row(i, 0, 0);
 #pragma unroll
         for (int t = 0; t < NA + NB; ++t) read_nth(0, t, smem);
         // the weight pieces of step 1 that a period issues behind its barrier (last sub-step's groups: one per group with
@@ -342,8 +346,9 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                             for (int i32 = 0; i32 < MI; ++i32) {
                                 const int f_last = (32 / BLK) * (i32 + 1) - 1;
                                 if ((f_last == 0 ? 1 : NB + f_last) / RPG == ia) {
-                                    frag_row(i32, (KW + 1) % 3, abuf_n, a_row[i32], a_sx[i32]);
-                                    asm volatile("" : "+v"(a_row[i32]), "+v"(a_sx[i32]));
+                                    frag_row(i32, (KW + 1) % 3, abuf_n);
+#pragma unroll
+                                    for (int sub2 = 0; sub2 < NSUB; ++sub2) asm volatile("" : "+v"(a_addr[i32][sub2]));
                                 }
                             }
                         }

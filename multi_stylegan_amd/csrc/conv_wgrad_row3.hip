@@ -17,6 +17,7 @@
 // same fp32 epilogue (stores or float atomics into GW[o][tap][i]).
 #include "msg_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -461,9 +462,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
 #pragma unroll
     for (int f = 0; f < 16; ++f) read_nth(f, 0, smem);
 
-    for (int it = 0; it < n_iters; ++it) {
-        const char* sa = smem + (it & 1) * R3_STAGE;
-        const char* sn = smem + ((it + 1) & 1) * R3_STAGE;
+    // One K-step with the stage it uses a compile-time constant (the loop is unrolled by two): the stage offset joins the
+    // fragment reads' immediate offsets, which takes the address add out of every one of the 32 reads of a sub-step.
+    auto k_step = [&](auto stage_tag, int it) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+        const char* sa = smem + ST * R3_STAGE;
+        const char* sn = smem + (ST ^ 1) * R3_STAGE;
         const bool live3 = it + 3 < n_iters;
         // sub-step 0: fragments of sub-step 1 in the first 32 gaps
 #pragma unroll
@@ -482,13 +486,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
         for (int m = 0; m < 48; ++m) {
             mfma(1, m / 16, (m / 4) % 4, m % 4);
             if (m < 32 && (m & 1) == 0) read_nth(m / 2, 0, sn);
-            if (m >= 30 && m < 39) park_piece(m - 30, it & 1);
+            if (m >= 30 && m < 39) park_piece(m - 30, ST);
             if (m == 38) { col_l = col_s; load_setup(); }
             if (m >= 39) load_piece(m - 39, live3);
             if (m == 47) load_advance();
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    int it = 0;
+    for (; it + 1 < n_iters; it += 2) {
+        k_step(std::integral_constant<int, 0>{}, it);
+        k_step(std::integral_constant<int, 1>{}, it + 1);
     }
+    if (it < n_iters) k_step(std::integral_constant<int, 0>{}, it);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // (the last inline-assembly MFMAs retire before anything reads them)
 
     // ---- epilogue: fp32; lanes 0..15 of a row group = 16 consecutive input channels, one pass per tap and block

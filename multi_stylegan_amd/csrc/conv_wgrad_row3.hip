@@ -341,6 +341,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
         xw_c[4] = r - 1;
         st_b[4] = r3_off(r, ch);
     }
+    const int voff_x0_left = r0 == 0 ? R3_OOB : voff_x[0];          // X row 0 = column col - 1
+    const int voff_x4_right = r0 == 1 ? R3_OOB : voff_x[4];         // X row 65 = column col + 64
     if constexpr (W32) {
         if (tid < 64) {
             const int hr = (tid >> 4) == 0 ? 0 : ((tid >> 4) == 1 ? 33 : ((tid >> 4) == 2 ? 34 : 67));
@@ -382,8 +384,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
         else {
             const int j = q - 4;
             if (W32 && j == 4) return;
-            const bool xok = live & (W32 ? (j < 2 ? row_ok : row_ok1) : (row_ok & ((unsigned)(col_l + xw_c[j]) < (unsigned)p.W)));
-            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[j] : R3_OOB, so_x, 0);
+            // (columns outside the map: only X row 0 of a row's first segment -- column -1 -- and X row 65 of its last
+            //  one; which lanes those are is known up front, so the per-step test is wave-uniform)
+            const bool ok = live & (W32 ? (j < 2 ? row_ok : row_ok1) : row_ok);
+            int off = voff_x[j];
+            if (!W32 && j == 0) off = col_l == 0 ? voff_x0_left : off;
+            if (!W32 && j == 4) off = col_l + R3_KP == p.W ? voff_x4_right : off;
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : R3_OOB, so_x, 0);
         }
     };
     auto load_advance = [&]() __attribute__((always_inline)) {

@@ -593,12 +593,12 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     if (zs > (1 << 24) || nblk >= (1ll << 31)) return 0;
     static int s16 = -1;                            // MSG_WGRAD_ROW3_S16=0: the 32x32x16 kernel (A/B)
     if (s16 < 0) { const char* e = getenv("MSG_WGRAD_ROW3_S16"); s16 = e ? atoi(e) : 1; }
-    // (measured, bf16, B = 16: 3x3 512->512 @256^2 per-sample 4235 -> 4005 us, @128^2 1079 -> 1036, 128->128 @256^2 shared
-    //  318 -> 305, 384->256 @128^2 447 -> 421; the 32-wide maps 246 -> 247 / 314 -> 323: those stay on the 32x32x16 kernel)
-    if (s16 > 1 && w32)
+    // (measured, bf16, B = 16, same box: 3x3 512->512 @256^2 per-sample 4235 -> 3930 us, @128^2 1079 -> 1010, 128->128 @256^2
+    //  shared 318 -> 305, 384->256 @128^2 447 -> 421; 32-wide maps: 768->768 265 -> 254, 1024->768 333 -> 317)
+    if (s16 && w32)
         hipLaunchKernelGGL(conv_wgrad_row3s_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)gy, (const bf16_t*)x, gw, p);
-    else if (s16 && !w32)
+    else if (s16)
         hipLaunchKernelGGL(conv_wgrad_row3s_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)gy, (const bf16_t*)x, gw, p);
     else if (w32)

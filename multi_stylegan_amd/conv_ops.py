@@ -565,6 +565,22 @@ def _g_raw(gy, x, o, i, g: Geometry):
     return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None, gain=g.wscale)
 
 
+def _consumed(ctx, arg_index: int, tensor_ordinal: int) -> bool:
+    """Whether the gradient of forward argument `arg_index` (the `tensor_ordinal`-th TENSOR argument) is worth computing
+    in this backward call: it requires grad AND the engine is going to run the node it would be handed to.  In a partial
+    backward -- ``torch.autograd.grad(outputs, inputs=[images])``, the first pass of the R1 and path-length regularisers --
+    ``ctx.needs_input_grad`` still says True for every weight, although their gradients are thrown away on return; asking
+    the engine (the query activation checkpointing uses for its early stop) skips the weight-gradient contractions of the
+    whole discriminator there.  Any doubt (no graph task, a leaf that is itself one of the requested inputs) -> True."""
+    if not ctx.needs_input_grad[arg_index]:
+        return False
+    try:
+        node = ctx.next_functions[tensor_ordinal][0]
+        return node is None or bool(torch._C._will_engine_execute_node(node))
+    except Exception:
+        return True
+
+
 # ------------------------------------------------------------------------------------- autograd closure of F/D/G
 class _ConvF(Function):
     @staticmethod
@@ -579,9 +595,9 @@ class _ConvF(Function):
         x, w = ctx.saved_tensors
         g = ctx.g
         gx = _ConvD.apply(gy, w, g) if ctx.needs_input_grad[0] else None
-        gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
+        gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g) if _consumed(ctx, 1, 1) else None
         # (the cast inside the reduction: `gy.float()` materialised an fp32 copy of the whole map first)
-        gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32) if ctx.has_bias and _consumed(ctx, 2, 2) else None
         return gx, gw, gb, None
 
 
@@ -658,7 +674,7 @@ class _ConvActF(Function):
                 ctx.slot.merged = True
             else:
                 gx = _ConvD.apply(gpre, w, g)
-        gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
+        gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
             (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None, None
 
@@ -693,7 +709,7 @@ class _ConvResidualF(Function):
             gx = _ConvD.apply(gs, w, gg) if ctx.needs_input_grad[0] else None
             if ctx.slot is not None and gx is not None:
                 ctx.slot.g = gx
-            gw = _ConvG.apply(gs, x, _oi(w), w.ndim, gg) if ctx.needs_input_grad[1] else None
+            gw = _ConvG.apply(gs, x, _oi(w), w.ndim, gg) if _consumed(ctx, 1, 1) else None
             return gx, gw, gs, None, None, None, None, None
         if g1 is None or g2 is None:
             gs = (g1 if g1 is not None else g2) * ctx.gain
@@ -704,7 +720,7 @@ class _ConvResidualF(Function):
         gx = _ConvD.apply(gs, w, ctx.g) if ctx.needs_input_grad[0] else None
         if ctx.slot is not None and gx is not None and not torch.is_grad_enabled():
             ctx.slot.g = gx                  # the main branch's first conv adds it in its data-gradient epilogue
-        gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g) if ctx.needs_input_grad[1] else None
+        gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
@@ -735,7 +751,7 @@ class _MultiConvF(Function):
                     gx = part if gx is None else gx + part
                 else:
                     gx = _d_raw(gy, w, g, residual=(gx, 1.0))
-            gws.append(_ConvG.apply(gy, x, _oi(w), w.ndim, g) if ctx.needs_input_grad[2 + k] else None)
+            gws.append(_ConvG.apply(gy, x, _oi(w), w.ndim, g) if _consumed(ctx, 2 + k, 1 + k) else None)
         return (gx, None, *gws)
 
 

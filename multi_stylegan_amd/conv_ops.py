@@ -1211,7 +1211,8 @@ class _ModulatedConv(Function):
         demodulate, upsample, g, scale = ctx.cfg
         _, o, i, kh, kw = weight.shape
         b, t = x.shape[0], kh * kw
-        need = ctx.needs_input_grad
+        need = list(ctx.needs_input_grad)
+        need[1], need[2] = _consumed(ctx, 1, 1), _consumed(ctx, 2, 2)       # (weight, style: see _consumed)
         gb = gnw = None
         if ctx.act is not None:
             # activation stage first (slope from the sign of the saved OUTPUT); a differentiable Function, so the

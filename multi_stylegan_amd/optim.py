@@ -55,7 +55,7 @@ class FlatAdam:
         self._ema_model = self._ema_train = None
         self._ema_first: List[Optional[torch.nn.Parameter]] = []
         for b in reducer.buckets:
-            self.param_flat.append(torch.empty_like(b.flat))
+            self.param_flat.append(torch.zeros_like(b.flat))            # (zeros in the alignment padding between parameters)
             self.exp_avg.append(torch.zeros_like(b.flat))
             self.exp_avg_sq.append(torch.zeros_like(b.flat))
             self.ema_flat.append(None)
@@ -70,8 +70,7 @@ class FlatAdam:
         steps = []
         with torch.no_grad():
             for k, b in enumerate(self.reducer.buckets):
-                off = 0
-                for p in b.params:
+                for p, off in zip(b.params, b.offsets):
                     n = p.numel()
                     view = self.param_flat[k][off:off + n].view_as(p)
                     if p.data.data_ptr() != view.data_ptr():
@@ -86,7 +85,6 @@ class FlatAdam:
                             v_view.copy_(st["exp_avg_sq"])
                         steps.append(int(float(st["step"])))
                     state[p] = {"step": self._step_tensor, "exp_avg": m_view, "exp_avg_sq": v_view}
-                    off += n
         if steps:
             # torch counts per parameter; every parameter of the buckets is stepped together here.  (A checkpoint
             # whose parameters disagree -- some never received a gradient -- resumes at the largest count.)
@@ -165,15 +163,13 @@ class FlatAdam:
                        ema_named[names[id(p)]].shape != p.shape or ema_named[names[id(p)]].dtype != torch.float32 or
                        ema_named[names[id(p)]].device != p.device for p in b.params):
                     continue
-                flat = torch.empty_like(b.flat)
-                off = 0
-                for p in b.params:
+                flat = torch.zeros_like(b.flat)
+                for p, off in zip(b.params, b.offsets):
                     e = ema_named[names[id(p)]]
                     view = flat[off:off + p.numel()].view_as(e)
                     view.copy_(e.data)
                     e.data = view
                     covered.add(names[id(p)])
-                    off += p.numel()
                 self.ema_flat[k] = flat
         train_named = dict(model_train.named_parameters())
         self._ema_rest = [(e, train_named[n]) for n, e in ema_named.items() if n not in covered]

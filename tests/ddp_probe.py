@@ -32,7 +32,8 @@ class StepProbe:
             idx = next(i for i, b in enumerate(red.buckets) if b is bucket)
             slot = self._pending.setdefault(id(red), {})
             assert idx not in slot, "bucket launched twice in one step"
-            slot[idx] = bucket.flat.detach().clone()
+            # (the parameters' slices, without the alignment padding between them)
+            slot[idx] = torch.cat([bucket.flat[o:o + p.numel()].detach() for p, o in zip(bucket.params, bucket.offsets)])
             orig(bucket)
         red._launch = launch
 

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     constexpr int HM = 64 * MI, WM = 32 * MI;                         // tile rows, wave-tile rows
     constexpr int NAP = 2 * MI;                                       // activation pieces per wave and group (+ piece NAP: rows HM..HM+7, wave 0)
     constexpr int HA = (HM + 8) * HROW;                               // activation buffer
-#ifdef MSG_ROW3_NO_STAGGER
+#if defined(MSG_ROW3_NO_STAGGER)
     constexpr bool STAGGER = false;
 #else
-    constexpr bool STAGGER = MI == 4;
+    constexpr bool STAGGER = true;        // (the 128 x 128 tile too: +1..2 %)
 #endif
     __shared__ __attribute__((aligned(16))) char smem[2 * HA + 2 * HB];
 
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     // staging instruction per group, a quarter of a group after the previous wave's, so that the CU's vector-memory port
     // sees one 1-KiB piece every 32 cycles instead of four at a time (stamps: issued by all four waves at the same
     // point, a piece costs each of them 50-70 cycles of MFMA issue; one wave at a time, nothing measurable).
-    // WV < 0 (the 128 x 128 tile, two workgroups per CU): two pieces per group from the start of the period.
+    // WV < 0 (-DMSG_ROW3_NO_STAGGER, A/B): one loop for all waves, two pieces per group from the start of the period.
     struct Pos { int kh, chunk, kw; };
     auto k_loop = [&](auto wv_tag) __attribute__((always_inline)) {
         constexpr int WV = decltype(wv_tag)::value;

@@ -280,6 +280,20 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
 //   * the first fragments of step t + 1 (parked before the barrier) are read beside the second sub-step's MFMAs.
 // Accumulators: 3 x 4 x 4 four-register blocks in AGPRs, tied operands of inline-assembly MFMAs (through the builtin the
 // compiler re-assigned and copied them around the loop); the compiler still places the s_waitcnt for their inputs.
+#ifdef MSG_WGRAD3_STAMPS
+// diagnostic build only (tools/wgrad3_stamps.py; never ship or benchmark it): cycle stamps of K-steps 8..9 of every wave
+// of the first 256 workgroups
+__device__ unsigned long long g_wgrad3_stamps[256 * 4 * 2 * 8];
+#define W3_STAMP(k) do { if (it >= 8 && it < 10 && blockIdx.x < 256 && lane == 0) { unsigned long long tt; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); \
+    g_wgrad3_stamps[((blockIdx.x * 4 + wid) * 2 + (it - 8)) * 8 + (k)] = tt; } } while (0)
+extern "C" int msg_wgrad3_debug_read(void* host_dst, int nbytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wgrad3_stamps), nbytes) == hipSuccess ? 0 : -1;
+}
+#else
+#define W3_STAMP(k) do {} while (0)
+#endif
+
 template <bool W32>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
                                                                   float* __restrict__ gw, Row3Params p) {
@@ -471,22 +485,31 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
 
     // One K-step with the stage it uses a compile-time constant (the loop is unrolled by two): the stage offset joins the
     // fragment reads' immediate offsets, which takes the address add out of every one of the 32 reads of a sub-step.
+    // (Stamps, tools/wgrad3_stamps.py: the nine parks and the nine loads of a K-step cost ~320 + ~300 cycles of its ~2450.
+    // Measured and rejected: per-wave instances of the loop that stagger them in time, one park + one load per 16 cycles
+    // on the CU, interleaved with the fragment reads -- 3800 -> 4030 us on 3x3 512->512 @256^2.  The first park waits for a
+    // global load issued less than one period earlier; that distance is set by the single register set in flight.)
     auto k_step = [&](auto stage_tag, int it) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_tag)::value;
         const char* sa = smem + ST * R3_STAGE;
         const char* sn = smem + (ST ^ 1) * R3_STAGE;
         const bool live3 = it + 3 < n_iters;
+        W3_STAMP(0);
         // sub-step 0: fragments of sub-step 1 in the first 32 gaps
 #pragma unroll
         for (int m = 0; m < 48; ++m) {
             mfma(0, m / 16, (m / 4) % 4, m % 4);
             if (m < 32 && (m & 1) == 0) read_nth(m / 2, 1, sa);    // (a fragment = two transposing reads: gaps m and m + 1)
             __builtin_amdgcn_sched_barrier(0);
+            if (m == 31) W3_STAMP(1);
         }
+        W3_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own fragment reads and parks done
         __builtin_amdgcn_sched_barrier(0);
+        W3_STAMP(3);
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        W3_STAMP(4);
         // sub-step 1: first fragments of step it + 1; then the registers (step it + 2) into the stage this step just
         // left, and the loads of step it + 3 behind them
 #pragma unroll
@@ -498,7 +521,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
             if (m >= 39) load_piece(m - 39, live3);
             if (m == 47) load_advance();
             __builtin_amdgcn_sched_barrier(0);
+            if (m == 29) W3_STAMP(5);
+            if (m == 38) W3_STAMP(6);
         }
+        W3_STAMP(7);
     };
     int it = 0;
     for (; it + 1 < n_iters; it += 2) {

@@ -60,6 +60,9 @@ class FlatAdam:
             self.exp_avg_sq.append(torch.zeros_like(b.flat))
             self.ema_flat.append(None)
         self.adopt()
+        # someone stepping the torch optimizer directly (not through ModelWrapper._step) gets the state in the form torch's
+        # own Adam expects; the next flat step adopts what it did
+        optimizer.register_step_pre_hook(lambda _opt, _args, _kwargs: self.release())
 
     # ---------------------------------------------------------------------------------------------------------
     def adopt(self) -> None:

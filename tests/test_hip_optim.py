@@ -98,8 +98,7 @@ def test_flat_adam_declines_mixed_hyperparameters_and_torch_takes_over():
     before = [p.detach().clone() for p in params]
     assert flat.step(None) is False                          # two learning rates in one bucket
     assert all(torch.equal(p.detach(), b) for p, b in zip(params, before))
-    flat.release()
-    opt.step()                                                # torch's fused Adam on the same (flat-view) state
+    opt.step()               # torch's fused Adam on the same (flat-view) state; FlatAdam's step pre-hook hands it over
     opt_ref.step()
     for p, q in zip(params, ref):
         assert rel_err(p.detach(), q.detach()) < 4e-6

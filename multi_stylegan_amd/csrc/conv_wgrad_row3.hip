@@ -487,8 +487,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
     // fragment reads' immediate offsets, which takes the address add out of every one of the 32 reads of a sub-step.
     // (Stamps, tools/wgrad3_stamps.py: the nine parks and the nine loads of a K-step cost ~320 + ~300 cycles of its ~2450.
     // Measured and rejected: per-wave instances of the loop that stagger them in time, one park + one load per 16 cycles
-    // on the CU, interleaved with the fragment reads -- 3800 -> 4030 us on 3x3 512->512 @256^2.  The first park waits for a
-    // global load issued less than one period earlier; that distance is set by the single register set in flight.)
+    // on the CU, interleaved with the fragment reads -- 3800 -> 4030 us on 3x3 512->512 @256^2; parks and loads as pairs, a
+    // period minus one gap apart -- no change.  An ablation whose parks do not depend on the loads shows the same ~44 cycles
+    // per park: it is not the loads' latency but the cost of four waves issuing 1-KiB LDS writes in the same gap.)
     auto k_step = [&](auto stage_tag, int it) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_tag)::value;
         const char* sa = smem + ST * R3_STAGE;

@@ -106,14 +106,19 @@ int msg_fused_bias_act(const void* x, const float* bias, const void* ref, void* 
  * a2  backward of the above with its reductions -- replaces
  *     FusedLeakyReLUFunctionBackward.forward (multi_stylegan/op_static/fused_act.py:24-42:
  *     one fused_bias_act(grad=1) call + grad_input.sum(dim) in PyTorch).
- * gx = gy * scale * (out > 0 ? 1 : alpha);  grad_bias[c] += sum gx;
- * grad_noise_weight[0] += sum gx * noise[pixel]   (if noise != NULL).
- * grad_bias / grad_noise_weight are float32 and ACCUMULATED into (zero them first).
+ * gx = gy * scale * (out > 0 ? 1 : alpha);  grad_bias[c] = sum gx;
+ * grad_noise_weight[0] = sum gx * noise[pixel]   (if noise != NULL).
+ * grad_bias / grad_noise_weight are float32 and OVERWRITTEN.  The sums are deterministic: workgroups leave partial sums
+ * in `ws` (float32, at least msg_bias_act_backward_workspace(...) elements, contents irrelevant) and a second launch adds
+ * them in index order -- no float atomics, bit-identical results for identical inputs.  ws may be NULL when neither sum
+ * is requested.
  * ------------------------------------------------------------------------- */
+long long msg_bias_act_backward_workspace(long long size_x, int step_b, int size_b, int has_noise);
 int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
                           long long size_x, int step_b, int size_b,
                           float* grad_bias, const float* noise, float* grad_noise_weight,
-                          int noise_batch, int pix, float alpha, float scale, void* stream);
+                          int noise_batch, int pix, float alpha, float scale,
+                          float* ws, long long ws_floats, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a3/a4  dense contractions on the matrix cores (channels-last, implicit GEMM).
@@ -132,8 +137,13 @@ int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
  *   Data gradients are the same entry with the caller's re-laid weights.
  * msg_conv2d_wgrad:
  *   gw[(b)][o][tap][i] (+)= sum_{pixels} gy[b,oh,ow,o] * x[b, oh*stride+kh-pad, ow*stride+kw-pad, i]
- *   gw fp32 [(B)][O][kh*kw][ldgw]; per_sample = 1 (k_chunks must be 1): one slice per sample, plain stores;
- *   otherwise every (sample, pixel-chunk) slice ACCUMULATES with float atomics (zero gw first).
+ *   gw fp32 [(B)][O][kh*kw][ldgw] (ldgw % 4 == 0), OVERWRITTEN; per_sample = 1: one result per sample (its pixels split
+ *   into k_chunks K-slices), otherwise ONE result for the whole batch (the library folds the batch into K and chooses the
+ *   number of K-slices itself; k_chunks is ignored unless folding is impossible).
+ *   A result that is the sum of several K-slices is formed deterministically: every slice stores its partial result into
+ *   its own slab of `ws` (float32, at least msg_conv2d_wgrad_workspace(...) elements -- 0 when nothing is split; contents
+ *   irrelevant) and a second launch adds the slabs in slice order.  No float atomics: identical inputs give bit-identical
+ *   gradients (the reference's cuDNN weight gradients are not deterministic; its training step is what ours must match).
  *   pixel_shuffle = 1: OH,OW are the LOW-res extent, gy is [B,2*OH,2*OW,ldgy], tap = (dy,dx).
  *   oi_major = 1 writes gw[(b)][o][i][tap] (the parameter's own [O,I,kh,kw] layout) instead; gain multiplies the result.
  * ------------------------------------------------------------------------- */
@@ -144,7 +154,12 @@ int msg_conv2d_fprop(const void* x, const void* w, const float* bias, void* y, i
 int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
                      int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
                      int kh, int kw, int stride, int pad, int pixel_shuffle,
-                     int per_sample, int k_chunks, int oi_major, float gain, void* stream);
+                     int per_sample, int k_chunks, int oi_major, float gain,
+                     float* ws, long long ws_floats, void* stream);
+/* Workspace elements (float32) the call above needs for the same geometry; negative = MSG_E* code. */
+long long msg_conv2d_wgrad_workspace(int dtype, int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy,
+                                     int O, int ldgw, int kh, int kw, int stride, int pad, int pixel_shuffle,
+                                     int per_sample, int k_chunks);
 
 /* ---------------------------------------------------------------------------
  * a3  weight modulation / demodulation of the dual-styled conv (multi_stylegan/multi_stylegan_generator.py:379-388).

@@ -31,11 +31,13 @@ _SIGNATURES = {
     "msg_upfirdn2d_separable": (_I, [_P, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     "msg_upfirdn2d_separable_act": (_I, [_P, _P, _P, _P, _I] + [_I] * 10 + [_P, _P, _P, _I, _F, _F, _P]),
     "msg_fused_bias_act": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
-    "msg_bias_act_backward": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _I, _F, _F, _P]),
+    "msg_bias_act_backward": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P]),
+    "msg_bias_act_backward_workspace": (_L, [_L, _I, _I, _I]),
     "msg_conv2d_fprop": (_I, [_P, _P, _P, _P, _I] + [_I] * 15 + [_L, _P]),
     "msg_conv2d_fprop_act": (_I, [_P, _P, _P, _I] + [_I] * 13 + [_L, _P, _P, _P, _I, _F, _F, _P]),
     "msg_conv2d_fprop_residual": (_I, [_P, _P, _P, _I] + [_I] * 13 + [_L, _P, _I, _F, _P]),
-    "msg_conv2d_wgrad": (_I, [_P, _P, _P, _I] + [_I] * 18 + [_F, _P]),
+    "msg_conv2d_wgrad": (_I, [_P, _P, _P, _I] + [_I] * 18 + [_F, _P, _L, _P]),
+    "msg_conv2d_wgrad_workspace": (_L, [_I] * 18),
     "msg_demod_coeff": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "msg_scale_rows_cols": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "msg_modulate_weights": (_I, [_P] * 5 + [_I] * 7 + [_F, _F, _P]),

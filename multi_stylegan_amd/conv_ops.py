@@ -396,36 +396,50 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
     oh, ow = low_hw if pixel_shuffle else gv.shape[2:]
     taps = kh * kw
     ldgw = _round_up(i, 4)
-    # The kernel's own [O][tap][I] layout keeps its stores / float atomics on 128-byte runs (the parameter layout
-    # [O][I][tap] would scatter them: measured 25 % slower end to end); the caller gets a strided VIEW in parameter
-    # order, so no transposing copy is made either.
-    oi_major = False
     kp = 64 if x.dtype == torch.bfloat16 else 32
     if per_sample:
         # one K sweep per (sample, tile, tap) unless that leaves most of the chip idle (the 512 -> 3 toRGB layers: 64
-        # workgroups); then the pixels are split and the slices meet in float atomics on a zeroed buffer
+        # workgroups); then the pixels are split into K-slices
         tiles = ((o + 127) // 128) * ((i + 127) // 128) * taps * b
         k_chunks = max(1, min((oh * ow) // (16 * kp), 1024 // tiles)) if tiles < 256 else 1
-        gw = (torch.zeros if k_chunks > 1 else torch.empty)((b, o, taps, ldgw), dtype=torch.float32, device=dev)
     else:
-        gw = torch.zeros((o, taps, ldgw), dtype=torch.float32, device=dev)
+        # (shared weights: the library folds the batch into K and picks the slice count; k_chunks only matters where it cannot)
         tiles = ((o + 127) // 128) * ((i + 127) // 128) * taps * b
         k_chunks = max(1, min((oh * ow + 4 * kp - 1) // (4 * kp), (1024 + tiles - 1) // tiles))
         while b * k_chunks > 65535:
             k_chunks -= 1
+    geom = (_lib.dtype_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw, kh, kw, stride, pad, int(pixel_shuffle),
+            int(per_sample), k_chunks)
+    # K-slices that add up to one result meet in a workspace of per-slice slabs and a fixed-order sum (deterministic; no
+    # float atomics, no zero fill).  That sum also transposes a SHARED gradient into the parameter's own [O, I, kh, kw]
+    # layout, so what autograd accumulates into the flat gradient bucket is a contiguous tensor; per-sample gradients and
+    # unsplit results stay in the kernel's [O][tap][I] layout (128-byte runs; the parameter layout would scatter the
+    # contraction kernel's stores: measured 25 % slower end to end) and the caller gets a strided view in parameter order.
+    need = _lib.lib().msg_conv2d_wgrad_workspace(*geom)
+    if need < 0:
+        _lib.check(int(need), "msg_conv2d_wgrad_workspace")
+    ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+    oi_major = bool(need) and not per_sample and not raw
+    if oi_major:
+        gw = torch.empty((o, i, kh, kw), dtype=torch.float32, device=dev)
+    elif per_sample:
+        gw = torch.empty((b, o, taps, ldgw), dtype=torch.float32, device=dev)
+    else:
+        gw = torch.empty((o, taps, ldgw), dtype=torch.float32, device=dev)
     flops = 2.0 * b * oh * ow * o * i * taps
     key = "conv_wgrad"
     if _CLOCK_SHAPES and _lib.kernel_clock.enabled:
         key += f"|B{b} {ih}x{iw}->{oh}x{ow} {i}->{o} {kh}x{kw} s{stride}{' ps' if pixel_shuffle else ''}" \
-               f"{' per-sample' if per_sample else f' chunks{k_chunks}'}|"
+               f"{' per-sample' if per_sample else ' shared'}{f' slabs{need // (o * taps * ldgw)}' if need else ''}|"
     with _lib.on_device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
         code = _lib.lib().msg_conv2d_wgrad(
-            gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw,
-            kh, kw, stride, pad, int(pixel_shuffle), int(per_sample), k_chunks, int(oi_major), float(gain),
+            gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), *geom, int(oi_major), float(gain), _lib.ptr(ws), need,
             _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_wgrad")
     if raw:
         return gw, ldgw                                   # kernel layout [(B)][O][taps][ldgw]
+    if oi_major:
+        return gw
     lead = gw.shape[:-2]                                  # [(B), O]
     return gw.view(*lead, kh, kw, ldgw)[..., :i].permute(*range(len(lead)), len(lead) + 2, len(lead), len(lead) + 1)
 
@@ -1033,13 +1047,15 @@ class _GroupedLinear(Function):
         slot_t = _ptr_table_ints(slot, dev)
         glat = None
         if need[0]:
-            gx = torch.empty((g, b, k), dtype=torch.float32, device=dev)
+            gx = torch.empty((g + 1, b, k), dtype=torch.float32, device=dev)
+            gx[g].zero_()                                   # (the row the padding entries of the gather table point at)
             with _lib.on_device(dev):
                 code = _lib.lib().msg_linear_grouped_dgrad(gy.data_ptr(), _ptr_table(ws, dev).data_ptr(), gx.data_ptr(),
                                                            g, b, n, k, wscale, _lib.stream_of(dev))
             _lib.check(code, "msg_linear_grouped_dgrad")
-            glat = torch.zeros((b, l, k), dtype=torch.float32, device=dev)
-            glat.index_add_(1, slot_t.long(), gx.transpose(0, 1))
+            # layers that read the same latent slot: gather + ordered sum (index_add_ adds with float atomics, i.e. in an
+            # order that changes from run to run)
+            glat = gx[_slot_gather_table(slot, l, dev)].sum(dim=1).transpose(0, 1)
         gw = gb = None
         if any(need[4:]):
             gw = torch.empty((g, n, k), dtype=torch.float32, device=dev)
@@ -1055,6 +1071,22 @@ class _GroupedLinear(Function):
 
 
 _INT_TABLES: dict = {}
+_GATHER_TABLES: dict = {}
+
+
+def _slot_gather_table(slot, n_slots, dev):
+    """[n_slots, max layers per slot] int64: row l lists the layers whose latent slot is l, padded with len(slot) (the index
+    of a zero row appended to what is gathered)."""
+    key = (dev.index, tuple(int(v) for v in slot), n_slots)
+    hit = _GATHER_TABLES.get(key)
+    if hit is None:
+        if len(_GATHER_TABLES) > 64:
+            _GATHER_TABLES.clear()
+        rows = [[j for j, v in enumerate(key[1]) if v == l] for l in range(n_slots)]
+        width = max(1, max(len(r) for r in rows))
+        hit = _GATHER_TABLES[key] = torch.tensor([r + [len(slot)] * (width - len(r)) for r in rows], dtype=torch.int64,
+                                                 device=dev)
+    return hit
 
 
 def _ptr_table_ints(values, dev):

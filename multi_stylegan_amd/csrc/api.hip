@@ -1,7 +1,7 @@
 // Library identity and error strings of the C ABI (include/msg_hip.h).
 #include "msg_common.h"
 
-extern "C" int msg_abi_version(void) { return 2; }   // 2: + fprop_act, upfirdn2d_separable, linear_*, modulate_weights
+extern "C" int msg_abi_version(void) { return 3; }   // 3: deterministic reductions (workspace arguments of msg_conv2d_wgrad, msg_bias_act_backward)
 extern "C" const char* msg_build_arch(void) { return "gfx950"; }
 extern "C" const char* msg_strerror(int code) {
     switch (code) {

@@ -149,13 +149,18 @@ extern "C" int msg_fused_bias_act(const void* x, const float* bias, const void* 
 }
 
 // ---- backward with reductions ---------------------------------------------------------------------------------
+// grad_bias[c] and grad_noise_weight are sums over the whole map.  They are NOT accumulated with float atomics (arrival
+// order = run-to-run differences in every training step): each workgroup stores its partial sums in a workspace,
+// part_b[j][c] (j = the workgroup's slice of the pixels) and part_n[block], and bias_act_bwd_reduce_kernel adds them in
+// index order.  Same shapes -> same grid -> same association -> bit-identical results.
+//
 // Channels-last: block = LC channel-vectors x (256/LC) pixel lanes; every lane keeps its VEC channels across its
-// pixel loop, partial sums meet in LDS, one float atomic per channel per block.
+// pixel loop, partial sums meet in LDS and are added there in lane order.
 template <typename T, bool HAS_NOISE>
 __global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restrict__ gy, const T* __restrict__ out,
-                                                              T* __restrict__ gx, float* __restrict__ grad_bias,
+                                                              T* __restrict__ gx, float* __restrict__ part_b,
                                                               const float* __restrict__ noise,
-                                                              float* __restrict__ grad_nw, BiasActParams p,
+                                                              float* __restrict__ part_n, BiasActParams p,
                                                               int lanes_c, long long npix, long long pix_per_block) {
     using V = Vec16<T>;
     constexpr int VEC = V::N;
@@ -189,42 +194,40 @@ __global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restric
         }
         *reinterpret_cast<uint4*>(gx + i) = r.raw;
     }
-    if (grad_bias) {
+    if (part_b) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) red[(pl * lanes_c + lc) * VEC + e] = sb[e];
     }
     if (HAS_NOISE) red[256 * VEC + threadIdx.x] = sn;
     __syncthreads();
-    if (grad_bias) {
+    if (part_b) {
         for (int j = threadIdx.x; j < lanes_c * VEC; j += 256) {
             float s = 0.f;
             for (int k = 0; k < npl; ++k) s += red[k * lanes_c * VEC + j];
-            atomicAdd(grad_bias + blockIdx.x * lanes_c * VEC + j, s);
+            part_b[(long long)blockIdx.y * p.size_b + blockIdx.x * lanes_c * VEC + j] = s;
         }
     }
     if (HAS_NOISE && threadIdx.x < 64) {
         float s = red[256 * VEC + threadIdx.x] + red[256 * VEC + threadIdx.x + 64] +
                   red[256 * VEC + threadIdx.x + 128] + red[256 * VEC + threadIdx.x + 192];
         s = wave_sum(s);
-        if (threadIdx.x == 0) atomicAdd(grad_nw, s);
+        if (threadIdx.x == 0) part_n[(long long)blockIdx.y * gridDim.x + blockIdx.x] = s;
     }
 }
 
-// Planar / generic: grid.x = plane (b*C + c) when step_b > 1, scalar loads, block reduction, one atomic per block.
+// Planar: grid.x = plane (b*C + c), grid.y = chunk of the plane; scalar loads, block reduction.
+// part_b[(b * chunks + chunk)][c], part_n[plane * chunks + chunk].
 template <typename T, bool HAS_NOISE>
 __global__ __launch_bounds__(256) void bias_act_bwd_planar_kernel(const T* __restrict__ gy, const T* __restrict__ out,
-                                                                  T* __restrict__ gx, float* __restrict__ grad_bias,
+                                                                  T* __restrict__ gx, float* __restrict__ part_b,
                                                                   const float* __restrict__ noise,
-                                                                  float* __restrict__ grad_nw, BiasActParams p) {
+                                                                  float* __restrict__ part_n, BiasActParams p) {
     __shared__ float red[8];
     const long long plane = blockIdx.x;
     const int c = (int)(plane % p.size_b);
     const long long b = plane / p.size_b;
     const long long base = plane * p.step_b;
-    // noise index of element j of this plane: planar -> b*pix + j; channels-last scalar fallback (step_b == 1,
-    // "plane" = one element) -> its pixel index b
-    const long long nbase = (p.step_b == 1) ? (p.noise_batch == 1 ? b % p.pix : b)
-                                            : (p.noise_batch == 1 ? 0 : b * p.pix);
+    const long long nbase = p.noise_batch == 1 ? 0 : b * p.pix;      // noise index of element j of this plane: b*pix + j
     float sb = 0.f, sn = 0.f;
     for (int j = blockIdx.y * 256 + threadIdx.x; j < p.step_b; j += gridDim.y * 256) {
         const float f = load_as_f32(gy + base + j) * p.scale *
@@ -239,66 +242,206 @@ __global__ __launch_bounds__(256) void bias_act_bwd_planar_kernel(const T* __res
     if ((threadIdx.x & 63) == 0) { red[w] = sb; red[4 + w] = sn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (grad_bias) atomicAdd(grad_bias + c, red[0] + red[1] + red[2] + red[3]);
-        if (HAS_NOISE) atomicAdd(grad_nw, red[4] + red[5] + red[6] + red[7]);
+        if (part_b) part_b[(b * gridDim.y + blockIdx.y) * p.size_b + c] = red[0] + red[1] + red[2] + red[3];
+        if (HAS_NOISE) part_n[plane * gridDim.y + blockIdx.y] = red[4] + red[5] + red[6] + red[7];
     }
+}
+
+// Channels-last / [B, C] maps the vector kernel cannot take (channel count not a whole number of 16-byte vectors, or
+// unaligned pointers): grid.x = channel, grid.y = slice of the pixels; a thread walks pixels q = y*256 + t, + 256*gridDim.y ...
+template <typename T, bool HAS_NOISE>
+__global__ __launch_bounds__(256) void bias_act_bwd_strided_kernel(const T* __restrict__ gy, const T* __restrict__ out,
+                                                                   T* __restrict__ gx, float* __restrict__ part_b,
+                                                                   const float* __restrict__ noise,
+                                                                   float* __restrict__ part_n, BiasActParams p,
+                                                                   long long npix) {
+    __shared__ float red[8];
+    const int c = blockIdx.x;
+    float sb = 0.f, sn = 0.f;
+    for (long long q = (long long)blockIdx.y * 256 + threadIdx.x; q < npix; q += (long long)gridDim.y * 256) {
+        const long long i = q * p.size_b + c;
+        const float f = load_as_f32(gy + i) * p.scale * ((load_as_f32(out + i) > 0.f || p.act != 3) ? 1.f : p.alpha);
+        store_from_f32(gx + i, f);
+        sb += f;
+        if (HAS_NOISE) sn = fmaf(f, noise[p.noise_batch == 1 ? q % p.pix : q], sn);
+    }
+    sb = wave_sum(sb);
+    if (HAS_NOISE) sn = wave_sum(sn);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w] = sb; red[4 + w] = sn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (part_b) part_b[(long long)blockIdx.y * p.size_b + c] = red[0] + red[1] + red[2] + red[3];
+        if (HAS_NOISE) part_n[(long long)blockIdx.y * gridDim.x + c] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+// grad_bias[c] = sum_j part_b[j][c]: a block takes 8 channels x 32 slices of the partial rows (up to 1024 rows of partials
+// behind the large maps: one thread per channel would walk them in a ~100 us dependent chain); every thread adds its
+// contiguous slice in row order, the 32 slice sums meet in LDS and are added in slice order.  grad_nw: the LAST block adds
+// the n_n partials, each thread its strided share in index order, then a fixed tree.  No atomics, fixed association.
+constexpr int BRC = 8, BRJ = 32;
+__global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(const float* __restrict__ part_b, float* __restrict__ grad_bias,
+                                                                  int C, long long n_b, const float* __restrict__ part_n,
+                                                                  float* __restrict__ grad_nw, long long n_n, int bias_blocks) {
+    __shared__ float red[256];
+    if ((int)blockIdx.x < bias_blocks) {
+        const int cl = threadIdx.x % BRC, jg = threadIdx.x / BRC;
+        const int c = blockIdx.x * BRC + cl;
+        const long long per = (n_b + BRJ - 1) / BRJ;
+        const long long j0 = jg * per, j1 = (j0 + per < n_b) ? j0 + per : n_b;
+        float s = 0.f;
+        if (c < C) {
+#pragma unroll 8
+            for (long long j = j0; j < j1; ++j) s += part_b[j * C + c];
+        }
+        red[jg * BRC + cl] = s;
+        __syncthreads();
+        if (threadIdx.x < BRC && c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < BRJ; ++g) t += red[g * BRC + threadIdx.x];
+            grad_bias[c] = t;
+        }
+        return;
+    }
+    float s = 0.f;
+    for (long long j = threadIdx.x; j < n_n; j += 256) s += part_n[j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *grad_nw = red[0];
+}
+
+// The launch geometry of the backward, a function of the SHAPE only (the workspace query and the launch must agree).
+struct BwdPlan {
+    int path;                   // 0 channels-last vectors, 1 planar, 2 strided
+    int lanes_c, gx_blocks;     // path 0
+    long long npix, ppb, gy_blocks;
+    long long planes; int chunks;
+    long long n_b, n_n;         // partial rows of part_b ([n_b][C]) / entries of part_n
+};
+
+static BwdPlan bwd_plan(long long size_x, int step_b, int size_b, int vec) {
+    BwdPlan q{};
+    if (step_b == 1 && size_b % vec == 0) {
+        const int nvec = size_b / vec;
+        int lanes_c = 1;
+        while (lanes_c < 64 && nvec % (lanes_c * 2) == 0) lanes_c *= 2;
+        q.path = 0;
+        q.lanes_c = lanes_c;
+        q.npix = size_x / size_b;
+        q.gx_blocks = nvec / lanes_c;
+        long long want_y = 1024 / q.gx_blocks; if (want_y < 1) want_y = 1;
+        const long long npl = 256 / lanes_c;
+        long long ppb = (q.npix + want_y - 1) / want_y;
+        q.ppb = ((ppb + npl - 1) / npl) * npl;
+        q.gy_blocks = (q.npix + q.ppb - 1) / q.ppb;
+        q.n_b = q.gy_blocks;
+        q.n_n = q.gy_blocks * q.gx_blocks;
+    } else if (step_b == 1) {
+        q.path = 2;
+        q.npix = size_x / size_b;
+        long long chunks = (q.npix + 4095) / 4096; if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
+        q.chunks = (int)chunks;
+        q.n_b = chunks;
+        q.n_n = chunks * size_b;
+    } else {
+        q.path = 1;
+        q.planes = size_x / step_b;
+        int chunks = (step_b + 4095) / 4096; if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
+        q.chunks = chunks;
+        q.n_b = (q.planes / size_b) * chunks;
+        q.n_n = q.planes * chunks;
+    }
+    return q;
 }
 
 template <typename T>
 static int bwd_dispatch(const void* gy, const void* out, void* gx, float* grad_bias, const float* noise,
-                        float* grad_nw, const BiasActParams& p, hipStream_t s) {
+                        float* grad_nw, const BiasActParams& p, float* ws, long long ws_floats, hipStream_t s) {
     constexpr int VEC = Vec16<T>::N;
     const bool aligned = (((uintptr_t)gy | (uintptr_t)out | (uintptr_t)gx) & 15u) == 0;
     const bool has_noise = noise && grad_nw;
-    if (p.step_b == 1 && p.size_b % VEC == 0 && aligned) {
-        const int nvec = p.size_b / VEC;
-        int lanes_c = 1;
-        while (lanes_c < 64 && nvec % (lanes_c * 2) == 0) lanes_c *= 2;
-        const long long npix = p.size_x / p.size_b;
-        const int gx_blocks = nvec / lanes_c;
-        long long want_y = 1024 / gx_blocks; if (want_y < 1) want_y = 1;
-        const long long npl = 256 / lanes_c;
-        long long ppb = (npix + want_y - 1) / want_y;
-        ppb = ((ppb + npl - 1) / npl) * npl;
-        const long long gy_blocks = (npix + ppb - 1) / ppb;
-        dim3 grid(gx_blocks, (unsigned)gy_blocks);
+    BwdPlan q = bwd_plan(p.size_x, p.step_b, p.size_b, aligned ? VEC : (1 << 30));
+    // workspace: [n_b][C] bias partials, then n_n noise partials
+    const long long need_b = grad_bias ? q.n_b * p.size_b : 0, need_n = has_noise ? q.n_n : 0;
+    if (need_b + need_n > 0 && (!ws || ws_floats < need_b + need_n)) return MSG_EINVAL;
+    float* part_b = grad_bias ? ws : nullptr;
+    float* part_n = has_noise ? ws + need_b : nullptr;
+    if (q.path == 0) {
+        dim3 grid(q.gx_blocks, (unsigned)q.gy_blocks);
         if (has_noise)
             hipLaunchKernelGGL((bias_act_bwd_cl_kernel<T, true>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
-                               (T*)gx, grad_bias, noise, grad_nw, p, lanes_c, npix, ppb);
+                               (T*)gx, part_b, noise, part_n, p, q.lanes_c, q.npix, q.ppb);
         else
             hipLaunchKernelGGL((bias_act_bwd_cl_kernel<T, false>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
-                               (T*)gx, grad_bias, noise, grad_nw, p, lanes_c, npix, ppb);
+                               (T*)gx, part_b, noise, part_n, p, q.lanes_c, q.npix, q.ppb);
+    } else if (q.path == 2) {
+        if (p.size_b > 65535 * 32) return MSG_EUNSUPPORTED;
+        dim3 grid(p.size_b, q.chunks);
+        if (has_noise)
+            hipLaunchKernelGGL((bias_act_bwd_strided_kernel<T, true>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
+                               (T*)gx, part_b, noise, part_n, p, q.npix);
+        else
+            hipLaunchKernelGGL((bias_act_bwd_strided_kernel<T, false>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
+                               (T*)gx, part_b, noise, part_n, p, q.npix);
     } else {
-        // planar NCHW (or odd channel counts, treated as planes of step_b elements)
-        const long long planes = p.size_x / p.step_b;
-        if (planes >= (1ll << 31)) return MSG_EUNSUPPORTED;
-        int chunks = (p.step_b + 4095) / 4096; if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
-        dim3 grid((unsigned)planes, chunks);
+        // planar NCHW
+        if (q.planes >= (1ll << 31)) return MSG_EUNSUPPORTED;
+        dim3 grid((unsigned)q.planes, q.chunks);
         if (has_noise)
             hipLaunchKernelGGL((bias_act_bwd_planar_kernel<T, true>), grid, dim3(256), 0, s, (const T*)gy,
-                               (const T*)out, (T*)gx, grad_bias, noise, grad_nw, p);
+                               (const T*)out, (T*)gx, part_b, noise, part_n, p);
         else
             hipLaunchKernelGGL((bias_act_bwd_planar_kernel<T, false>), grid, dim3(256), 0, s, (const T*)gy,
-                               (const T*)out, (T*)gx, grad_bias, noise, grad_nw, p);
+                               (const T*)out, (T*)gx, part_b, noise, part_n, p);
     }
+    if (MSG_CHECK_LAUNCH() != MSG_OK) return MSG_ELAUNCH;
+    if (need_b + need_n == 0) return MSG_OK;
+    const int bias_blocks = grad_bias ? (p.size_b + BRC - 1) / BRC : 0;
+    hipLaunchKernelGGL(bias_act_bwd_reduce_kernel, dim3(bias_blocks + (has_noise ? 1 : 0)), dim3(256), 0, s, part_b, grad_bias,
+                       p.size_b, q.n_b, part_n, grad_nw, q.n_n, bias_blocks);
     return MSG_CHECK_LAUNCH();
+}
+
+extern "C" long long msg_bias_act_backward_workspace(long long size_x, int step_b, int size_b, int has_noise) {
+    if (size_x <= 0 || step_b <= 0 || size_b <= 0 || size_x % ((long long)step_b * size_b) != 0) return 0;
+    // (whether the vector path is taken depends on the storage type's vector width and on pointer alignment, which this
+    //  query does not see: the largest need over the candidates)
+    long long need = 0;
+    const int vecs[3] = {4, 8, 1 << 30};
+    for (int k = 0; k < 3; ++k) {
+        const BwdPlan q = bwd_plan(size_x, step_b, size_b, vecs[k]);
+        const long long n = q.n_b * size_b + (has_noise ? q.n_n : 0);
+        if (n > need) need = n;
+    }
+    return need;
 }
 
 extern "C" int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
                                      long long size_x, int step_b, int size_b,
                                      float* grad_bias, const float* noise, float* grad_noise_weight,
-                                     int noise_batch, int pix, float alpha, float scale, void* stream) {
-    if (size_x == 0) return MSG_OK;
-    if (!gy || !out || !gx || size_x < 0 || step_b <= 0 || size_b <= 0) return MSG_EINVAL;
+                                     int noise_batch, int pix, float alpha, float scale,
+                                     float* ws, long long ws_floats, void* stream) {
+    if (size_x < 0 || step_b <= 0 || size_b <= 0) return MSG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (size_x == 0) {                                 // empty map: the sums are zeros (the results are overwritten, not accumulated)
+        if (grad_bias && hipMemsetAsync(grad_bias, 0, sizeof(float) * size_b, s) != hipSuccess) return MSG_ELAUNCH;
+        if (noise && grad_noise_weight && hipMemsetAsync(grad_noise_weight, 0, sizeof(float), s) != hipSuccess) return MSG_ELAUNCH;
+        return MSG_OK;
+    }
+    if (!gy || !out || !gx) return MSG_EINVAL;
     if (size_x % ((long long)step_b * size_b) != 0) return MSG_EINVAL;
     if (noise && grad_noise_weight && (pix <= 0 || noise_batch <= 0)) return MSG_EINVAL;
     if (noise && grad_noise_weight && step_b > 1 && pix != step_b) return MSG_EINVAL;
-    if (size_x == 0) return MSG_OK;
     BiasActParams p{size_x, step_b, size_b, noise_batch, pix, 3, 1, alpha, scale};
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == MSG_F32) return bwd_dispatch<float>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
-    if (dtype == MSG_BF16) return bwd_dispatch<bf16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
-    if (dtype == MSG_F16) return bwd_dispatch<f16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, s);
+    if (dtype == MSG_F32) return bwd_dispatch<float>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, ws, ws_floats, s);
+    if (dtype == MSG_BF16) return bwd_dispatch<bf16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, ws, ws_floats, s);
+    if (dtype == MSG_F16) return bwd_dispatch<f16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, ws, ws_floats, s);
     return MSG_EUNSUPPORTED;
 }
 

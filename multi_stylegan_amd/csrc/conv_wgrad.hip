@@ -13,10 +13,13 @@
 // 64 pixels (bf16) / 32 pixels (f32) per step, double-buffered through registers like the forward kernel.  The grid
 // is 1-D over (channel tile, tap, K-slice) in an XCD-aware order (see the kernel); a K-slice is a sample or a chunk
 // of one (per-sample weights), or -- shared weights -- a chunk of the pixels of ALL samples concatenated (the batch is
-// folded into K; the chunk count comes from a wave-quantisation cost model in the launcher).  Output is fp32; slices
-// either own their own GW[z] (per-sample gradients of the modulated conv) or accumulate into one GW with float
-// atomics (128-B runs).  On power-of-two maps the staging loads are buffer loads with a constant per-lane offset and
-// an SGPR cursor (UNI, see the kernel); other maps take the generic incremental addressing.
+// folded into K; the chunk count comes from a wave-quantisation cost model in the launcher).  Output is fp32.  A GW that
+// is the sum of several K-slices is NOT accumulated with float atomics (their arrival order made the weight gradients,
+// and every training step behind them, differ from run to run): each slice stores its partial tile into its own slab of
+// a caller-provided workspace, and wgrad_reduce_kernel adds the slabs in slice order -- a fixed association, bit-identical
+// results -- writing GW in the kernel layout or, transposed on the way, in the parameter's own [O][I][tap] layout.
+// On power-of-two maps the staging loads are buffer loads with a constant per-lane offset and an SGPR cursor (UNI, see
+// the kernel); other maps take the generic incremental addressing.
 // pixel_shuffle = 1 is the weight gradient of the generator's 2x2 stride-2 transposed conv: tap (dy,dx) pairs
 // X[b,h,w,:] with GY[b, 2h+dy, 2w+dx, :].
 #include "msg_common.h"
@@ -32,7 +35,7 @@ __device__ __attribute__((aligned(256))) unsigned int g_wgrad_zero_page[64];   /
 struct WgradParams {
     int B, IH, IW, Cx, I, OH, OW, ldgy, O;
     int kh, kw, stride, pad, pixel_shuffle;
-    int per_sample, chunks_per_sample, pix_per_chunk, atomic;
+    int per_sample, chunks_per_sample, pix_per_chunk, split;   // split: this launch writes K-slice slabs (see the reduce)
     int xcd_slices;                                   // 1: one K-slice per XCD (single channel tile), 0: tile-major order
     int nz;                                           // number of K-slices (samples x chunks, or chunks when folded)
     int fold;                                         // 1: shared weights, K runs over the concatenated pixels of ALL samples
@@ -40,6 +43,7 @@ struct WgradParams {
     int oi_major;                                     // 1: gw[o][i][tap] (the parameter's own layout), 0: gw[o][tap][ldgw]
     float gain;                                       // multiplies the result (equalized-lr scale of the layer)
     long long gw_zstride;
+    long long slab;                                   // floats per slab: O * taps * ldgw
 };
 
 constexpr int WT = 128;                              // tile extent in both channel dimensions
@@ -60,7 +64,7 @@ constexpr int BUF_OOB = (int)0x80000000;             // voffset >= num_records: 
 
 template <typename T, bool DMA, bool UNI>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ gy, const T* __restrict__ x,
-                                                            float* __restrict__ gw, WgradParams p) {
+                                                            float* __restrict__ gw, float* __restrict__ ws, WgradParams p) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int KP = WgCfg<T>::KP;
     constexpr int ROW = WT * sizeof(T);
@@ -338,7 +342,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     // ---- epilogue: fp32, lanes 0..31 = 32 consecutive input channels (128-B runs)
     const int lr = lane & 31, lh = lane >> 5;
     const int taps = p.kh * p.kw;
-    float* gz = gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+    // a K-slice of a split sum owns slab z of the workspace (kernel layout, every element written: zeros included)
+    float* gz = p.split ? ws + (long long)z * p.slab : gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+    const bool oi_major = p.oi_major && !p.split;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -349,35 +355,100 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             for (int e = 0; e < 16; ++e) {
                 const int o = o0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (o >= p.O) continue;
-                float* dst = p.oi_major ? gz + ((long long)o * p.I + ic) * taps + tap
-                                        : gz + ((long long)o * taps + tap) * p.ldgw + ic;
-                if (p.oi_major && ic >= p.I) continue;
-                const float v = acc[i][j][e] * p.gain;
-                if (p.atomic) atomicAdd(dst, v);
-                else *dst = v;
+                float* dst = oi_major ? gz + ((long long)o * p.I + ic) * taps + tap
+                                      : gz + ((long long)o * taps + tap) * p.ldgw + ic;
+                if (oi_major && ic >= p.I) continue;
+                *dst = acc[i][j][e] * p.gain;
             }
         }
 }
 
+// ---- the fixed-order sum of the K-slice slabs -------------------------------------------------------------------
+//   out[(n)][o][tap][i] = ((ws[n*chunks + 0] + ws[n*chunks + 1]) + ...)[o][tap][i]        (oi_major: out[(n)][o][i][tap])
+// A block = 64 float4 columns x 4 slice groups: wave g adds its contiguous quarter of the slices in slice order (fully
+// coalesced 1-KiB reads), the four partial sums meet in LDS and are added in group order.  The association depends on
+// `chunks` only, never on timing.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                           long long slab, int chunks, int O, int taps, int I, int ldgw,
+                                                           int oi_major) {
+    __shared__ float4 part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long nvec = slab >> 2;
+    const long long v = (long long)blockIdx.x * 64 + lane;
+    const int n = blockIdx.y;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    if (v < nvec) {
+        const int per = (chunks + 3) >> 2;
+        const int c0 = grp * per, c1 = min(chunks, c0 + per);
+        const float4* src = reinterpret_cast<const float4*>(ws + ((long long)n * chunks + c0) * slab) + v;
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c, src += nvec) {
+            const float4 t = *src;
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+    }
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp != 0 || v >= nvec) return;
+    float4 t = part[0][lane];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) { t.x += part[g][lane].x; t.y += part[g][lane].y; t.z += part[g][lane].z; t.w += part[g][lane].w; }
+    if (!oi_major) {
+        reinterpret_cast<float4*>(out + (long long)n * slab)[v] = t;
+        return;
+    }
+    const int vpr = ldgw >> 2;                                     // float4 per (o, tap) row
+    const long long row = v / vpr;
+    const int i = (int)(v - row * vpr) * 4;
+    const int o = (int)(row / taps), tap = (int)(row - (long long)o * taps);
+    float* dst = out + ((long long)n * O + o) * I * taps + (long long)i * taps + tap;
+    const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i + k < I) dst[(long long)k * taps] = e[k];
+}
+
+// Launches the reduce for `n_out` results of `chunks` slabs each (shared by conv_wgrad_row3.hip).
+extern "C" int msg_wgrad_reduce_launch(const float* ws, float* gw, long long slab, int n_out, int chunks, int O, int taps,
+                                       int I, int ldgw, int oi_major, void* stream) {
+    const long long nvec = slab >> 2;
+    const long long blocks = (nvec + 63) / 64;
+    if (blocks >= (1ll << 31) || n_out > 65535) return MSG_EUNSUPPORTED;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks, (unsigned)n_out), dim3(256), 0, (hipStream_t)stream,
+                       ws, gw, slab, chunks, O, taps, I, ldgw, oi_major);
+    return MSG_CHECK_LAUNCH();
+}
+
+// conv_wgrad_row3.hip: returns 0 if the geometry is not its own, 1 if it planned / launched, a negative MSG_E* code on
+// error.  *need = workspace floats of the launch it would make (0: no split).  plan_only: no launch.
 extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* gw, int dtype,
                                          int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
                                          int kh, int kw, int stride, int pad, int pixel_shuffle,
-                                         int per_sample, int k_chunks, int oi_major, float gain, void* stream);
+                                         int per_sample, int k_chunks, int oi_major, float gain,
+                                         float* ws, long long ws_floats, int plan_only, long long* need, void* stream);
 
-extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
-                                int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
-                                int kh, int kw, int stride, int pad, int pixel_shuffle,
-                                int per_sample, int k_chunks, int oi_major, float gain, void* stream) {
+static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
+                      int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
+                      int kh, int kw, int stride, int pad, int pixel_shuffle,
+                      int per_sample, int k_chunks, int oi_major, float gain,
+                      float* ws, long long ws_floats, int plan_only, long long* need, void* stream) {
+    *need = 0;
     if (B == 0) return MSG_OK;
-    if (!gy || !x || !gw || B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || O <= 0 || I <= 0 || kh <= 0 ||
-        kw <= 0 || stride <= 0 || Cx <= 0 || ldgy <= 0 || ldgw < I || k_chunks <= 0)
+    if (B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || O <= 0 || I <= 0 || kh <= 0 ||
+        kw <= 0 || stride <= 0 || Cx <= 0 || ldgy <= 0 || ldgw < I || ldgw % 4 || k_chunks <= 0)
         return MSG_EINVAL;
+    if (!plan_only && (!gy || !x || !gw)) return MSG_EINVAL;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz;
-    if (Cx % vec || ldgy % vec || (((uintptr_t)gy | (uintptr_t)x) & 15u)) return MSG_EUNSUPPORTED;
-    if (msg_conv2d_wgrad_row3_try(gy, x, gw, dtype, B, IH, IW, Cx, I, OH, OW, ldgy, O, ldgw, kh, kw, stride, pad,
-                                  pixel_shuffle, per_sample, k_chunks, oi_major, gain, stream))
-        return MSG_CHECK_LAUNCH();                 // kh x 3 'same' convs on wide maps: three taps per workgroup
+    if (Cx % vec || ldgy % vec) return MSG_EUNSUPPORTED;
+    if (!plan_only && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gw | (uintptr_t)ws) & 15u)) return MSG_EUNSUPPORTED;
+    {
+        const int r3 = msg_conv2d_wgrad_row3_try(gy, x, gw, dtype, B, IH, IW, Cx, I, OH, OW, ldgy, O, ldgw, kh, kw, stride, pad,
+                                                 pixel_shuffle, per_sample, k_chunks, oi_major, gain, ws, ws_floats, plan_only,
+                                                 need, stream);
+        if (r3 < 0) return r3;
+        if (r3) return MSG_OK;                     // kh x 3 'same' convs on wide maps: three taps per workgroup
+    }
     WgradParams p{};
     p.B = B; p.IH = IH; p.IW = IW; p.Cx = Cx; p.I = I; p.OH = OH; p.OW = OW; p.ldgy = ldgy; p.O = O;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.pixel_shuffle = pixel_shuffle;
@@ -386,7 +457,6 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     const int npix = OH * OW;
     const int kp = dtype == MSG_BF16 ? 64 : 32;
     p.pix_per_chunk = (((npix + k_chunks - 1) / k_chunks + kp - 1) / kp) * kp;
-    p.atomic = !(per_sample && k_chunks == 1);
     long long zs = (long long)B * k_chunks;
     // uniform-row addressing: K-steps map onto whole rows / whole row fragments and per-sample tensors fit 31-bit offsets
     static int variant = -1;
@@ -401,17 +471,20 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     if (can_fold && uni && !((npix % kp == 0 || kp % npix == 0) && B * gy_bytes < (1ll << 32) && B * x_bytes < (1ll << 32)))
         uni = false;
     // shared weights: fold the batch into K (one sweep over the concatenated pixels of all samples), so that small maps
-    // still give every workgroup a long K loop and the float atomics shrink from B*chunks to `chunks` per element
+    // still give every workgroup a long K loop and the slabs to add shrink from B*chunks to `chunks` per element
     if (can_fold) {
         const long long steps = ((long long)B * npix + kp - 1) / kp;
         const long long tiles = (long long)((O + WT - 1) / WT) * ((I + WT - 1) / WT) * kh * kw;
         // K split: pick the chunk count that minimises (rounds of 512 co-resident workgroups) x (K-steps per workgroup +
-        // a fixed prologue/epilogue/atomics cost of ~8 steps).  A fixed target count left a quarter of the chip idle in
-        // the last round on some layers (768->768 @32^2: 5 chunks = 3.2 rounds, 274 us; 3 chunks = 1.9 rounds, 226 us).
+        // a fixed prologue/epilogue cost of ~8 steps, + ~MSG_WGRAD_SLAB_COST steps when the sum is split: a workgroup's
+        // 64-KiB slab tile is written once and read once by the reduce).  A fixed target count left a quarter of the chip
+        // idle in the last round on some layers (768->768 @32^2: 5 chunks = 3.2 rounds, 274 us; 3 chunks = 1.9 rounds, 226 us).
         static int target_wgs = -1;                      // MSG_WGRAD_TARGET_WGS > 0: the old fixed-target rule (A/B)
         if (target_wgs < 0) { const char* e = getenv("MSG_WGRAD_TARGET_WGS"); target_wgs = e ? atoi(e) : 0; }
         static int slice_tiles = -1;                     // MSG_WGRAD_SLICE_TILES: largest channel-tile count that takes the slice-per-XCD order
         if (slice_tiles < 0) { const char* e = getenv("MSG_WGRAD_SLICE_TILES"); slice_tiles = e ? atoi(e) : 6; }
+        static int slab_cost = -1;
+        if (slab_cost < 0) { const char* e = getenv("MSG_WGRAD_SLAB_COST"); slab_cost = e ? atoi(e) : 6; }
         const bool sliced = tiles <= (long long)kh * kw * slice_tiles;       // slices are dealt to the XCDs 8 at a time
         long long chunks = 1;
         if (target_wgs > 0) {
@@ -424,7 +497,7 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
             for (long long c = 1; c <= cmax; c += (sliced && c >= 8 ? 8 : 1)) {
                 if (sliced && c > 1 && c < 8) continue;
                 const long long rounds = (tiles * c + 511) / 512;
-                const long long cost = rounds * ((steps + c - 1) / c + 8);
+                const long long cost = rounds * ((steps + c - 1) / c + 8 + (c > 1 ? slab_cost : 0));
                 if (best < 0 || cost < best) { best = cost; chunks = c; }
                 if (tiles * c > 8192) break;
             }
@@ -432,16 +505,19 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
         if (chunks < 1) chunks = 1;
         if (chunks > 65535) chunks = 65535;
         p.fold = 1;
-        p.chunks_per_sample = (int)chunks;               // (z = chunk; the sample index derived from it is always 0)
         p.pix_per_chunk = (int)(((steps + chunks - 1) / chunks) * kp);
         zs = ((long long)B * npix + p.pix_per_chunk - 1) / p.pix_per_chunk;
-        p.chunks_per_sample = (int)zs;
-        p.atomic = zs > 1;
+        p.chunks_per_sample = (int)zs;                   // (z = chunk; the sample index derived from it is always 0)
     }
+    // K-slices per result: a result that is the sum of several slices goes through slabs + the fixed-order reduce
+    const long long chunks_per_out = per_sample ? k_chunks : zs;
+    const int n_out = per_sample ? B : 1;
+    p.split = chunks_per_out > 1;
     p.o_tiles = (O + WT - 1) / WT;
     p.i_tiles = (I + WT - 1) / WT;
     p.ldgw = ldgw;
     p.gw_zstride = oi_major ? (long long)O * I * kh * kw : (long long)O * kh * kw * ldgw;
+    p.slab = (long long)O * kh * kw * ldgw;
     p.oi_major = oi_major;
     p.gain = gain;
     p.nz = (int)zs;
@@ -450,20 +526,44 @@ extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dt
     p.xcd_slices = (p.o_tiles * p.i_tiles <= slice_tiles2 && variant != 4 && (slice_tiles2 == 1 || zs % 8 == 0 || zs >= 64)) ||
                    (variant == 5 && zs % 8 == 0);   // 4 / 5: A/B switches
     const long long nblk = (p.xcd_slices ? ((zs + 7) / 8) * 8 : zs) * p.o_tiles * p.i_tiles * kh * kw;
-    if (zs > (1 << 24) || nblk >= (1ll << 31)) return MSG_EUNSUPPORTED;
+    if (zs > (1 << 24) || nblk >= (1ll << 31) || chunks_per_out > (1 << 24)) return MSG_EUNSUPPORTED;
+    *need = p.split ? zs * p.slab : 0;
+    if (plan_only) return MSG_OK;
+    if (p.split && (!ws || ws_floats < *need)) return MSG_EINVAL;
     dim3 grid((unsigned)nblk);
     hipStream_t s = (hipStream_t)stream;
     // Register staging keeps two K-steps of loads in flight; measured faster here than LDS-DMA with one step in
     // flight (685 vs 608 TFLOP/s at 3x3 512->512 @256^2): both operands of this kernel stream from beyond L2.
     const bool dma = variant == 1;                   // MSG_CONV_VARIANT=1 forces LDS-DMA staging, 2 the generic addressing (A/B)
     if (dtype == MSG_BF16) {
-        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
-        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
+        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     } else {
-        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
-        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, p);
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
     }
-    return MSG_CHECK_LAUNCH();
+    const int rc = MSG_CHECK_LAUNCH();
+    if (rc != MSG_OK || !p.split) return rc;
+    return msg_wgrad_reduce_launch(ws, gw, p.slab, n_out, (int)chunks_per_out, O, kh * kw, I, ldgw, oi_major, stream);
+}
+
+extern "C" long long msg_conv2d_wgrad_workspace(int dtype, int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy,
+                                                int O, int ldgw, int kh, int kw, int stride, int pad, int pixel_shuffle,
+                                                int per_sample, int k_chunks) {
+    long long need = 0;
+    const int rc = wgrad_impl(nullptr, nullptr, nullptr, dtype, B, IH, IW, Cx, I, OH, OW, ldgy, O, ldgw, kh, kw, stride, pad,
+                              pixel_shuffle, per_sample, k_chunks, 0, 1.f, nullptr, 0, 1, &need, nullptr);
+    return rc == MSG_OK ? need : (long long)rc;
+}
+
+extern "C" int msg_conv2d_wgrad(const void* gy, const void* x, float* gw, int dtype,
+                                int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
+                                int kh, int kw, int stride, int pad, int pixel_shuffle,
+                                int per_sample, int k_chunks, int oi_major, float gain,
+                                float* ws, long long ws_floats, void* stream) {
+    long long need = 0;
+    return wgrad_impl(gy, x, gw, dtype, B, IH, IW, Cx, I, OH, OW, ldgy, O, ldgw, kh, kw, stride, pad, pixel_shuffle,
+                      per_sample, k_chunks, oi_major, gain, ws, ws_floats, 0, &need, stream);
 }

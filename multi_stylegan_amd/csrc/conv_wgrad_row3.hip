@@ -14,7 +14,7 @@
 //
 // Same LDS image as conv_wgrad.hip ([pixel][128 channels], rows rotated by 64 B * (pixel & 3), ds_read_b64_tr_b16),
 // same buffer-load addressing (per-thread constant offset + wave-uniform SGPR cursor, out-of-range rows read zeros),
-// same fp32 epilogue (stores or float atomics into GW[o][tap][i]).
+// same fp32 epilogue (plain stores into GW[o][tap][i], or into the K-slice's slab when the sum is split: conv_wgrad.hip).
 #include "msg_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -26,10 +26,10 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 struct Row3Params {
     int B, H, W, Cx, I, ldgy, O, ldgw;
     int kh, pad;                                      // kernel rows and vertical padding (kw = 3, horizontal padding 1)
-    int per_sample, steps_per_chunk, chunks_per_sample, nz, atomic;
+    int per_sample, steps_per_chunk, chunks_per_sample, nz, split;
     int o_tiles, i_tiles, oi_major;
     float gain;
-    long long gw_zstride;
+    long long gw_zstride, slab;
 };
 
 constexpr int R3_ROW = 256;                           // bytes of one pixel row of a 128-channel tile
@@ -45,7 +45,7 @@ __device__ __forceinline__ int r3_off(int r, int ch) { return r * R3_ROW + (((ch
 // pixels between two zero rows, written once), tap kw of pixel p of image row q reads X row 34 q + p + kw.
 template <bool W32>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
-                                                                 float* __restrict__ gw, Row3Params p) {
+                                                                 float* __restrict__ gw, float* __restrict__ ws, Row3Params p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * R3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
     // ---- epilogue: fp32, lanes 0..31 = 32 consecutive input channels (128-B runs), one pass per horizontal tap
     const int lr = lane & 31, lh = lane >> 5;
     const int taps = p.kh * 3;
-    float* gz = gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+    float* gz = p.split ? ws + (long long)z * p.slab : gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+    const bool oi_major = p.oi_major && !p.split;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int tap = khi * 3 + k;
@@ -258,12 +259,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
                 for (int e = 0; e < 16; ++e) {
                     const int o = o0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     if (o >= p.O) continue;
-                    float* dst = p.oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
-                                            : gz + ((long long)o * taps + tap) * p.ldgw + icn;
-                    if (p.oi_major && icn >= p.I) continue;
-                    const float v = acc[k][i][j][e] * p.gain;
-                    if (p.atomic) atomicAdd(dst, v);
-                    else *dst = v;
+                    float* dst = oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
+                                          : gz + ((long long)o * taps + tap) * p.ldgw + icn;
+                    if (oi_major && icn >= p.I) continue;
+                    *dst = acc[k][i][j][e] * p.gain;
                 }
             }
     }
@@ -296,7 +295,7 @@ extern "C" int msg_wgrad3_debug_read(void* host_dst, int nbytes) {
 
 template <bool W32>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
-                                                                  float* __restrict__ gw, Row3Params p) {
+                                                                  float* __restrict__ gw, float* __restrict__ ws, Row3Params p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * R3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -538,7 +537,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
     // ---- epilogue: fp32; lanes 0..15 of a row group = 16 consecutive input channels, one pass per tap and block
     const int l15 = lane & 15;
     const int taps = p.kh * 3;
-    float* gz = gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+    float* gz = p.split ? ws + (long long)z * p.slab : gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+    const bool oi_major = p.oi_major && !p.split;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int tap = khi * 3 + k;
@@ -552,22 +552,25 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
                 for (int e = 0; e < 4; ++e) {
                     const int o = o0 + wm * 64 + i * 16 + 4 * g4 + e;
                     if (o >= p.O) continue;
-                    float* dst = p.oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
-                                            : gz + ((long long)o * taps + tap) * p.ldgw + icn;
-                    if (p.oi_major && icn >= p.I) continue;
-                    const float v = acc[k][i][j][e] * p.gain;
-                    if (p.atomic) atomicAdd(dst, v);
-                    else *dst = v;
+                    float* dst = oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
+                                          : gz + ((long long)o * taps + tap) * p.ldgw + icn;
+                    if (oi_major && icn >= p.I) continue;
+                    *dst = acc[k][i][j][e] * p.gain;
                 }
             }
     }
 }
 
-// Called by msg_conv2d_wgrad (conv_wgrad.hip) after its argument checks; returns 1 if it launched.
+extern "C" int msg_wgrad_reduce_launch(const float* ws, float* gw, long long slab, int n_out, int chunks, int O, int taps,
+                                       int I, int ldgw, int oi_major, void* stream);
+
+// Called by msg_conv2d_wgrad (conv_wgrad.hip) after its argument checks; returns 1 if the geometry is this file's (planned,
+// and launched unless plan_only), 0 if not, a negative MSG_E* code on error.  *need = workspace floats (0: no split).
 extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* gw, int dtype,
                                          int B, int IH, int IW, int Cx, int I, int OH, int OW, int ldgy, int O, int ldgw,
                                          int kh, int kw, int stride, int pad, int pixel_shuffle,
-                                         int per_sample, int k_chunks, int oi_major, float gain, void* stream) {
+                                         int per_sample, int k_chunks, int oi_major, float gain,
+                                         float* ws, long long ws_floats, int plan_only, long long* need, void* stream) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("MSG_WGRAD_ROW3"); enabled = e ? atoi(e) : 1; }
     static int w32_on = -1;                         // MSG_WGRAD_ROW3_W32=0: 32-wide maps stay on conv_wgrad_kernel (A/B)
@@ -589,50 +592,64 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     p.oi_major = oi_major;
     p.gain = gain;
     p.gw_zstride = oi_major ? (long long)O * I * kh * 3 : (long long)O * kh * 3 * ldgw;
+    p.slab = (long long)O * kh * 3 * ldgw;
     const long long steps_per_sample = w32 ? OH / 2 : (long long)OH * (OW / R3_KP);
     const long long tiles = (long long)p.o_tiles * p.i_tiles * kh;
-    long long zs;
+    long long zs, chunks_per_out;
     if (per_sample) {
-        // the caller chose k_chunks (and zero-filled GW iff k_chunks > 1)
+        // the caller chose k_chunks
         p.chunks_per_sample = k_chunks;
         p.steps_per_chunk = (int)((steps_per_sample + k_chunks - 1) / k_chunks);
-        p.atomic = k_chunks > 1;
         zs = (long long)B * k_chunks;
+        chunks_per_out = k_chunks;
     } else {
         // shared weights: the batch is folded into K; K split by the wave-quantisation cost model of conv_wgrad.hip
-        // with ONE workgroup per CU (rounds of 256) and ~3 steps of fixed cost per workgroup
+        // with ONE workgroup per CU (rounds of 256), ~3 steps of fixed cost per workgroup and, when the sum is split, the
+        // write + read of a workgroup's three 64-KiB slab tiles (~MSG_WGRAD3_SLAB_COST steps)
+        static int slab_cost = -1;
+        if (slab_cost < 0) { const char* e = getenv("MSG_WGRAD3_SLAB_COST"); slab_cost = e ? atoi(e) : 4; }
         const long long steps = (long long)B * steps_per_sample;
         long long chunks = 1, best = -1;
         const long long cmax = steps / 4 < 4096 ? steps / 4 : 4096;
         for (long long c = 1; c <= cmax; ++c) {
             const long long rounds = (tiles * c + 255) / 256;
-            const long long cost = rounds * ((steps + c - 1) / c + 3);
+            const long long cost = rounds * ((steps + c - 1) / c + 3 + (c > 1 ? slab_cost : 0));
             if (best < 0 || cost < best) { best = cost; chunks = c; }
             if (tiles * c > 4096) break;
         }
         p.steps_per_chunk = (int)((steps + chunks - 1) / chunks);
         zs = (steps + p.steps_per_chunk - 1) / p.steps_per_chunk;
         p.chunks_per_sample = (int)zs;
-        p.atomic = zs > 1;
+        chunks_per_out = zs;
     }
+    p.split = chunks_per_out > 1;
     p.nz = (int)zs;
     const long long nblk = zs * tiles;
     if (zs > (1 << 24) || nblk >= (1ll << 31)) return 0;
+    *need = p.split ? zs * p.slab : 0;
+    if (plan_only) return 1;
+    if (p.split && (!ws || ws_floats < *need)) return MSG_EINVAL;
     static int s16 = -1;                            // MSG_WGRAD_ROW3_S16=0: the 32x32x16 kernel (A/B)
     if (s16 < 0) { const char* e = getenv("MSG_WGRAD_ROW3_S16"); s16 = e ? atoi(e) : 1; }
     // (measured, bf16, B = 16, same box: 3x3 512->512 @256^2 per-sample 4235 -> 3930 us, @128^2 1079 -> 1010, 128->128 @256^2
     //  shared 318 -> 305, 384->256 @128^2 447 -> 421; 32-wide maps: 768->768 265 -> 254, 1024->768 333 -> 317)
     if (s16 && w32)
         hipLaunchKernelGGL(conv_wgrad_row3s_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     else if (s16)
         hipLaunchKernelGGL(conv_wgrad_row3s_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     else if (w32)
         hipLaunchKernelGGL(conv_wgrad_row3_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     else
         hipLaunchKernelGGL(conv_wgrad_row3_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, p);
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
+    if (MSG_CHECK_LAUNCH() != MSG_OK) return MSG_ELAUNCH;
+    if (p.split) {
+        const int rc = msg_wgrad_reduce_launch(ws, gw, p.slab, per_sample ? B : 1, (int)chunks_per_out, O, kh * 3, I, ldgw,
+                                               oi_major, stream);
+        if (rc != MSG_OK) return rc;
+    }
     return 1;
 }

@@ -50,11 +50,22 @@ class GeneratorSampler:
         self._z = [torch.zeros(batch_size, ld, device=self.device) for _ in range(2 if mixing else 1)]
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._image: Optional[torch.Tensor] = None
+        self._stamps: Optional[tuple] = None
         self.use_graph = use_graph and self.device.type == "cuda"
 
     def _forward(self) -> torch.Tensor:
         z = self._z if self.mixing else self._z[0]
         return self.generator(z, randomize_noise=self.randomize_noise, inject_index=self.inject_index)
+
+    def _weight_stamps(self) -> tuple:
+        """What the captured graph depends on besides its static buffers: the kernel-side weight images are built during the
+        warm-up, OUTSIDE the graph, and the graph holds pointers to them.  Any weight change (an EMA step on the wrapped
+        generator, load_generator_ema, load_checkpoint, an in-place edit) changes these stamps."""
+        return tuple(conv_ops._stamp(p) for p in self.generator.parameters())
+
+    def reset(self) -> None:
+        """Drop the captured graph; the next call re-captures (and re-lays the weights)."""
+        self._graph, self._image, self._stamps = None, None, None
 
     @torch.no_grad()
     def _capture(self) -> None:
@@ -69,6 +80,7 @@ class GeneratorSampler:
         with torch.cuda.graph(graph):
             self._image = self._forward()
         self._graph = graph
+        self._stamps = self._weight_stamps()
 
     @torch.no_grad()
     def __call__(self, z: Union[torch.Tensor, List[torch.Tensor], None] = None) -> torch.Tensor:
@@ -83,6 +95,8 @@ class GeneratorSampler:
             buf.copy_(t, non_blocking=True)
         if not self.use_graph:
             return self._forward()
+        if self._graph is not None and self._stamps != self._weight_stamps():
+            self.reset()                                    # the weights changed since the capture: stale images in the graph
         if self._graph is None:
             self._capture()
         self._graph.replay()

@@ -131,6 +131,17 @@ class ModelWrapper(object):
         # only discriminators that know about minibatch groups (ours) can take the concatenated batch
         self.batch_discriminator_passes = batch_discriminator_passes and \
             getattr(discriminator, "supports_minibatch_groups", False)
+        # Draws that decide WHICH optimiser steps an iteration contains (the CutMix gate, reference :331-332) must come out
+        # the same on every rank: a rank that runs two extra discriminator exchanges while the others start the
+        # generator's deadlocks RCCL or mixes up buckets.  Python's global `random` is rank-distinct by design (it also
+        # drives the per-rank style-mixing draws), so under data parallelism the gate uses a generator of its own whose
+        # seed rank 0 hands to everyone; a single process keeps the reference's `random.random()` stream.
+        self._control_rng: Optional[random.Random] = None
+        if msg_dist.collectives_active():
+            seed = torch.tensor([random.getrandbits(62)], dtype=torch.int64,
+                                device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.broadcast(seed, src=0)
+            self._control_rng = random.Random(int(seed.item()))
         self.iteration = 0                       # == progress_bar.n of the reference (1-based when tested, Q12)
         self.step_trace: Optional[Dict[str, torch.Tensor]] = None      # see _step
         self._param_names = {id(p): n for mod in (self.generator, self.discriminator)
@@ -196,6 +207,10 @@ class ModelWrapper(object):
             trace[f"{label}.gnorm"] = total.detach().clone()
             for n, p in named:
                 trace[f"{label}.delta.{n}"] = p.detach() - before[n]
+
+    def _control_random(self) -> float:
+        """``random.random()`` for control flow: identical on every rank (see ``_control_rng``)."""
+        return self._control_rng.random() if self._control_rng is not None else random.random()
 
     def _zero(self) -> None:
         self.discriminator_reducer.zero_grad()
@@ -284,8 +299,8 @@ class ModelWrapper(object):
         if dr.cut_mix is not None:
             do_cut_mix = dr.cut_mix
         else:
-            do_cut_mix = (random.random() <= (0.5 / float(self.epochs)) * float(self.epoch)) or \
-                (resume_training and random.random() <= 0.5)
+            do_cut_mix = (self._control_random() <= (0.5 / float(self.epochs)) * float(self.epoch)) or \
+                (resume_training and self._control_random() <= 0.5)
         if do_cut_mix:
             w_reg = hp["w_discriminator_regularization"]
             self._zero()
@@ -392,6 +407,8 @@ class ModelWrapper(object):
             state = module.state_dict()
             return {("module." + k if data_parallel_prefix else k): v for k, v in state.items()}
         extra = {"iteration": self.iteration, "epoch": self.epoch}
+        if self._control_rng is not None:
+            extra["control_rng"] = self._control_rng.getstate()
         ada = getattr(self.discriminator, "ada_state", None)
         if callable(ada):
             extra["ada"] = ada()
@@ -430,6 +447,8 @@ class ModelWrapper(object):
                 pl_state["mean_path_length"].to(self.device, torch.float).reshape(1)
         extra = checkpoint.get("multi_stylegan_amd", {})
         self.iteration = int(extra.get("iteration", self.iteration))
+        if self._control_rng is not None and "control_rng" in extra:
+            self._control_rng.setstate(extra["control_rng"])
         if "ada" in extra and callable(getattr(self.discriminator, "load_ada_state", None)):
             self.discriminator.load_ada_state(extra["ada"])
         # load_state_dict copies into the parameters in place: kernel-side weight images cached so far are stale

@@ -58,20 +58,29 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, noise, need_bias, negative_slope, scale):
-        g, step_b, pix, _ = _layout(grad_output)
-        dev = _lib.require_gpu(g, out, noise)
-        o = out.reshape(g.shape)
-        o = o.contiguous(memory_format=torch.channels_last) if (step_b == 1 and g.ndim == 4) else o.contiguous()
+        # The SAVED OUTPUT's memory layout picks the kernel (channels-last vectors or planes), not the incoming gradient's:
+        # a gradient that autograd summed from two consumers inherits the layout of whichever arrived first, and the engine's
+        # order in second-order passes depends on thread-local node counters, i.e. on the process's history -- a
+        # layout-dependent kernel choice would make the order of the bias sum, and so its last bit, vary between runs.
+        o, step_b, pix, _ = _layout(out)
+        dev = _lib.require_gpu(grad_output, o, noise)
+        g = grad_output.reshape(o.shape)
+        g = g.contiguous(memory_format=torch.channels_last) if (step_b == 1 and g.ndim == 4) else g.contiguous()
         gx = torch.empty_like(g)
         channels = g.shape[1]
-        gb = torch.zeros(channels, dtype=torch.float32, device=dev) if need_bias else None
+        # grad_bias / grad_noise_weight are overwritten by a fixed-order sum of per-workgroup partials (deterministic)
+        gb = torch.empty(channels, dtype=torch.float32, device=dev) if need_bias else None
         nz, nb = _noise_args(noise, g)
-        gnw = torch.zeros(1, dtype=torch.float32, device=dev) if noise is not None else None
+        gnw = torch.empty(1, dtype=torch.float32, device=dev) if noise is not None else None
+        need = 0
+        if need_bias or noise is not None:
+            need = _lib.lib().msg_bias_act_backward_workspace(g.numel(), step_b, channels, int(noise is not None))
+        ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
         with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
             code = _lib.lib().msg_bias_act_backward(
                 g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g, True), g.numel(), step_b, channels,
                 _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
-                _lib.stream_of(dev))
+                _lib.ptr(ws), need, _lib.stream_of(dev))
         _lib.check(code, "msg_bias_act_backward")
         ctx.save_for_backward(out, noise)
         ctx.cfg = (negative_slope, scale)

@@ -25,6 +25,15 @@ def _hyper(group) -> tuple:
     return (float(group["lr"]), float(b1), float(b2), float(group["eps"]))
 
 
+def _unshare_steps(_optimizer, state_dict):
+    """state_dict post hook: every parameter gets its own copy of its step counter."""
+    for entry in state_dict.get("state", {}).values():
+        step = entry.get("step")
+        if isinstance(step, torch.Tensor):
+            entry["step"] = step.clone()
+    return state_dict
+
+
 class FlatAdam:
     """Steps the parameters of ``reducer``'s buckets for ``optimizer`` (a ``torch.optim.Adam``)."""
 
@@ -44,7 +53,10 @@ class FlatAdam:
 
     def __init__(self, optimizer: torch.optim.Adam, reducer):
         self.optimizer, self.reducer = optimizer, reducer
-        self._group_of = {id(p): g for g in optimizer.param_groups for p in g["params"]}
+        self._group_of: Dict[int, dict] = {}
+        self._groups_seen: tuple = ()
+        self._adopted = False                                             # (the flat stores are still all zeros)
+        self._refresh_groups()
         self.step_count = 0
         self._step_tensor = torch.zeros((), dtype=torch.float32)          # what state_dict() shows as every 'step'
         self.param_flat: List[torch.Tensor] = []
@@ -53,22 +65,35 @@ class FlatAdam:
         self.ema_flat: List[Optional[torch.Tensor]] = []
         self._ema_rest: List[tuple] = []                                  # (ema parameter, parameter) pairs outside the buckets
         self._ema_model = self._ema_train = None
-        self._ema_first: List[Optional[torch.nn.Parameter]] = []
+        self._ema_params: List[Optional[List[torch.nn.Parameter]]] = []
         for b in reducer.buckets:
             self.param_flat.append(torch.zeros_like(b.flat))            # (zeros in the alignment padding between parameters)
             self.exp_avg.append(torch.zeros_like(b.flat))
             self.exp_avg_sq.append(torch.zeros_like(b.flat))
             self.ema_flat.append(None)
         self.adopt()
+        # state_dict() must not show ONE step tensor shared by every parameter: torch.save keeps the aliasing, and an Adam
+        # that advances `step` in place per parameter (CPU parameters, the torch 1.8 the reference pins) would then count
+        # ~400 steps per step after loading such a checkpoint
+        optimizer.register_state_dict_post_hook(_unshare_steps)
         # someone stepping the torch optimizer directly (not through ModelWrapper._step) gets the state in the form torch's
         # own Adam expects; the next flat step adopts what it did
         optimizer.register_step_pre_hook(lambda _opt, _args, _kwargs: self.release())
+
+    def _refresh_groups(self) -> None:
+        """``optimizer.param_groups`` is the owner of the hyper-parameters; ``load_state_dict`` REPLACES the group dicts (and a
+        scheduler or the user may edit them), so the parameter -> group table is rebuilt whenever the list's dicts change."""
+        seen = tuple(id(g) for g in self.optimizer.param_groups)
+        if seen != self._groups_seen:
+            self._group_of = {id(p): g for g in self.optimizer.param_groups for p in g["params"]}
+            self._groups_seen = seen
 
     # ---------------------------------------------------------------------------------------------------------
     def adopt(self) -> None:
         """(Re-)establish the flat layout from whatever the parameters and the optimizer's state hold now: after
         construction, after ``load_state_dict`` of the optimizer (which replaces the state tensors) or after anything
         that re-allocated a parameter's storage."""
+        self._refresh_groups()
         state = self.optimizer.state
         steps = []
         with torch.no_grad():
@@ -87,12 +112,18 @@ class FlatAdam:
                             m_view.copy_(st["exp_avg"])
                             v_view.copy_(st["exp_avg_sq"])
                         steps.append(int(float(st["step"])))
+                    elif self._adopted:
+                        # no moments came with this parameter (a checkpoint that lacks it): its slices of the flat stores
+                        # still hold the previous run's moments
+                        m_view.zero_()
+                        v_view.zero_()
                     state[p] = {"step": self._step_tensor, "exp_avg": m_view, "exp_avg_sq": v_view}
         if steps:
             # torch counts per parameter; every parameter of the buckets is stepped together here.  (A checkpoint
             # whose parameters disagree -- some never received a gradient -- resumes at the largest count.)
             self.step_count = max(steps)
         self._step_tensor.fill_(float(self.step_count))
+        self._adopted = True
 
     def release(self) -> None:
         """Hand the state back in the form torch's own (fused) Adam expects -- a step counter per parameter on its
@@ -105,11 +136,17 @@ class FlatAdam:
                     st["step"] = torch.tensor(float(self.step_count), dtype=torch.float32, device=p.device)
 
     def _layout_intact(self) -> bool:
+        """Every parameter still IS its slice of the flat store (a re-pointed `.data` would keep computing with detached
+        storage while msg_flat_adam updates the store), and the first parameter's state is the flat state (load_state_dict
+        replaces all state entries together).  ~400 integer compares per step."""
+        state = self.optimizer.state
         for k, b in enumerate(self.reducer.buckets):
-            p = b.params[0]
-            st = self.optimizer.state.get(p)
-            if p.data.data_ptr() != self.param_flat[k].data_ptr() or not st or st["step"] is not self._step_tensor or \
-                    st["exp_avg"].data_ptr() != self.exp_avg[k].data_ptr():
+            base = self.param_flat[k].data_ptr()
+            for p, off in zip(b.params, b.offsets):
+                if p.data.data_ptr() != base + 4 * off:
+                    return False
+            st = state.get(b.params[0])
+            if not st or st["step"] is not self._step_tensor or st["exp_avg"].data_ptr() != self.exp_avg[k].data_ptr():
                 return False
         return True
 
@@ -130,6 +167,7 @@ class FlatAdam:
         -- nothing done -- if a bucket mixes parameter groups whose hyper-parameters differ (the caller then steps
         through torch)."""
         from . import conv_ops
+        self._refresh_groups()
         hypers = [self._bucket_hyper(b) for b in self.reducer.buckets]
         if any(h is None for h in hypers):
             return False
@@ -177,11 +215,18 @@ class FlatAdam:
         train_named = dict(model_train.named_parameters())
         self._ema_rest = [(e, train_named[n]) for n, e in ema_named.items() if n not in covered]
         self._ema_model, self._ema_train = model_ema, model_train
-        self._ema_first = [None if self.ema_flat[k] is None else ema_named[names[id(b.params[0])]]
-                           for k, b in enumerate(self.reducer.buckets)]
+        self._ema_params = [None if self.ema_flat[k] is None else [ema_named[names[id(p)]] for p in b.params]
+                            for k, b in enumerate(self.reducer.buckets)]
 
     def _ema_intact(self) -> bool:
-        return all(e is None or e.data.data_ptr() == self.ema_flat[k].data_ptr() for k, e in enumerate(self._ema_first))
+        for k, flat in enumerate(self.ema_flat):
+            if flat is None:
+                continue
+            base = flat.data_ptr()
+            for e, off in zip(self._ema_params[k], self.reducer.buckets[k].offsets):
+                if e.data.data_ptr() != base + 4 * off:
+                    return False
+        return True
 
     def ema_update(self, decay: float = 0.999) -> None:
         """ema <- decay * ema + (1 - decay) * parameter (misc.exponential_moving_average) on the flat stores."""

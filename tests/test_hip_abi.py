@@ -85,7 +85,7 @@ def test_conv_entries(lib):
     assert lib.msg_conv2d_fprop_act(*act, None, None, None, 1, 0.2, 1.0, s) == OK
     assert lib.msg_conv2d_fprop_residual(*act, None, 16, 1.0, s) == EINVAL           # no residual map
     assert lib.msg_conv2d_fprop_residual(*act, y.data_ptr(), 8, 1.0, s) == EINVAL    # residual pitch below N
-    wg = (y.data_ptr(), x.data_ptr(), gw.data_ptr(), BF16, 1, 8, 8, 64, 64, 8, 8, 16, 16, 64, 3, 3, 1, 1, 0, 0, 1, 0, 1.0, s)
+    wg = (y.data_ptr(), x.data_ptr(), gw.data_ptr(), BF16, 1, 8, 8, 64, 64, 8, 8, 16, 16, 64, 3, 3, 1, 1, 0, 0, 1, 0, 1.0, None, 0, s)
     assert lib.msg_conv2d_wgrad(*wg) == OK
     assert lib.msg_conv2d_wgrad(*wg[:13], 32, *wg[14:]) == EINVAL                    # gradient pitch below I
     assert lib.msg_conv2d_wgrad(*wg[:20], 0, *wg[21:]) == EINVAL                     # zero K chunks

@@ -1,0 +1,176 @@
+"""Every backward kernel is deterministic: no float atomics anywhere on the training path, sums that span workgroups are
+formed from per-workgroup partials in a fixed order (csrc/conv_wgrad.hip: K-slice slabs + wgrad_reduce_kernel,
+csrc/bias_act.hip: part_b / part_n + bias_act_bwd_reduce_kernel).  Identical inputs therefore give bit-identical gradients
+and a bit-reproducible training step -- what lets the second-order (R1, path-length) steps be held to the north-star
+tolerance in tests/test_hip_models.py instead of to the run-to-run spread of atomic accumulation."""
+import copy
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPEATS = 8
+
+# (name, batch, in, out, h, w, k, stride, pad, kind, per_sample, dtype): one shape per weight-gradient kernel / addressing path
+WGRAD_CASES = [
+    ("row3s_shared_128ch_256px", 4, 128, 128, 256, 256, 3, 1, 1, "conv", False, torch.bfloat16),      # many K-slices, one tile
+    ("row3s_shared_512ch_64px", 4, 512, 512, 64, 64, 3, 1, 1, "conv", False, torch.bfloat16),
+    ("row3s_w32_shared_768ch", 8, 768, 768, 32, 32, 3, 1, 1, "conv", False, torch.bfloat16),
+    ("row3s_per_sample", 3, 256, 256, 64, 64, 3, 1, 1, "conv", True, torch.bfloat16),                  # no split
+    ("uni_1x1_shared", 4, 256, 128, 128, 128, 1, 1, 0, "conv", False, torch.bfloat16),
+    ("uni_s2_shared", 4, 128, 256, 128, 128, 3, 2, 1, "conv", False, torch.bfloat16),
+    ("generic_odd_map_shared", 3, 72, 40, 45, 37, 3, 1, 1, "conv", False, torch.bfloat16),
+    ("up2_per_sample", 3, 256, 256, 32, 32, 2, 1, 0, "up2", True, torch.bfloat16),
+    ("up2_shared", 4, 128, 128, 32, 32, 2, 1, 0, "up2", False, torch.bfloat16),
+    ("torgb_per_sample_split", 4, 512, 3, 128, 128, 1, 1, 0, "conv", True, torch.bfloat16),            # per-sample AND split
+    ("small_map_big_output", 16, 1024, 1024, 16, 16, 3, 1, 1, "conv", False, torch.bfloat16),
+    ("f32_shared", 4, 64, 96, 64, 64, 3, 1, 1, "conv", False, torch.float32),
+    ("f32_generic_shared", 2, 40, 24, 33, 29, 3, 1, 1, "conv", False, torch.float32),
+    ("f32_torgb_per_sample_split", 2, 256, 3, 128, 128, 1, 1, 0, "conv", True, torch.float32),
+    ("thin_input", 4, 6, 128, 128, 128, 3, 1, 1, "conv", False, torch.bfloat16),
+]
+
+
+def _wgrad_reference(gy, x, k, stride, pad, kind, per_sample, o, i):
+    """fp64 weight gradient, one contraction per tap (rocBLAS dgemm on the device: the CPU would take minutes on these sizes).
+    conv: gw[o,i,kh,kw] = sum gy[b,o,y,x] * xpad[b,i,y*s+kh,x*s+kw];  up2: gw[o,i,dy,dx] = sum gy[b,o,2y+dy,2x+dx] * x[b,i,y,x]."""
+    gy64, x64 = gy.double(), x.double()
+    eq = "boyx,biyx->boi" if per_sample else "boyx,biyx->oi"
+    taps = []
+    if kind == "up2":
+        for dy in range(2):
+            for dx in range(2):
+                taps.append(torch.einsum(eq, gy64[:, :, dy::2, dx::2], x64))
+        kk = 2
+    else:
+        xp = torch.nn.functional.pad(x64, (pad, pad, pad, pad))
+        oh, ow = gy64.shape[2:]
+        for kh in range(k):
+            for kw in range(k):
+                taps.append(torch.einsum(eq, gy64, xp[:, :, kh:kh + stride * (oh - 1) + 1:stride,
+                                                      kw:kw + stride * (ow - 1) + 1:stride]))
+        kk = k
+    out = torch.stack(taps, dim=-1)
+    return out.reshape(*out.shape[:-1], kk, kk)
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_weight_gradient_kernels_are_deterministic(case):
+    from multi_stylegan_amd import conv_ops
+    _, b, i, o, h, w_, k, stride, pad, kind, per_sample, dtype = case
+    torch.manual_seed(b * 1000 + i + o)
+    x = conv_ops.to_compute_layout(torch.randn(b, i, h, w_, device=DEV), dtype)
+    geo = conv_ops.Geometry(kind, k, k, stride, pad, (h, w_), per_sample)
+    gy = conv_ops.to_compute_layout(torch.randn(b, o, *geo.y_hw, device=DEV), dtype)
+    first = conv_ops._g_raw(gy, x, o, i, geo).clone()
+    for _ in range(REPEATS):
+        assert torch.equal(first, conv_ops._g_raw(gy, x, o, i, geo))
+    # and the fixed-order sum is the right sum
+    want = _wgrad_reference(gy, x, k, stride, pad, kind, per_sample, o, i)
+    assert first.shape == want.shape
+    assert rel_err(first, want) < (2e-5 if dtype == torch.float32 else 2e-3)
+
+
+def test_weight_gradient_workspace_contract():
+    """A split sum without (enough) workspace is refused, never silently accumulated; the query is a function of the shape."""
+    from multi_stylegan_amd import _lib
+    lib = _lib.lib()
+    geom = (_lib.MSG_BF16, 4, 256, 256, 128, 128, 256, 256, 128, 128, 128, 3, 3, 1, 1, 0, 0, 1)
+    need = lib.msg_conv2d_wgrad_workspace(*geom)
+    assert need > 0 and need % (128 * 9 * 128) == 0 and need == lib.msg_conv2d_wgrad_workspace(*geom)
+    x = torch.zeros(4, 256, 256, 128, dtype=torch.bfloat16, device=DEV)
+    gw = torch.zeros(128, 9, 128, device=DEV)
+    ws = torch.empty(need, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    args = (x.data_ptr(), x.data_ptr(), gw.data_ptr(), *geom, 0, 1.0)
+    assert lib.msg_conv2d_wgrad(*args, None, 0, s) == -1                       # MSG_EINVAL
+    assert lib.msg_conv2d_wgrad(*args, ws.data_ptr(), need - 1, s) == -1
+    assert lib.msg_conv2d_wgrad(*args, ws.data_ptr(), need, s) == 0
+    torch.cuda.synchronize()
+    assert lib.msg_conv2d_wgrad_workspace(_lib.MSG_BF16, 1, 8, 8, 64, 64, 8, 8, 16, 16, 64, 3, 3, 1, 1, 0, 0, 1) == 0
+    assert lib.msg_conv2d_wgrad_workspace(_lib.MSG_BF16, 1, 8, 8, 64, 64, 8, 8, 16, 16, 32, 3, 3, 1, 1, 0, 0, 1) == -1  # ldgw < I
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,channels_last,noise", [((16, 512, 64, 64), True, "batch"), ((4, 128, 256, 256), True, "shared"),
+                                                       ((3, 20, 33, 29), False, "batch"), ((5, 7, 16, 16), True, None),
+                                                       ((16, 512), False, None), ((2, 6, 40, 24), True, "batch")])
+def test_activation_backward_sums_are_deterministic(shape, channels_last, noise, dtype):
+    """grad_bias / grad_noise_weight of the fused activation: bit-identical over repeated launches, and equal to the sums."""
+    from multi_stylegan_amd.op_static.fused_act import FusedLeakyReLUFunctionBackward
+    torch.manual_seed(len(shape) * 100 + shape[1])
+    g = torch.randn(shape, device=DEV).to(dtype)
+    out = torch.randn(shape, device=DEV).to(dtype)
+    if channels_last and len(shape) == 4:
+        g, out = g.contiguous(memory_format=torch.channels_last), out.contiguous(memory_format=torch.channels_last)
+    nz = None
+    if noise is not None:
+        nz = torch.randn((shape[0] if noise == "batch" else 1, 1, *shape[2:]), device=DEV)
+    first = [t.clone() for t in FusedLeakyReLUFunctionBackward.apply(g, out, nz, True, 0.2, 1.5)]
+    for _ in range(REPEATS):
+        again = FusedLeakyReLUFunctionBackward.apply(g, out, nz, True, 0.2, 1.5)
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
+    gx64 = g.double() * 1.5 * torch.where(out.double() > 0, 1.0, 0.2)
+    dims = (0, 2, 3) if len(shape) == 4 else (0,)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(first[0].double(), gx64) < tol
+    assert rel_err(first[1].double(), gx64.sum(dims)) < tol
+    if nz is not None:
+        assert rel_err(first[2].double(), (gx64 * nz.double()).sum().reshape(1)) < tol
+
+
+def test_grouped_linear_latent_gradient_is_deterministic():
+    from multi_stylegan_amd import conv_ops
+    torch.manual_seed(4)
+    g, b, l, n, k = 20, 16, 14, 512, 512
+    slot = tuple(min(l - 1, j * l // g) for j in range(g))
+    lat = torch.randn(b, l, k, device=DEV, requires_grad=True)
+    ws = [torch.randn(n, k, device=DEV, requires_grad=True) for _ in range(g)]
+    bs = [torch.randn(n, device=DEV, requires_grad=True) for _ in range(g)]
+    gy = torch.randn(g, b, n, device=DEV)
+    runs = []
+    for _ in range(4):
+        y = conv_ops._GroupedLinear.apply(lat, slot, 0.1, 1.0, *ws, *bs)
+        runs.append(torch.autograd.grad(y, [lat, *ws], gy))
+    for other in runs[1:]:
+        assert all(torch.equal(a, c) for a, c in zip(runs[0], other))
+    want = torch.zeros_like(lat)
+    for j in range(g):
+        want[:, slot[j]] += 0.1 * gy[j] @ ws[j].detach()
+    assert rel_err(runs[0][0], want) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_iteration_is_bit_reproducible(golden, dtype):
+    """Two trainers from the same state and the same draws, through a regularised iteration (D step, R1 with its double
+    backward, G step, path length with its double backward, EMA): every parameter of G, D and the EMA copy, the Adam
+    moments and the logged losses agree BIT FOR BIT.  With float atomics in the weight / bias gradients they did not."""
+    import multi_stylegan_amd as m
+    from test_hip_models import _golden_trainer
+    from test_oracle_golden import load_train_draws
+    results = []
+    for _ in range(3):
+        z, g, d, trainer = _golden_trainer(golden)
+        g.compute_dtype = d.compute_dtype = trainer.generator_ema.compute_dtype = dtype
+        real, draws = load_train_draws(z, 1, m.model_wrapper)           # golden iteration 16: both lazy regularisers fire
+        trainer.iteration = 15
+        trainer.train_iteration(real.to(DEV), draws.to(DEV))
+        log = trainer.pop_logs()
+        state = {f"G.{n}": p.detach().clone() for n, p in g.named_parameters()}
+        state.update({f"D.{n}": p.detach().clone() for n, p in d.named_parameters()})
+        state.update({f"E.{n}": p.detach().clone() for n, p in trainer.generator_ema.named_parameters()})
+        names = {id(p): n for mod in (g, d) for n, p in mod.named_parameters()}
+        for opt in (trainer.generator_optimizer, trainer.discriminator_optimizer):
+            for p, st in opt.state.items():
+                state[f"adam.m.{names[id(p)]}"], state[f"adam.v.{names[id(p)]}"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+        results.append((state, log))
+    (a, la) = results[0]
+    assert "loss_discriminator_regularization" in la and "path_length" in la
+    for b, lb in results[1:]:
+        assert la == lb
+        differing = [n for n in a if not torch.equal(a[n], b[n])]
+        assert not differing, differing[:8]

@@ -118,17 +118,15 @@ LOG_NAMES = {"loss_d_real": "loss_discriminator_real", "loss_d_fake": "loss_disc
              "loss_g_px": "loss_generator_pixel_wise", "path_length": "path_length",
              "loss_pl": "loss_path_length_regularization", "cut_mix_aug": "loss_cut_mix_augmentation",
              "cut_mix_reg": "loss_cut_mix_regularization"}
-# fp32 path on the GPU against the reference-driven golden run.  Pre-clip gradients: 1e-3 of each tensor's largest
-# element (north star; measured: 1e-6 first order; the second-order steps, whose float-atomic weight gradients pass
-# through a second differentiation, vary between runs, 1e-4 .. 3e-4 with rare excursions: they get 3e-3), global norm 1e-4,
-# parameter movement 1.5e-2 of the largest movement (typically 7e-4, most of it the fp16 storage of the fixtures), on
-# the elements whose gradient is above rounding noise (Adam with beta1 = 0 turns noise-level gradients into +-lr).
-# Movement tolerance 1.5e-2: Adam normalises by sqrt(v), and from iteration 16 on v carries the second-order steps, whose
-# float-atomic weight gradients differ by up to 3e-3 between runs -- one run in ~ten showed 9e-3 on one tensor of a
-# first-order step at 5e-3.  (A trainer that skips or doubles a step, does not clip or mishandles the EMA is off by O(1):
-# test_train_iteration_check_catches_a_broken_trainer.)
-STEP_TOL = {label: (1e-3, 1e-4, 1.5e-2) for label in ("d", "g", "cm_aug", "cm_reg")}
-STEP_TOL.update(r1=(3e-3, 1e-4, 1.5e-2), pl=(3e-3, 1e-4, 1.5e-2))
+# fp32 path on the GPU against the reference-driven golden run, every optimiser step, first AND second order, at the
+# north-star tolerance: pre-clip gradients 1e-3 of each tensor's largest element (measured: 1e-6 .. 1e-5 first order and R1,
+# 1.4e-4 .. 2.6e-4 path length), global norm 1e-4 (measured <= 1e-6), parameter movement 2e-3 of the largest movement
+# (measured <= 7.3e-4, most of it the fp16 storage of the fixtures), on the elements whose gradient is above rounding noise
+# (Adam with beta1 = 0 turns noise-level gradients into +-lr).  Round 2 had to allow 3e-3 / 1.5e-2 on the second-order
+# steps because float-atomic weight / bias gradients varied from run to run; every backward kernel is deterministic now
+# (tests/test_hip_determinism.py), so the numbers above are THE numbers, not a sample.  (A trainer that skips or doubles a
+# step, does not clip or mishandles the EMA is off by O(1): test_train_iteration_check_catches_a_broken_trainer.)
+STEP_TOL = {label: (1e-3, 1e-4, 2e-3) for label in ("d", "g", "cm_aug", "cm_reg", "r1", "pl")}
 
 
 def _golden_trainer(golden, **kw):
@@ -171,7 +169,7 @@ def _run_golden_iterations(golden, fused, prepare=None):
             assert st["compared"] > 0.2 * st["total"], (label, st)
             report[f"it{iteration}.{label}"] = st
         worst_ema = max(rel_err(got_ema[n], want) for n, want in want_ema.items())
-        assert worst_ema < 1e-2, ("ema", worst_ema)
+        assert worst_ema < 1e-2, ("ema", worst_ema)         # (fp16 fixtures of 1e-3-sized EMA movements: 6e-3 with the plain optimiser)
         report[f"it{iteration}.ema"] = worst_ema
         for key in z.keys(pre + "log."):
             want, got = float(z[key]), log[LOG_NAMES[key[len(pre + "log."):]]][0]

@@ -173,6 +173,64 @@ def test_trainer_data_parallel_gloo_world2():
     assert q.get(timeout=5) == "ok"
 
 
+def _cut_mix_gate_worker(rank, world, port, out):
+    """Late-training iterations with the RANDOM CutMix gate (no Draws.cut_mix) and rank-distinct Python RNGs, as bench.py
+    and the per-rank style-mixing draws leave them: every rank must take the same branch in every iteration."""
+    import random
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from multi_stylegan_amd.model_wrapper import ModelWrapper
+    from oracle import models as om
+    from tools.gen_golden import TINY_D, TINY_G
+    torch.manual_seed(10)
+    g, d = om.Generator(TINY_G), om.Discriminator(TINY_D, no_rfp=True)
+    g.live_parameters = lambda: [p for n, p in g.named_parameters() if not n.startswith("main_convolutions_2.")]
+    orig_forward = g.forward
+    g.forward = lambda *a, path_length_noise=None, **k: orig_forward(*a, **k)
+    random.seed(1234 + rank)
+    tr = ModelWrapper(g, d, device="cpu", bucket_bytes=1 << 16,
+                      generator_optimizer=torch.optim.SGD(g.parameters(), lr=1e-3),
+                      discriminator_optimizer=torch.optim.SGD(d.parameters(), lr=1e-3))
+    assert tr._control_rng is not None
+    tr.epoch, tr.epochs = 5, 10                          # gate probability 0.25, plus the resume_training coin
+    torch.manual_seed(1000 + rank)
+    gates = []
+    for _ in range(6):
+        tr.train_iteration(torch.rand(2, 2, 3, 32, 32), resume_training=True)
+        gates.append("loss_cut_mix_augmentation" in tr.pop_logs())
+    everyone = [None] * world
+    dist.all_gather_object(everyone, gates)
+    assert everyone[0] == everyone[1], everyone
+    assert any(gates) and not all(gates), gates          # both branches were taken
+    flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), "replicas diverged"
+    # a checkpoint carries the gate's generator state: a resumed job draws the same continuation on every rank
+    state = tr.checkpoint_dict()["multi_stylegan_amd"]["control_rng"]
+    nxt = tr._control_random()
+    tr._control_rng.setstate(state)
+    assert tr._control_random() == nxt
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_cut_mix_gate_is_rank_consistent_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 28200 + os.getpid() % 400
+    procs = [ctx.Process(target=_cut_mix_gate_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    hung = [p for p in procs if p.exitcode is None]
+    [p.kill() for p in hung]
+    assert not hung, "ranks disagreed on the CutMix gate and deadlocked"
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == "ok"
+
+
 def test_non_square_conv_geometry_is_refused():
     """EqualizedConv2d keeps the reference's (h, w) tuple arguments; a non-square stride / padding must raise instead
     of being computed with the first entry (round-1 advice)."""

@@ -12,9 +12,19 @@ master weights.  Weak scaling: every rank runs the same per-GPU batch; gradients
 Warm-up: W untimed iterations, the last of them a regularised one (so that every code path has run once before the
 timed region; the timed K iterations fire the regularisers at their natural cadence).
 
+`value`: training runs 15 plain iterations per regularised one.  A window of K iterations holds floor(K/16) or one more
+regularised iteration, so its raw average is optimistic or pessimistic depending on K and the phase.  The timed region
+therefore also clocks every iteration (one HIP event per iteration boundary) and `value` is the 15:1 amortised rate
+    world * batch / ((15 * plain_ms + regularised_ms) / 16)
+from the timed region's own plain and regularised iterations (`timed_region` carries both and the raw average; when the
+window holds no regularised iteration or no plain one, `value` falls back to the raw average and says so).
+
 Rank 0 prints ONE JSON line; besides the contract's keys it carries
-  roofline      the dominant hand-written kernel, timed per launch with HIP events inside the timed region
-  cpu_baseline  the CPU oracle (oracle/) timed on this host on a bounded sample of the workload
+  roofline        the dominant hand-written kernel, timed per launch with HIP events inside the timed region
+  cpu_baseline    the CPU oracle (oracle/) timed on this host on a bounded sample of the workload (64^2, batch 4, and one
+                  iteration at the benchmark's own resolution for a same-resolution ratio)
+  value_fp32_path the same iteration on the fp32-storage path (the path the 1e-3 parity gate is held on), batch 4
+  losses          the last value of every logged loss (asserted finite)
 """
 import argparse
 import json
@@ -52,6 +62,11 @@ def parse_args():
                     help="HIP-event timing of EVERY launch (per-kernel table in the JSON line); by default only the two "
                          "roofline kernels are timed, which keeps the event overhead out of the host path")
     ap.add_argument("--cpu-baseline-iters", type=int, default=4)
+    ap.add_argument("--no-cpu-same-resolution", action="store_true",
+                    help="skip the CPU oracle's one iteration at the benchmark's own resolution (about a minute at 256^2)")
+    ap.add_argument("--no-h2d-leg", action="store_true",
+                    help="skip the leg that feeds the step from pageable host memory through the prefetcher")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-storage leg (value_fp32_path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device): rehearses the "
                          "launcher, the rendezvous and the exchange path on a 1-GPU box; not a measurement")
@@ -72,6 +87,11 @@ def baseline_config(args, world) -> str:
     return ""
 
 
+def _is_flops(key: str) -> bool:
+    """Kernel-clock keys whose `work` is FLOPs (the contractions); everything else counts bytes."""
+    return key.startswith(("conv", "linear", "nonlocal_attention", "attention"))
+
+
 def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -85,7 +105,7 @@ def host_threads() -> int:
     return max(1, min(n, int(os.environ.get("MSG_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(iters: int):
+def cpu_baseline(iters: int, same_resolution: int = 0):
     """The CPU oracle on BASELINE config 1 (64x64, 5 x 512 channels, B=4): `iters` plain iterations after one
     warm-up.  A bounded sample: the 256^2 workload itself takes minutes per iteration on a CPU."""
     from multi_stylegan_amd.config import generator_config_for_resolution
@@ -108,11 +128,62 @@ def cpu_baseline(iters: int):
     ot.train_iteration(g, d, g_ema, og, od, pl, real, 16)            # R1 + path-length regularisers fire
     dt_lazy = time.perf_counter() - t1
     amortised = 16 * 4 / (15 * dt / iters + dt_lazy)                 # 15 plain + 1 regularised iteration
-    return {"value": round(amortised, 4), "unit": "img/s", "cores": threads, "kind": "port",
-            "plain_iteration_s": round(dt / iters, 3), "regularised_iteration_s": round(dt_lazy, 3),
-            "sample": f"{iters} plain training iterations + 1 iteration with the lazy R1 / path-length regularisers "
-                      f"of the CPU oracle at 64x64, batch 4 (BASELINE config 1), weighted 15:1 as in training; "
-                      f"torch {torch.__version__}, {threads} threads"}
+    out = {"value": round(amortised, 4), "unit": "img/s", "cores": threads, "kind": "port",
+           "plain_iteration_s": round(dt / iters, 3), "regularised_iteration_s": round(dt_lazy, 3),
+           "sample": f"{iters} plain training iterations + 1 iteration with the lazy R1 / path-length regularisers "
+                     f"of the CPU oracle at 64x64, batch 4 (BASELINE config 1), weighted 15:1 as in training; "
+                     f"torch {torch.__version__}, {threads} threads"}
+    if same_resolution:
+        # one PLAIN iteration at the benchmark's own resolution and channel configuration ("optionally one 256^2
+        # B=2 iteration for a same-resolution ratio"): bounded at batch 2, no warm-up (an iteration takes minutes)
+        del g, d, g_ema, og, od
+        res, bsz = same_resolution, 2
+        torch.manual_seed(4321)
+        g, d = om.Generator(generator_config_for_resolution(res)), om.Discriminator(no_rfp=True)
+        g_ema = copy.deepcopy(g)
+        og, od = ot.make_optimizers(g, d)
+        real = torch.rand(bsz, 2, 3, res, res)
+        t2 = time.perf_counter()
+        ot.train_iteration(g, d, g_ema, og, od, ot.PathLength(), real, 2)
+        dt_same = time.perf_counter() - t2
+        out["same_resolution"] = {"value": round(bsz / dt_same, 4), "unit": "img/s", "iteration_s": round(dt_same, 2),
+                                  "sample": f"1 plain training iteration of the CPU oracle at {res}x{res}, batch {bsz}, "
+                                            f"no warm-up, {threads} threads"}
+    return out
+
+
+def fp32_leg(args, dev, batch: int = 4, steps: int = 3):
+    """The same training iteration on the fp32-storage path -- exact-fp32 MFMA contractions, the path the 1e-3 parity
+    gate of tests/test_hip_models.py is held on -- at batch 4: one regularised warm-up iteration, `steps` timed plain
+    iterations and one timed regularised iteration, amortised 15:1 like `value`."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    torch.manual_seed(1234)
+    gen = m.MultiStyleGANGenerator(generator_config_for_resolution(args.resolution))
+    dis = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    trainer = m.ModelWrapper(gen, dis, device=dev)
+    lazy = trainer.hyperparameters["lazy_discriminator_regularization"]
+    real = torch.rand(batch, 2, 3, args.resolution, args.resolution, device=dev)
+    trainer.iteration = lazy - 1
+    trainer.train_iteration(real)                              # warm-up, regularised: iteration 16
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_iteration(real)                          # 17, 18, ...: plain
+    torch.cuda.synchronize(dev)
+    plain_ms = 1e3 * (time.perf_counter() - t0) / steps
+    trainer.iteration = 2 * lazy - 1
+    t1 = time.perf_counter()
+    trainer.train_iteration(real)                              # 32: regularised
+    torch.cuda.synchronize(dev)
+    reg_ms = 1e3 * (time.perf_counter() - t1)
+    last = {k: v[-1] for k, v in trainer.pop_logs().items()}
+    assert all(v == v and abs(v) != float("inf") for v in last.values()), f"non-finite loss on the fp32 path: {last}"
+    step_ms = ((lazy - 1) * plain_ms + reg_ms) / lazy
+    return {"value": round(batch / (step_ms * 1e-3), 3), "unit": "img/s", "dtype": "f32", "batch": batch,
+            "plain_ms": round(plain_ms, 2), "regularised_ms": round(reg_ms, 2), "ms_per_step": round(step_ms, 2),
+            "sample": f"{steps} plain + 1 regularised iteration at {args.resolution}x{args.resolution}, batch {batch}, "
+                      f"fp32 storage and exact-fp32 MFMA, amortised {lazy - 1}:1"}
 
 
 def self_launch(n: int) -> int:
@@ -201,11 +272,23 @@ def main():
     roofline_keys = (("conv_fprop_row3", "conv_fprop_pp") if args.dtype == "bf16" else ("conv_fprop_dma",)) + ("upfirdn2d",)
     _lib.kernel_clock.reset(enabled=not args.no_kernel_clock, only=None if clock_all else roofline_keys)
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    first_iteration = trainer.iteration + 1
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         trainer.train_iteration(batch_of())
+        marks[k + 1].record()                                  # (one event per iteration: the plain / regularised split)
     barrier()
     elapsed = time.perf_counter() - t0
+    iter_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    is_reg = [(first_iteration + k) % hp_lazy == 0 for k in range(args.steps)]
+    plain = [t for t, r in zip(iter_ms, is_reg) if not r]
+    regd = [t for t, r in zip(iter_ms, is_reg) if r]
+    split = torch.tensor([sum(plain) / max(1, len(plain)), sum(regd) / max(1, len(regd))], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(split, op=torch.distributed.ReduceOp.MAX)     # the job is as slow as its slowest rank
+    plain_ms, reg_ms = split.tolist()
     per_rank = [elapsed]
     overlap_off_ms = None
     if world > 1:
@@ -229,11 +312,35 @@ def main():
     note(f"timed region done: {elapsed:.2f} s for {args.steps} steps")
     clock = _lib.kernel_clock.summary()
     _lib.kernel_clock.reset(enabled=False)
+    h2d = None
+    if world == 1 and not args.no_h2d_leg and plain:
+        # the same plain iterations with the real batch arriving from PAGEABLE host memory every step through the data
+        # feed (multi_stylegan_amd.data.DevicePrefetcher: pinned staging + copy stream, one iteration ahead) -- the only
+        # host->device traffic of the reference's loop (model_wrapper.py:253-256).  Outside `value`'s timed region.
+        from multi_stylegan_amd.data import DevicePrefetcher
+        host_batch = real.cpu()
+        n_h2d = 8
+        trainer.iteration = 4 * hp_lazy                        # the next n_h2d (< 16) iterations are plain ones
+        barrier()
+        t1 = time.perf_counter()
+        for batch in DevicePrefetcher([host_batch] * n_h2d, dev):
+            trainer.train_iteration(batch)
+        barrier()
+        h2d_ms = 1e3 * (time.perf_counter() - t1) / n_h2d
+        h2d = {"plain_ms_with_h2d": round(h2d_ms, 2), "plain_ms_resident": round(plain_ms, 2),
+               "bytes_per_step": host_batch.numel() * host_batch.element_size(),
+               "img_per_s_with_h2d": round(args.batch / (((hp_lazy - 1) * h2d_ms + (reg_ms if regd else h2d_ms)) / hp_lazy * 1e-3), 3),
+               "sample": f"{n_h2d} plain iterations, the real batch copied from pageable host memory every step through "
+                         f"data.DevicePrefetcher (pinned double buffer, copy stream); amortised with the resident "
+                         f"regularised iteration"}
     logs = trainer.pop_logs()
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
 
     if rank == 0:
-        value = world * args.batch * args.steps / elapsed
+        raw_ms = 1e3 * elapsed / args.steps
+        amortise = bool(plain) and bool(regd)
+        step_ms = ((hp_lazy - 1) * plain_ms + reg_ms) / hp_lazy if amortise else raw_ms
+        value = world * args.batch / (step_ms * 1e-3)
         # dominant kernel (rocprofv3: ~44 % of GPU time): the bf16 implicit-GEMM conv on the matrix cores.
         # achieved = algorithmic FLOPs of its launches inside the timed region / their HIP-event durations.
         pmc, pmc_file = {}, None       # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this workload
@@ -279,13 +386,15 @@ def main():
             leg(f"upfirdn2d/{args.dtype}/up1down1/vec", "hbm", HBM_PEAK_GBS, "GB/s",
                 "upfirdn2d_vec_kernel<up=1,down=1> (4x4 FIR blur, channels-last)")
         kernels = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
-                       ("TFLOP/s" if k.startswith("conv") else "GB/s"):
-                           round(v["work"] / (v["total_ms"] * 1e-3) / (1e12 if k.startswith("conv") else 1e9), 1)}
+                       ("TFLOP/s" if _is_flops(k) else "GB/s"):
+                           round(v["work"] / (v["total_ms"] * 1e-3) / (1e12 if _is_flops(k) else 1e9), 1)}
                    for k, v in sorted(clock.items())}
+        last = {k: v[-1] for k, v in logs.items() if v}
+        assert last and all(v == v and abs(v) != float("inf") for v in last.values()), f"non-finite loss: {last}"
         out = {
             "metric": "training images/sec (G+D step, 256^2, seq=3x2ch)", "value": round(value, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_ms, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.resolution}x{args.resolution}, seq_len=3, 2 channels, batch={args.batch}/GPU"
                                    f"{baseline_config(args, world)}; full iteration: D step + G step + EMA, lazy R1 and "
@@ -300,12 +409,26 @@ def main():
             "per_rank_img_per_s": [round(args.batch * args.steps / t, 2) for t in per_rank],
             "overlap": {"on_ms_per_step": round(1e3 * elapsed / args.steps, 2),
                         "off_ms_per_step": round(overlap_off_ms, 2)} if overlap_off_ms is not None else None,
+            "timed_region": {"iterations": [first_iteration, first_iteration + args.steps - 1],
+                             "regularised_iterations": len(regd), "plain_ms": round(plain_ms, 2) if plain else None,
+                             "regularised_ms": round(reg_ms, 2) if regd else None, "raw_ms_per_step": round(raw_ms, 2),
+                             "raw_img_per_s": round(world * args.batch * args.steps / elapsed, 3),
+                             "value_is": f"{hp_lazy - 1}:1 amortised (plain : regularised iterations, as in training)"
+                             if amortise else "raw average of the window (it holds no regularised or no plain iteration)"},
             "roofline": roof, "roofline_upfirdn2d": roof_fir, "kernels": kernels, "peak_mem_GiB": round(peak_mem, 2),
-            "loss_d_real_last": round(logs["loss_discriminator_real"][-1], 4) if logs else None,
+            "losses": {k: round(v, 5) for k, v in last.items()},
+            "h2d": h2d,
         }
+        if world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and not args.rehearse_on_one_gpu:
+            note("fp32-storage leg (batch 4) ...")
+            del trainer, gen, dis, real
+            torch.cuda.empty_cache()
+            out["value_fp32_path"] = fp32_leg(args, dev)
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
-            note("CPU baseline (oracle, 64x64, B=4) ...")
-            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters)
+            note("CPU baseline (oracle, 64x64, B=4" + ("" if args.no_cpu_same_resolution else
+                                                       f"; one iteration at {args.resolution}^2, B=2") + ") ...")
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters,
+                                               0 if args.no_cpu_same_resolution else args.resolution)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -3,6 +3,7 @@ reference's nn.Module / op_static API).  See DESIGN.md.  Public names follow mul
 from .adaptive_discriminator_augmentation import AdaptiveDiscriminatorAugmentation, AugmentationPipeline
 from .config import (generation_hyperparameters, multi_style_gan_generator_config,
                      u_net_2d_discriminator_config)
+from .data import DevicePrefetcher, SyntheticBatches
 from .inference import GeneratorSampler, load_generator_ema, split_sequences, validation_samples
 from .loss import PathLengthRegularization, TopK
 from .model_wrapper import Draws, ModelWrapper
@@ -11,4 +12,4 @@ from .u_net_2d_discriminator import Discriminator as MultiStyleGANDiscriminator
 
 __all__ = ["MultiStyleGANGenerator", "MultiStyleGANDiscriminator", "ModelWrapper", "Draws", "PathLengthRegularization",
            "TopK", "AdaptiveDiscriminatorAugmentation", "AugmentationPipeline", "GeneratorSampler", "load_generator_ema", "split_sequences", "validation_samples",
-           "multi_style_gan_generator_config", "u_net_2d_discriminator_config", "generation_hyperparameters"]
+           "DevicePrefetcher", "SyntheticBatches", "multi_style_gan_generator_config", "u_net_2d_discriminator_config", "generation_hyperparameters"]

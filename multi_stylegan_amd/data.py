@@ -1,0 +1,180 @@
+"""The data feed of the training step: host batches reach the GPU without ever stalling an iteration.
+
+The reference feeds ``_gan_training`` from a ``DataLoader(num_workers=..., pin_memory=True)`` (train_multi_stylegan.py:60-63
+over dataset/tlfm_dataset.py:128-198) and moves each batch with ``.to(device)`` at the top of the iteration
+(model_wrapper.py:253-256) -- on the compute stream, i.e. in front of the iteration's first kernel, and synchronously
+whenever the batch is pageable.  Here:
+
+* ``DevicePrefetcher`` wraps ANY iterable of host batches (a DataLoader, a list, a generator; tensors or nested tuples of
+  tensors; pinned or pageable).  A background thread pulls the next batch, stages it in a pinned slot, issues the H2D copy
+  on a dedicated copy stream and hands the consumer a device tensor guarded by an event -- ``depth`` batches ahead
+  (double buffering by default).  The compute stream only ever waits on an event that completed tens of milliseconds
+  earlier; the slot is recycled once the compute stream has passed the last kernel that read it.
+* ``SyntheticBatches`` draws the batches on the device itself (``torch.rand`` in the dataset's [0, 1] range,
+  dataset/tlfm_dataset.py:187,191): what the benchmark and smoke runs use when there is no dataset.
+
+``ModelWrapper.train`` / ``_gan_training`` put every host iterable behind a ``DevicePrefetcher`` themselves.
+"""
+import queue
+import threading
+from typing import Any, Iterable, Iterator, Optional, Union
+
+import torch
+
+
+def _map(fn, batch):
+    if isinstance(batch, torch.Tensor):
+        return fn(batch)
+    if isinstance(batch, (list, tuple)):
+        return type(batch)(_map(fn, b) for b in batch)
+    if isinstance(batch, dict):
+        return {k: _map(fn, v) for k, v in batch.items()}
+    return batch
+
+
+def _tensors(batch, out=None):
+    out = [] if out is None else out
+    if isinstance(batch, torch.Tensor):
+        out.append(batch)
+    elif isinstance(batch, (list, tuple)):
+        for b in batch:
+            _tensors(b, out)
+    elif isinstance(batch, dict):
+        for b in batch.values():
+            _tensors(b, out)
+    return out
+
+
+class _Slot:
+    """One in-flight batch: pinned staging tensors, device tensors, `ready` (copy done) and `released` (compute stream is
+    past the consumer's last use) events."""
+
+    def __init__(self, device):
+        self.device = device
+        self.host, self.dev = [], []
+        self.ready = torch.cuda.Event()
+        self.released: Optional[torch.cuda.Event] = None
+        self.batch: Any = None
+
+    def fit(self, tensors) -> None:
+        ok = len(tensors) == len(self.host) and all(h.shape == t.shape and h.dtype == t.dtype
+                                                    for h, t in zip(self.host, tensors))
+        if not ok:                                          # first use, or a ragged last batch: (re)allocate this slot
+            self.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+            self.dev = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in tensors]
+
+
+class DevicePrefetcher:
+    """``for batch in DevicePrefetcher(loader, device)``: device-resident batches, copied ``depth`` iterations ahead on a
+    copy stream from pinned staging buffers.  A yielded batch is valid until the consumer asks for the next one (its device
+    buffer is then refilled, ordered behind everything the consumer has launched so far); clone it to keep it longer.
+    Batches that already live on the device pass through."""
+
+    def __init__(self, loader: Iterable, device: Union[str, torch.device] = "cuda", depth: int = 2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(2, int(depth))
+        if self.device.type != "cuda":
+            raise ValueError("DevicePrefetcher stages batches for a GPU; iterate the loader directly on the CPU")
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self) -> int:
+        return len(self.loader)
+
+    def __iter__(self) -> Iterator:
+        dev = self.device
+        slots = [_Slot(dev) for _ in range(self.depth)]
+        free = queue.Queue()
+        for s in slots:
+            free.put(s)
+        ready: "queue.Queue" = queue.Queue()
+        stop = threading.Event()
+        _END, _ERR = object(), object()
+
+        def worker():
+            try:
+                torch.cuda.set_device(dev)
+                for batch in self.loader:
+                    tensors = _tensors(batch)
+                    if not tensors or all(t.is_cuda for t in tensors):
+                        ready.put((None, batch))                          # nothing to copy
+                        continue
+                    slot = None
+                    while slot is None:                                   # a free slot (the consumer returns them)
+                        if stop.is_set():
+                            return
+                        try:
+                            slot = free.get(timeout=0.05)
+                        except queue.Empty:
+                            continue
+                    slot.fit(tensors)
+                    with torch.cuda.stream(self.copy_stream):
+                        if slot.released is not None:                     # kernels that still read the device buffers
+                            self.copy_stream.wait_event(slot.released)
+                        for h, d, t in zip(slot.host, slot.dev, tensors):
+                            if t.is_cuda:
+                                d.copy_(t, non_blocking=True)
+                            else:
+                                # the pinned tensor of the slot's previous batch may still be the source of an in-flight
+                                # copy: `ready` of that batch is behind us only once the copy stream has reached it
+                                slot.ready.synchronize()
+                                h.copy_(t)                                # pageable -> pinned (releases the GIL)
+                                d.copy_(h, non_blocking=True)
+                        slot.ready.record(self.copy_stream)
+                    it = iter(slot.dev)
+                    slot.batch = _map(lambda _t: next(it), batch)
+                    ready.put((slot, slot.batch))
+                ready.put((_END, None))
+            except BaseException as exc:                                  # surfaces in the consumer
+                ready.put((_ERR, exc))
+
+        thread = threading.Thread(target=worker, name="msg-prefetch", daemon=True)
+        thread.start()
+        try:
+            while True:
+                slot, batch = ready.get()
+                if slot is _END:
+                    return
+                if slot is _ERR:
+                    raise batch
+                if slot is not None:
+                    torch.cuda.current_stream(dev).wait_event(slot.ready)
+                    for t in slot.dev:
+                        t.record_stream(torch.cuda.current_stream(dev))
+                yield batch
+                # the consumer is back for its next batch: every kernel that reads this one has been enqueued, so the slot
+                # can be refilled behind an event recorded on the compute stream now
+                if slot is not None:
+                    slot.released = torch.cuda.Event()
+                    slot.released.record(torch.cuda.current_stream(dev))
+                    free.put(slot)
+        finally:
+            stop.set()
+            thread.join(timeout=5.0)
+
+
+class SyntheticBatches:
+    """``steps`` batches ``[B, 2, 3, H, W]`` drawn on the device, uniform in [0, 1] like the dataset's normalised
+    frames (dataset/tlfm_dataset.py:187,191).  ``fresh=False`` re-uses one resident batch (the benchmark's default)."""
+
+    def __init__(self, steps: int, batch_size: int, resolution: int, device: Union[str, torch.device] = "cuda",
+                 seed: int = 1234, fresh: bool = True, sequence_length: int = 3, channels: int = 2):
+        self.steps, self.fresh = int(steps), fresh
+        self.shape = (batch_size, channels, sequence_length, resolution, resolution)
+        self.device = torch.device(device)
+        self.generator = torch.Generator(device=self.device).manual_seed(seed)
+        self._resident = None if fresh else torch.rand(self.shape, device=self.device, generator=self.generator)
+
+    def __len__(self) -> int:
+        return self.steps
+
+    def __iter__(self) -> Iterator[torch.Tensor]:
+        for _ in range(self.steps):
+            yield torch.rand(self.shape, device=self.device, generator=self.generator) if self.fresh else self._resident
+
+
+def prefetch(loader: Iterable, device: Union[str, torch.device], depth: int = 2) -> Iterable:
+    """``loader`` behind a DevicePrefetcher when that helps (a GPU target and a loader that is not already one of this
+    module's device-side feeds); otherwise the loader itself."""
+    device = torch.device(device)
+    if device.type != "cuda" or isinstance(loader, (DevicePrefetcher, SyntheticBatches)):
+        return loader
+    return DevicePrefetcher(loader, device, depth)

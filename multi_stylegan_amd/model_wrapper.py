@@ -20,6 +20,7 @@ from typing import Any, Dict, List, Optional, Union
 import torch
 import torch.nn as nn
 
+from . import data as msg_data
 from . import dist as msg_dist
 from . import loss, misc
 from . import optim as msg_optim
@@ -367,8 +368,10 @@ class ModelWrapper(object):
     def _gan_training(self, training_dataset, resume_training: bool = False,
                       top_k: Optional[nn.Module] = None) -> None:
         """One epoch: the reference's ``_gan_training`` (model_wrapper.py:245-451) over any iterable of real batches
-        ``[B, 2, 3, H, W]`` (host or device tensors; host batches are copied asynchronously)."""
-        for real_images in training_dataset:
+        ``[B, 2, 3, H, W]``.  Host batches (the reference's pinned-memory DataLoader, train_multi_stylegan.py:60-63, or any
+        pageable iterable) go through ``data.DevicePrefetcher``: staged in pinned slots and copied on a side stream one
+        iteration ahead, so the step never waits for its input; device-side feeds (``data.SyntheticBatches``) pass through."""
+        for real_images in msg_data.prefetch(training_dataset, self.device):
             self.train_iteration(real_images, resume_training=resume_training, top_k=top_k)
 
     def train(self, training_dataset, epochs: int = 20, save_model_after_n_epochs: int = 5,

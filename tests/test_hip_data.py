@@ -1,0 +1,117 @@
+"""The data feed (multi_stylegan_amd.data): pinned double-buffer prefetcher and device-side synthetic batches.
+Reference behaviour replaced: DataLoader(pin_memory=True) + `.to(device)` at the top of the iteration
+(train_multi_stylegan.py:60-63, model_wrapper.py:253-256)."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_prefetcher_delivers_every_batch_in_order_bit_exact():
+    from multi_stylegan_amd.data import DevicePrefetcher
+    torch.manual_seed(0)
+    host = [torch.rand(4, 2, 3, 64, 64) for _ in range(7)] + [torch.rand(3, 2, 3, 64, 64)]      # ragged last batch
+    seen = []
+    for i, batch in enumerate(DevicePrefetcher(host, DEV)):
+        assert batch.is_cuda and batch.shape == host[i].shape
+        # work that keeps reading the batch while the NEXT copy is already in flight on the copy stream
+        acc = batch.clone()
+        for _ in range(20):
+            acc = acc * 1.0 + (batch - batch)
+        seen.append(acc)
+    assert len(seen) == len(host)
+    for got, want in zip(seen, host):
+        assert torch.equal(got.cpu(), want)
+    # nested batches (tuples / dicts), pinned inputs, device tensors passing through, an early break, an empty loader
+    nested = [(torch.full((2, 3), float(i)), {"label": torch.tensor([i]), "dev": torch.full((2,), float(i), device=DEV)})
+              for i in range(5)]
+    nested[2] = (nested[2][0].pin_memory(), nested[2][1])
+    for i, (a, d) in enumerate(DevicePrefetcher(nested, DEV, depth=3)):
+        assert a.is_cuda and d["label"].is_cuda and float(a[0, 0]) == i and int(d["label"]) == i and float(d["dev"][0]) == i
+        if i == 3:
+            break
+    assert list(DevicePrefetcher([], DEV)) == []
+    assert [float(t) for t in DevicePrefetcher([torch.tensor(1.0, device=DEV), torch.tensor(2.0, device=DEV)], DEV)] == [1.0, 2.0]
+
+
+def test_prefetcher_surfaces_loader_errors():
+    from multi_stylegan_amd.data import DevicePrefetcher
+
+    def loader():
+        yield torch.zeros(2, 2)
+        raise RuntimeError("disk on fire")
+    it = iter(DevicePrefetcher(loader(), DEV))
+    assert next(it).shape == (2, 2)
+    with pytest.raises(RuntimeError, match="disk on fire"):
+        next(it)
+
+
+def test_synthetic_batches_are_device_side_and_reproducible():
+    from multi_stylegan_amd.data import SyntheticBatches, prefetch
+    a = [b.clone() for b in SyntheticBatches(3, 2, 32, DEV, seed=5)]
+    b = [b.clone() for b in SyntheticBatches(3, 2, 32, DEV, seed=5)]
+    assert len(a) == 3 and a[0].shape == (2, 2, 3, 32, 32) and a[0].is_cuda
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[0], a[1])
+    assert float(a[0].min()) >= 0.0 and float(a[0].max()) <= 1.0
+    resident = list(SyntheticBatches(3, 2, 32, DEV, fresh=False))
+    assert resident[0] is resident[2]
+    feed = SyntheticBatches(3, 2, 32, DEV)
+    assert prefetch(feed, DEV) is feed and prefetch([1, 2], "cpu") == [1, 2]
+
+
+def test_epoch_loop_feeds_pageable_host_batches_through_the_prefetcher(golden):
+    """ModelWrapper._gan_training on a list of pageable host batches == the same iterations on resident device batches
+    (same seeds): the prefetcher changes where the copy happens, not what is trained."""
+    import multi_stylegan_amd as m
+    from test_hip_models import _models
+    results = []
+    for feed in ("host", "device"):
+        _, g, d = _models(golden)
+        tr = m.ModelWrapper(g, d, device=DEV)
+        torch.manual_seed(3)
+        import random
+        import numpy
+        random.seed(3); numpy.random.seed(3)
+        batches = [torch.rand(3, 2, 3, 32, 32, generator=torch.Generator().manual_seed(i)) for i in range(3)]
+        if feed == "device":
+            batches = [b.to(DEV) for b in batches]
+        tr._gan_training(batches)
+        results.append([p.detach().clone() for p in list(g.parameters()) + list(d.parameters())])
+    assert all(torch.equal(a, b) for a, b in zip(*results))
+
+
+def test_pageable_host_feed_does_not_slow_the_step():
+    """256^2, batch 16 (BASELINE configs[1]): iterations fed from PAGEABLE host memory through the prefetcher take the time of
+    iterations on a resident batch.  (The reference's `.to(device)` of a pageable batch is a synchronous 25 MB copy in
+    front of the step; here staging and H2D run a whole iteration ahead on their own thread and stream.)"""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    from multi_stylegan_amd.data import DevicePrefetcher
+    torch.manual_seed(1)
+    gen = m.MultiStyleGANGenerator(generator_config_for_resolution(256))
+    dis = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    gen.compute_dtype = dis.compute_dtype = torch.bfloat16
+    tr = m.ModelWrapper(gen, dis, device=DEV)
+    tr.generator_ema.compute_dtype = torch.bfloat16
+    host = torch.rand(16, 2, 3, 256, 256)                                 # pageable
+    resident = host.to(DEV)
+    n = 12
+
+    def timed(feed):
+        tr.iteration = 16                                                 # 17 .. 28: plain iterations only
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for batch in feed:
+            tr.train_iteration(batch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    timed([resident] * 3)                                                 # warm-up
+    t_res = min(timed([resident] * n) for _ in range(2))
+    t_feed = min(timed(DevicePrefetcher([host] * n, DEV)) for _ in range(2))
+    t_naive = timed([host] * n)                                           # the reference's way, for the record
+    print(f"resident {1e3 * t_res:.2f} ms/step, prefetched from pageable host memory {1e3 * t_feed:.2f}, "
+          f"`.to(device)` per step {1e3 * t_naive:.2f}")
+    assert t_feed <= 1.02 * t_res, (t_feed, t_res)

@@ -417,9 +417,11 @@ def test_config2_256px_batch16_matches_oracle():
 def test_config4_512px_matches_oracle():
     """BASELINE config 4's models -- 512x512, 8 x 512 channels in G, the discriminator on 512^2 inputs with its
     16384 x 4096 non-local attention (fused kernels) -- against the CPU oracle with the same weights, z and noise:
-    generator image and discriminator outputs, fp32 (1e-3) and bf16 storage (5e-2).  Batch 2 instead of the config's 8
-    per GPU: the oracle needs ~25 s per sample on the box's CPU; the batch-8 launch shapes are exercised by
-    test_full_size_models / the benchmark, the 512^2-only shapes (9th generator level, 16384-query attention) here."""
+    generator image, discriminator outputs and the gradients of one discriminator backward, fp32 (1e-3 / 2e-3) and bf16
+    storage (5e-2 / 0.1 norm-wise).  Batch 2 instead of the config's 8 per GPU: the oracle needs ~25 s per sample forward
+    on the box's CPU; the config's own batch runs whole training iterations in
+    test_config4_512px_batch8_train_iteration, the 512^2-only shapes (9th generator level, 16384-query attention) are
+    checked against the oracle here."""
     import time
     import multi_stylegan_amd as m
     from multi_stylegan_amd.config import generator_config_for_resolution
@@ -439,10 +441,18 @@ def test_config4_512px_matches_oracle():
     z = [torch.randn(bsz, 512, generator=gen_cpu), torch.randn(bsz, 512, generator=gen_cpu)]
     noise = [torch.randn(bsz, 1, 4, 4, generator=gen_cpu)] + \
             [torch.randn(bsz, 1, 2 ** (i // 2 + 3), 2 ** (i // 2 + 3), generator=gen_cpu) for i in range(14)]
+    watch = ["encoder_blocks.0.main_mapping.0.weight", "encoder_blocks.1.main_mapping.2.weight",
+             "encoder_blocks.2.theta.weight", "encoder_blocks.2.g.weight", "downscale_convolutions.1.0.weight",
+             "decoder_blocks.1.o.weight", "decoder_blocks.3.main_mapping.0.weight", "transposed_convolutions.3.1.weight",
+             "final_mapping.1.weight", "classification_head.2.weight", "encoder_blocks.4.main_mapping.1.bias"]
     t0 = time.time()
     with torch.no_grad():
         want_img = go(z, noise=noise, inject_index=7)
-        ws, wp = do(want_img)
+    ws, wp = do(want_img)
+    (ws.mean() + wp.mean()).backward()
+    want_grads = {n: dict(do.named_parameters())[n].grad.clone() for n in watch}
+    ws, wp = ws.detach(), wp.detach()
+    do.zero_grad(set_to_none=True)
     print(f"oracle on the CPU: {time.time() - t0:.1f} s")
     assert want_img.shape == (bsz, 2, 3, 512, 512)
     gd = m.MultiStyleGANGenerator(cfg)
@@ -454,19 +464,138 @@ def test_config4_512px_matches_oracle():
     orig = attention._NonLocalAttention.apply
     attention._NonLocalAttention.apply = staticmethod(lambda *a: (fused_calls.append(a[0].shape), orig(*a))[1])
     try:
-        for dt, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+        for dt, tol, tol_grad in ((torch.float32, 1e-3, 2e-3), (torch.bfloat16, 5e-2, 0.1)):
             gd.compute_dtype = dd.compute_dtype = dt
+            dd.zero_grad()
             with torch.no_grad():
                 img = gd([t.to(DEV) for t in z], noise=[t.to(DEV) for t in noise], inject_index=7)
-                s, px = dd(want_img.to(DEV))
+            s, px = dd(want_img.to(DEV))
+            (s.mean() + px.mean()).backward()           # the discriminator's backward at 512^2: 16384-query attention included
             errs = (rel_err(img, want_img), rel_err(s, ws), rel_err(px, wp))
-            print(f"{dt}: image {errs[0]:.2e}  score {errs[1]:.2e}  pixel map {errs[2]:.2e}")
+            params = dict(dd.named_parameters())
+            if dt == torch.float32:
+                e_g = {n: rel_err(params[n].grad, want_grads[n]) for n in watch}
+            else:
+                e_g = {n: ((params[n].grad.cpu() - want_grads[n]).norm() / want_grads[n].norm()).item() for n in watch}
+            print(f"{dt}: image {errs[0]:.2e}  score {errs[1]:.2e}  pixel map {errs[2]:.2e}  grads " +
+                  " ".join(f"{v:.1e}" for v in e_g.values()))
             assert max(errs) < tol, (dt, errs)
+            assert max(e_g.values()) < tol_grad, (dt, e_g)
             del img, s, px
             torch.cuda.empty_cache()
     finally:
         attention._NonLocalAttention.apply = orig
     assert (bsz, 16384, 48) in [tuple(sh) for sh in fused_calls], "the 16384-query attention ran on the fused kernels"
+
+
+def test_config4_512px_batch8_train_iteration():
+    """BASELINE config 4's per-GPU work at its own size: 512x512, 8 x 512 channels, batch 8 -- whole training iterations,
+    the 15th (plain) and the 16th (lazy R1 and path-length regularisers: double backward through the 16384-query attention
+    and the 9-level generator), in bf16 storage (the benchmarked path) and in fp32 storage from the same initial state with
+    the same draws.  Checks: every loss and parameter finite; the pre-clip global gradient norm of every optimiser step
+    (d, r1, g, pl) and the logged losses of the bf16 path track the fp32 path; peak memory of the bf16 path below 48 GiB
+    (one MI355X holds six times that)."""
+    import copy as _copy
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    torch.manual_seed(41)
+    bsz, res = 8, 512
+    g0 = m.MultiStyleGANGenerator(generator_config_for_resolution(res))
+    d0 = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    gen_cpu = torch.Generator().manual_seed(42)
+    n_noise = 2 * (int(math.log2(res)) - 2)
+    mk_noise = lambda n: [torch.randn(n, 1, 4, 4, generator=gen_cpu)] + \
+        [torch.randn(n, 1, 2 ** (i // 2 + 3), 2 ** (i // 2 + 3), generator=gen_cpu) for i in range(n_noise)]
+    zz = lambda n: [torch.randn(n, 512, generator=gen_cpu), torch.randn(n, 512, generator=gen_cpu)]
+    draws = [m.Draws(z_d=zz(bsz), inject_d=5, noise_d=mk_noise(bsz), z_g=zz(bsz), inject_g=9, noise_g=mk_noise(bsz),
+                     z_pl=zz(bsz // 2), inject_pl=7, noise_pl=mk_noise(bsz // 2),
+                     pl_image_noise=torch.randn(bsz // 2, 2, 3, res, res, generator=gen_cpu)) for _ in range(2)]
+    real = torch.rand(bsz, 2, 3, res, res, generator=gen_cpu)
+    runs = {}
+    for dt in (torch.bfloat16, torch.float32):
+        g, d = _copy.deepcopy(g0), _copy.deepcopy(d0)
+        g.compute_dtype = d.compute_dtype = dt
+        tr = m.ModelWrapper(g, d, device=DEV)
+        tr.generator_ema.compute_dtype = dt
+        tr.iteration = 14
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        norms = {}
+        for it, dr in enumerate(draws):
+            tr.step_trace = {}
+            tr.train_iteration(real.to(DEV), dr.to(DEV))
+            norms.update({f"it{15 + it}.{k[:-6]}": float(v) for k, v in tr.step_trace.items() if k.endswith(".gnorm")})
+            tr.step_trace = None
+        logs = tr.pop_logs()
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        assert sorted(norms) == ["it15.d", "it15.g", "it16.d", "it16.g", "it16.pl", "it16.r1"], sorted(norms)
+        assert {"loss_discriminator_regularization", "path_length", "loss_generator"} <= set(logs)
+        assert all(math.isfinite(v) for vals in logs.values() for v in vals), logs
+        assert all(math.isfinite(v) and v > 0 for v in norms.values()), norms
+        assert all(torch.isfinite(p).all() for p in list(g.parameters()) + list(d.parameters()))
+        runs[dt] = (norms, logs, peak)
+        print(f"{dt}: peak {peak:.1f} GiB  norms " + " ".join(f"{k}={v:.4g}" for k, v in norms.items()))
+        del tr, g, d
+        torch.cuda.empty_cache()
+    (nb, lb, peak_bf16), (nf, lf, _) = runs[torch.bfloat16], runs[torch.float32]
+    assert peak_bf16 < 48.0, peak_bf16
+    for k in nf:                              # bf16 storage drift through ~35 layers and two differentiations
+        assert abs(nb[k] - nf[k]) <= 0.2 * nf[k], (k, nb[k], nf[k])
+    for k in ("loss_discriminator_real", "loss_discriminator_fake", "loss_generator", "path_length"):
+        for a, b in zip(lb[k], lf[k]):
+            assert abs(a - b) <= 0.1 * abs(b) + 1e-3, (k, a, b)
+
+
+MODCONV = {"conv3x3_demod": dict(kernel_size=(3, 3), demodulate=True, upsampling=False),
+           "up2x2_demod": dict(kernel_size=(2, 2), demodulate=True, upsampling=True),
+           "torgb1x1_nodemod": dict(kernel_size=(1, 1), demodulate=False, upsampling=False)}
+
+
+@pytest.mark.parametrize("kind", list(MODCONV))
+@pytest.mark.parametrize("mapped", [True, False])
+def test_modulated_conv_module_golden(golden, kind, mapped):
+    """The product's ``ModulatedConv2d`` MODULE against the reference's (tests/golden/modconv.npz): with and
+    without its ``modulation_mapping``, output, returned style, gradients wrt input / style / weight, and one double
+    gradient (d |gx|^2 / d style -- the path-length pattern) through the native kernels."""
+    from multi_stylegan_amd import multi_stylegan_generator as G
+    z = golden("modconv")
+    name = f"{kind}.{'map' if mapped else 'nomap'}"
+    out_c = 3 if kind.startswith("torgb") else 12
+    mod = G.ModulatedConv2d(8, out_c, 10, modulation_mapping=mapped, **MODCONV[kind])
+    mod.load_state_dict(z.state_dict(name + ".sd."))
+    mod.to(DEV)
+    x, st = z[name + ".x"].to(DEV).requires_grad_(True), z[name + ".style"].to(DEV).requires_grad_(True)
+    res = mod(x, st)
+    y = res[0] if mapped else res
+    gx, gst, gw = torch.autograd.grad(y, (x, st, mod.weight), z[name + ".gy"].to(DEV), create_graph=True)
+    gg, = torch.autograd.grad(gx.square().sum(), st)
+    assert rel_err(y, z[name + ".y"]) < TOL
+    assert rel_err(gx, z[name + ".gx"]) < TOL
+    assert rel_err(gst, z[name + ".gstyle"]) < TOL
+    assert rel_err(gw, z[name + ".gweight"]) < TOL
+    assert rel_err(gg, z[name + ".gg_style"]) < TOL
+    if mapped:
+        assert rel_err(res[1], z[name + ".style_out"]) < TOL
+
+
+def test_discriminator_block_modules_golden(golden):
+    """``NonLocalBlock``, ``ResNetBlock(mini_batch_std_dev=True)``, ``MinibatchStdDev`` and ``PixelwiseNormalization``
+    MODULES against the reference's (tests/golden/layers.npz): output and input gradient."""
+    from multi_stylegan_amd import equalized_layer as E, u_net_2d_discriminator as U
+    z = golden("layers")
+    for name, blk in (("nonlocal", U.NonLocalBlock(8, 16)), ("resnet_mbstd", U.ResNetBlock(8, 12, True))):
+        blk.load_state_dict(z.state_dict(name + ".sd."))
+        blk.to(DEV)
+        x = z[name + ".x"].to(DEV).requires_grad_(True)
+        y = blk(x)
+        gx, = torch.autograd.grad(y, x, z[name + ".gy"].to(DEV))
+        assert rel_err(y, z[name + ".y"]) < TOL and rel_err(gx, z[name + ".gx"]) < TOL, name
+    assert rel_err(U.MinibatchStdDev()(z["mbstd.x"].to(DEV)), z["mbstd.y"]) < TOL
+    assert rel_err(E.PixelwiseNormalization()(z["pixelnorm.x"].to(DEV)), z["pixelnorm.y"]) < TOL
+    lin = E.EqualizedLinear(12, 7).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(z["eqlinear.w"]); lin.bias.copy_(z["eqlinear.b"])
+    assert rel_err(lin(z["eqlinear.x"].to(DEV)), z["eqlinear.y"]) < TOL
 
 
 @pytest.mark.parametrize("batch", [1, 3])
@@ -605,6 +734,24 @@ def test_graph_captured_sampler_matches_eager(golden):
     bf, gfp = m.split_sequences(a)
     assert bf.shape == (2, 3, 3, 32, 32) and torch.equal(bf[:, :, 0], a[:, 0]) and torch.equal(gfp[:, :, 1], a[:, 1])
     assert gfp[:, :, 0].abs().max() == 0 and gfp[:, :, 2].abs().max() == 0
+    # weights that change AFTER the capture (an EMA step on the wrapped generator, a loaded checkpoint): the graph holds
+    # pointers to weight images re-laid outside it, so the sampler must notice and re-capture (round-2 advice)
+    fixed = m.GeneratorSampler(g2, batch_size=2, randomize_noise=False, device=DEV)
+    before = fixed(zfix).clone()
+    captured = fixed._graph
+    with torch.no_grad():
+        for p in g2.parameters():
+            p.mul_(0.9)                  # (in place: bumps the tensors' version counters, as load_state_dict does)
+    after = fixed(zfix).clone()
+    eager = m.GeneratorSampler(g2, batch_size=2, randomize_noise=False, use_graph=False, device=DEV)(zfix)
+    assert fixed._graph is not captured and torch.equal(after, eager) and not torch.equal(after, before)
+    with torch.no_grad():                # a `.data` write announced through invalidate_weight_cache (FlatAdam's EMA update)
+        for p in g2.parameters():
+            p.data.mul_(1.1)
+    m.conv_ops.invalidate_weight_cache(list(g2.parameters()))
+    again = fixed(zfix).clone()
+    eager = m.GeneratorSampler(g2, batch_size=2, randomize_noise=False, use_graph=False, device=DEV)(zfix)
+    assert torch.equal(again, eager) and not torch.equal(again, after)
 
 
 def test_validation_samples(golden):

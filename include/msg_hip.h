@@ -12,9 +12,11 @@
  *     configuration is an error, never a silent no-op (the reference silently
  *     launches nothing for unmatched modes: op_static/upfirdn2d_kernel.cu:172-211);
  *   - dtype: MSG_F32 or MSG_BF16 storage; arithmetic is always fp32.  The two entries that replace the
- *     reference's CUDA modules (msg_upfirdn2d[_pitched], msg_fused_bias_act, msg_bias_act_backward) also take
- *     MSG_F16, the `half` of AT_DISPATCH_FLOATING_TYPES_AND_HALF (op_static/upfirdn2d_kernel.cu:225,
- *     op_static/fused_bias_act_kernel.cu:79); double is not provided.
+ *     reference's CUDA modules (msg_upfirdn2d[_pitched], msg_fused_bias_act) take every type of
+ *     AT_DISPATCH_FLOATING_TYPES_AND_HALF (op_static/upfirdn2d_kernel.cu:225, op_static/fused_bias_act_kernel.cu:79):
+ *     also MSG_F16 (`half`; fp32 arithmetic) and MSG_F64 (`double`: storage AND arithmetic in float64, and the `fir` /
+ *     `bias` operands then point to float64 values too, as the reference's kernel / bias tensors share the input's
+ *     dtype -- the precision torch.autograd.gradcheck needs).  msg_bias_act_backward takes MSG_F16 as well.
  *
  * Each entry cites the reference interface it replaces (paths relative to the
  * reference repository root).
@@ -27,7 +29,7 @@ extern "C" {
 #endif
 
 enum { MSG_OK = 0, MSG_EINVAL = -1, MSG_EUNSUPPORTED = -2, MSG_ELAUNCH = -3 };
-enum { MSG_F32 = 0, MSG_BF16 = 1, MSG_F16 = 2 };
+enum { MSG_F32 = 0, MSG_BF16 = 1, MSG_F16 = 2, MSG_F64 = 3 };
 
 /* Library/ABI version and the code-object architecture it was built for ("gfx950"). */
 int msg_abi_version(void);

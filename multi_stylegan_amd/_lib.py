@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmsg_hip" + ("_" + os.environ["MSG_LIB_VARIANT
                         + ".so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msg_hip.h")
 
-MSG_F32, MSG_BF16, MSG_F16 = 0, 1, 2
+MSG_F32, MSG_BF16, MSG_F16, MSG_F64 = 0, 1, 2, 3
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_longlong, _c.c_float
 
@@ -101,15 +101,18 @@ def check(code, what):
         raise MsgHipError(f"{what}: {lib().msg_strerror(code).decode()} (code {code})")
 
 
-def dtype_code(t: torch.Tensor, allow_half: bool = False) -> int:
-    """MSG_* storage code of a tensor.  float16 only where `allow_half` (the FIR / activation entries that replace the
-    reference's CUDA modules, which dispatch float / double / half: upfirdn2d_kernel.cu:225)."""
+def dtype_code(t: torch.Tensor, allow_half: bool = False, allow_double: bool = False) -> int:
+    """MSG_* storage code of a tensor.  float16 only where `allow_half`, float64 only where `allow_double` (the FIR /
+    activation entries that replace the reference's CUDA modules, which dispatch float / double / half:
+    upfirdn2d_kernel.cu:225)."""
     if t.dtype == torch.float32:
         return MSG_F32
     if t.dtype == torch.bfloat16:
         return MSG_BF16
     if allow_half and t.dtype == torch.float16:
         return MSG_F16
+    if allow_double and t.dtype == torch.float64:
+        return MSG_F64
     raise MsgHipError(f"dtype {t.dtype} is not supported by the gfx950 kernels (float32 / bfloat16"
                       f"{' / float16' if allow_half else ''} only)")
 

@@ -38,6 +38,22 @@ __global__ __launch_bounds__(256) void bias_act_scalar_kernel(const T* __restric
     store_from_f32(y + i, act_apply(v, gate, p.act, p.alpha, p.scale));
 }
 
+// ---- float64 (MSG_F64: the `double` of AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79) -------------
+// x, bias, ref, y all float64, arithmetic in double exactly as fused_bias_act_kernel.cu:26-47 (x + b, slope by the sign
+// of x + b or of ref, * scale; alpha and scale are the float arguments widened).  No noise (our extension is fp32).
+__global__ __launch_bounds__(256) void bias_act_f64_kernel(const double* __restrict__ x, const double* __restrict__ bias,
+                                                           const double* __restrict__ ref, double* __restrict__ y,
+                                                           BiasActParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.size_x) return;
+    if (p.grad == 2) { y[i] = 0.0; return; }
+    double v = x[i];
+    if (bias) v += bias[(i / p.step_b) % p.size_b];
+    const double gate = (p.grad == 1 && ref) ? ref[i] : v;
+    if (p.act == 3) v = (gate > 0.0) ? v : v * (double)p.alpha;
+    y[i] = v * (double)p.scale;
+}
+
 // ---- vector paths ---------------------------------------------------------------------------------------------
 // CL = true : channels-last / [B,C] (step_b == 1, size_b % VEC == 0): one bias vector, one noise scalar per lane
 // CL = false: planar NCHW (step_b % VEC == 0): one bias scalar, one noise vector per lane
@@ -145,6 +161,14 @@ extern "C" int msg_fused_bias_act(const void* x, const float* bias, const void* 
     if (dtype == MSG_F32) return fwd_dispatch<float>(x, bias, ref, y, noise, noise_weight, p, s);
     if (dtype == MSG_BF16) return fwd_dispatch<bf16_t>(x, bias, ref, y, noise, noise_weight, p, s);
     if (dtype == MSG_F16) return fwd_dispatch<f16_t>(x, bias, ref, y, noise, noise_weight, p, s);
+    if (dtype == MSG_F64) {                          // `bias` holds float64 values (the reference's bias has the input's dtype)
+        if (noise) return MSG_EUNSUPPORTED;
+        const long long blocks = (size_x + 255) / 256;
+        if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
+        hipLaunchKernelGGL(bias_act_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const double*)x,
+                           (const double*)(const void*)bias, (const double*)ref, (double*)y, p);
+        return MSG_CHECK_LAUNCH();
+    }
     return MSG_EUNSUPPORTED;
 }
 

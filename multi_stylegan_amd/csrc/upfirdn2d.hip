@@ -47,6 +47,36 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const T* __restr
     store_from_f32(y + i, acc);
 }
 
+// float64 (MSG_F64; the `double` of AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:225): storage, FIR and
+// accumulation in double, taps visited in the reference kernel's order (upfirdn2d_kernel.cu:114-133: ky outer, kx inner),
+// so that gradcheck / gradgradcheck run through this entry in the precision they need.  Not a speed path.
+__global__ __launch_bounds__(256) void upfirdn2d_f64_kernel(const double* __restrict__ x, const double* __restrict__ fir,
+                                                            double* __restrict__ y, UpfirdnParams p, long long total) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int m = (int)(i % p.minor);
+    long long t = i / p.minor;
+    const int ox = (int)(t % p.out_w); t /= p.out_w;
+    const int oy = (int)(t % p.out_h);
+    const long long mj = t / p.out_h;
+    const double* xb = x + mj * (long long)p.in_h * p.in_w * p.in_pitch + m;
+    double acc = 0.0;
+    for (int ty = 0; ty < p.kh; ++ty) {
+        const int py = oy * p.down_y + ty - p.pad_y0;
+        if (py < 0 || py % p.up_y) continue;
+        const int iy = py / p.up_y;
+        if (iy >= p.in_h) continue;
+        for (int tx = 0; tx < p.kw; ++tx) {
+            const int px = ox * p.down_x + tx - p.pad_x0;
+            if (px < 0 || px % p.up_x) continue;
+            const int ix = px / p.up_x;
+            if (ix >= p.in_w) continue;
+            acc += xb[((long long)iy * p.in_w + ix) * p.in_pitch] * fir[(p.kh - 1 - ty) * p.kw + (p.kw - 1 - tx)];
+        }
+    }
+    y[i] = acc;
+}
+
 // Fast path: k <= 4x4, (UP,DOWN) in {(1,1),(1,2),(2,1)}, minor a multiple of the 16-byte vector.
 // One lane = one 16-byte channel vector of a TH x TW output tile.  For UP == 2 tiles start on even outputs,
 // so which taps meet which input sample depends only on the parity PY/PX of (-pad0): a template constant.
@@ -276,5 +306,13 @@ extern "C" int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, i
     if (dtype == MSG_F32) return dispatch<float>(x, fir, y, p, s);
     if (dtype == MSG_BF16) return dispatch<bf16_t>(x, fir, y, p, s);
     if (dtype == MSG_F16) return dispatch<f16_t>(x, fir, y, p, s);
+    if (dtype == MSG_F64) {                          // `fir` holds float64 taps (the reference's kernel tensor has the input's dtype)
+        const long long n_out = (long long)major * p.out_h * p.out_w * minor;
+        const long long blocks = (n_out + 255) / 256;
+        if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
+        hipLaunchKernelGGL(upfirdn2d_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const double*)x,
+                           (const double*)(const void*)fir, (double*)y, p, n_out);
+        return MSG_CHECK_LAUNCH();
+    }
     return MSG_EUNSUPPORTED;
 }

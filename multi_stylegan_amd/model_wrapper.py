@@ -211,7 +211,8 @@ class ModelWrapper(object):
 
     def _control_random(self) -> float:
         """``random.random()`` for control flow: identical on every rank (see ``_control_rng``)."""
-        return self._control_rng.random() if self._control_rng is not None else random.random()
+        local = random.random()          # (the reference's draw: this rank's own stream advances as in a single process)
+        return self._control_rng.random() if self._control_rng is not None else local
 
     def _zero(self) -> None:
         self.discriminator_reducer.zero_grad()

@@ -42,6 +42,17 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
         ref = ref.reshape(x.shape).contiguous(memory_format=torch.channels_last if step_b == 1 and x.ndim == 4
                                              else torch.contiguous_format)
     y = torch.empty_like(x)
+    if x.dtype == torch.float64:
+        # the `double` of the reference's dispatch (fused_bias_act_kernel.cu:79): everything in float64
+        if noise is not None:
+            raise _lib.MsgHipError("the fused noise injection is an fp32 / bf16 / fp16 path; float64 takes bias only")
+        b64 = None if bias is None else bias.to(torch.float64).contiguous()
+        with _lib.on_device(dev):
+            code = _lib.lib().msg_fused_bias_act(
+                x.data_ptr(), _lib.ptr(b64), _lib.ptr(ref), y.data_ptr(), _lib.MSG_F64, x.numel(), step_b, x.shape[1],
+                None, None, 1, pix, act, grad, float(alpha), float(scale), _lib.stream_of(dev))
+        _lib.check(code, "msg_fused_bias_act")
+        return y.reshape(shape) if y.shape != shape else y
     nz, nb = _noise_args(noise, x)
     b32 = None if bias is None else bias.to(torch.float32).contiguous()
     nw32 = None if noise_weight is None else noise_weight.to(torch.float32).contiguous()
@@ -62,6 +73,14 @@ class FusedLeakyReLUFunctionBackward(Function):
         # a gradient that autograd summed from two consumers inherits the layout of whichever arrived first, and the engine's
         # order in second-order passes depends on thread-local node counters, i.e. on the process's history -- a
         # layout-dependent kernel choice would make the order of the bias sum, and so its last bit, vary between runs.
+        if grad_output.dtype == torch.float64:
+            # float64 (gradcheck): the reference's own formulation -- fused_bias_act(grad=1) and the bias sum in PyTorch
+            # (op_static/fused_act.py:24-42)
+            gx = _bias_act(grad_output, None, out, None, None, 1, negative_slope, scale)
+            ctx.save_for_backward(out, noise)
+            ctx.cfg = (negative_slope, scale)
+            dims = [0] + list(range(2, gx.ndim))
+            return gx, (gx.sum(dims) if need_bias else gx.new_zeros(0)), gx.new_zeros(0)
         o, step_b, pix, _ = _layout(out)
         dev = _lib.require_gpu(grad_output, o, noise)
         g = grad_output.reshape(o.shape)

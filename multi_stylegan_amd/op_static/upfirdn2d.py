@@ -61,6 +61,20 @@ def _launch(x, fir, up, down, pad):
     oh, ow = _out_size(h, up_y, down_y, py0, py1, kh), _out_size(w, up_x, down_x, px0, px1, kw)
     if oh <= 0 or ow <= 0:
         raise _lib.MsgHipError(f"upfirdn2d: empty output {oh}x{ow}")
+    if x.dtype == torch.float64:
+        # the `double` of the reference's dispatch (upfirdn2d_kernel.cu:225): storage, FIR and arithmetic in float64 -- the
+        # precision gradcheck / gradgradcheck need.  One scalar kernel, either layout.
+        cl = _is_channels_last(x)
+        x = x if cl else x.contiguous()
+        major, minor = (b, c) if cl else (b * c, 1)
+        y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev,
+                        memory_format=torch.channels_last if cl else torch.contiguous_format)
+        fir64 = fir.to(torch.float64).contiguous()
+        with _lib.on_device(dev):
+            code = _lib.lib().msg_upfirdn2d(x.data_ptr(), fir64.data_ptr(), y.data_ptr(), _lib.MSG_F64, major, h, w, minor,
+                                            kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1, _lib.stream_of(dev))
+        _lib.check(code, "msg_upfirdn2d")
+        return y
     fir = fir.to(torch.float32).contiguous()
     pitch = None
     if c > 1 and x.stride(1) == 1 and not _is_channels_last(x):

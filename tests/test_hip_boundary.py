@@ -16,7 +16,14 @@ from conftest import ROOT, rel_err
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # storage type -> tolerance relative to max|ref| (inputs are rounded to the storage type first; fp32 arithmetic)
-TOLS = {torch.float32: 1e-5, torch.float16: 3e-3, torch.bfloat16: 2e-2}
+TOLS = {torch.float32: 1e-5, torch.float16: 3e-3, torch.bfloat16: 2e-2, torch.float64: 1e-12}
+
+
+def _want(z, key, dtype, fn):
+    """The expected tensor: the reference-generated golden vector, except in float64, where the fixtures (float32 data) are
+    too coarse for a 1e-12 check -- there the pinned oracle (oracle/ops.py, checked against the same fixtures in
+    tests/test_oracle_golden.py) is evaluated in float64 on the same inputs."""
+    return fn() if dtype == torch.float64 else z[key]
 UPFIRDN_CASES = ["g_blur_pad21_gain4", "g_skip_up2_pad21", "d_blur_pad22_odd", "bwd_of_up2_down2",
                  "asym_blur_pad21", "asym_up2_pad21", "asym_down2_pad12", "blur_pad11"]
 
@@ -52,17 +59,24 @@ def test_upfirdn2d_stub_module(golden, stubs, case, dtype):
     y = up_mod.upfirdn2d(_planes(x), fir, up, up, down, down, p0, p1, p0, p1)
     out_h, out_w = y.shape[1:3]
     assert y.dtype == dtype and y.shape == (b * c, out_h, out_w, 1)
-    assert rel_err(y.reshape(b, c, out_h, out_w), z[case + ".y"]) < tol
+    from oracle import ops as oo
+    f64 = lambda t: t.double().cpu()
+    want_y = _want(z, case + ".y", dtype, lambda: oo.upfirdn2d(f64(x), f64(fir), up, down, (p0, p1)))
+    assert rel_err(y.reshape(b, c, out_h, out_w), want_y) < tol
     # backward = the same op with up <-> down, the flipped kernel and g_pad (upfirdn2d.py:34-45, 114-119)
     g0x, g1x = kw - p0 - 1, in_w * up - out_w * down + p0 - up + 1
     g0y, g1y = kh - p0 - 1, in_h * up - out_h * down + p0 - up + 1
     gy = z[case + ".gy"].to(DEV, dtype)
     gx = up_mod.upfirdn2d(_planes(gy), torch.flip(fir, [0, 1]), down, down, up, up, g0x, g1x, g0y, g1y)
-    assert rel_err(gx.reshape(b, c, in_h, in_w), z[case + ".gx"]) < tol
+    def adjoint():                                  # d<oracle(x), gy>/dx in float64
+        x64 = f64(x).requires_grad_(True)
+        return torch.autograd.grad(oo.upfirdn2d(x64, f64(fir), up, down, (p0, p1)), x64, f64(gy))[0]
+    assert rel_err(gx.reshape(b, c, in_h, in_w), _want(z, case + ".gx", dtype, adjoint)) < tol
     # double backward = the forward configuration on the incoming second-order gradient (upfirdn2d.py:71-82)
     ggx = z[case + ".ggx"].to(DEV, dtype)
     ggy = up_mod.upfirdn2d(_planes(ggx), fir, up, up, down, down, p0, p1, p0, p1)
-    assert rel_err(ggy.reshape(b, c, out_h, out_w), z[case + ".ggy"]) < tol
+    want_ggy = _want(z, case + ".ggy", dtype, lambda: oo.upfirdn2d(f64(ggx), f64(fir), up, down, (p0, p1)))
+    assert rel_err(ggy.reshape(b, c, out_h, out_w), want_ggy) < tol
 
 
 @pytest.mark.parametrize("dtype", list(TOLS))
@@ -73,30 +87,62 @@ def test_fused_bias_act_stub_module(golden, stubs, case, dtype):
     x, bias = z[case + ".x"].to(DEV, dtype), z[case + ".b"].to(DEV)
     empty = torch.empty(0, device=DEV)                                   # "absent" (fused_act.py:27, 59)
     out = act_mod.fused_bias_act(x, bias, empty, 3, 0, 0.2, scale)
-    assert out.dtype == dtype and rel_err(out, z[case + ".y"]) < tol
+    from oracle import ops as oo
+    f64 = lambda t: t.double().cpu()
+    bshape = (1, -1) + (1,) * (x.ndim - 2)
+    want_y = _want(z, case + ".y", dtype, lambda: oo.fused_leaky_relu(f64(x), f64(bias), 0.2, scale))
+    assert out.dtype == dtype and rel_err(out, want_y) < tol
     # backward: grad=1, slope from the sign of the saved OUTPUT, no bias (fused_act.py:31-33); grad_bias in PyTorch
     gy = z[case + ".gy"].to(DEV, dtype)
-    ref_out = z[case + ".y"].to(DEV, dtype)
+    ref_out = out if dtype == torch.float64 else z[case + ".y"].to(DEV, dtype)
     gx = act_mod.fused_bias_act(gy, empty, ref_out, 3, 1, 0.2, scale)
-    assert rel_err(gx, z[case + ".gx"]) < tol
+    mask = lambda: torch.where(f64(ref_out) > 0, 1.0, 0.2) * scale
+    assert rel_err(gx, _want(z, case + ".gx", dtype, lambda: f64(gy) * mask())) < tol
     dims = [0] + list(range(2, gx.ndim))
-    assert rel_err(gx.float().sum(dims), z[case + ".gb"]) < max(tol, 1e-5) * 4
+    want_gb = _want(z, case + ".gb", dtype, lambda: (f64(gy) * mask()).sum(dims))
+    assert rel_err((gx if dtype == torch.float64 else gx.float()).sum(dims), want_gb) < max(tol, 1e-5) * 4
     # double backward: grad=1 on (gg_input + gg_bias[c]) with the same refer (fused_act.py:47-49)
-    ggy = act_mod.fused_bias_act(z[case + ".ggx"].to(DEV, dtype), z[case + ".ggb"].to(DEV), ref_out, 3, 1, 0.2, scale)
-    assert rel_err(ggy, z[case + ".ggy"]) < tol
+    ggx, ggb = z[case + ".ggx"].to(DEV, dtype), z[case + ".ggb"].to(DEV)
+    ggy = act_mod.fused_bias_act(ggx, ggb, ref_out, 3, 1, 0.2, scale)
+    want_ggy = _want(z, case + ".ggy", dtype, lambda: (f64(ggx) + f64(ggb).view(bshape)) * mask())
+    assert rel_err(ggy, want_ggy) < tol
 
 
 def test_stub_modules_error_behaviour(stubs):
-    """CHECK_CUDA of the reference (upfirdn2d.cpp:15-16, fused_bias_act.cpp:13-14): host tensors are refused; double
-    (not provided) is refused loudly instead of computing in another type."""
+    """CHECK_CUDA of the reference (upfirdn2d.cpp:8,15-16, fused_bias_act.cpp:7,13-14) is a TORCH_CHECK: host tensors raise
+    RuntimeError, exactly what a caller of the CUDA modules catches; a dtype outside the dispatch list is refused loudly."""
     up_mod, act_mod = stubs["upfirdn2d_cuda"], stubs["fused_act_cuda"]
-    with pytest.raises(AssertionError):
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
         up_mod.upfirdn2d(torch.zeros(1, 4, 4, 1), torch.ones(4, 4), 1, 1, 1, 1, 2, 1, 2, 1)
-    with pytest.raises(AssertionError):
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
         act_mod.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), torch.empty(0), 3, 0, 0.2, 1.0)
     with pytest.raises(KeyError):
-        up_mod.upfirdn2d(torch.zeros(1, 4, 4, 1, device=DEV, dtype=torch.float64), torch.ones(4, 4, device=DEV),
+        up_mod.upfirdn2d(torch.zeros(1, 4, 4, 1, device=DEV, dtype=torch.int32), torch.ones(4, 4, device=DEV),
                          1, 1, 1, 1, 2, 1, 2, 1)
+
+
+def test_gradcheck_runs_in_float64_through_the_drop_in_ops():
+    """What SURVEY 8c did with CPU stand-ins, on the device through the C ABI: gradcheck and gradgradcheck of the
+    twice-differentiable drop-in ops (`op_static.upfirdn2d`, `fused_leaky_relu`: the reference's public names and argument
+    lists, op_static/upfirdn2d.py:148-153, fused_act.py:88-89) in float64, i.e. through msg_upfirdn2d / msg_fused_bias_act
+    with MSG_F64 -- the same entries the stub modules above bind."""
+    from multi_stylegan_amd import op_static
+    torch.manual_seed(11)
+    fir = torch.tensor([1., 3., 3., 1.], dtype=torch.float64, device=DEV)
+    fir = torch.outer(fir, fir) / 64
+    for up, down, p0, p1 in ((1, 1, 2, 1), (2, 1, 2, 1), (1, 2, 1, 1)):
+        x = torch.randn(2, 3, 6, 5, dtype=torch.float64, device=DEV, requires_grad=True)
+        own = lambda t: op_static.upfirdn2d(t, fir, up=up, down=down, pad=(p0, p1))
+        assert torch.autograd.gradcheck(own, (x,), eps=1e-6, atol=1e-8)
+        assert torch.autograd.gradgradcheck(own, (x,), eps=1e-6, atol=1e-8)
+        xcl = torch.randn(2, 3, 6, 5, dtype=torch.float64, device=DEV).contiguous(memory_format=torch.channels_last)
+        assert torch.autograd.gradcheck(own, (xcl.requires_grad_(True),), eps=1e-6, atol=1e-8)
+    x = torch.randn(3, 4, 5, 5, dtype=torch.float64, device=DEV)
+    x = (x + 0.3 * x.sign()).requires_grad_(True)                       # keep clear of the kink at 0
+    bias = (0.05 * torch.randn(4, dtype=torch.float64, device=DEV)).requires_grad_(True)
+    act = lambda t, b: op_static.fused_leaky_relu(t, b, 0.2, 2 ** 0.5)
+    assert torch.autograd.gradcheck(act, (x, bias), eps=1e-6, atol=1e-8)
+    assert torch.autograd.gradgradcheck(act, (x, bias), eps=1e-6, atol=1e-8)
 
 
 def test_product_ops_accept_half():

@@ -132,7 +132,7 @@ def test_trainer_one_rank_rccl_collectives_forced():
     p2.join(120)
     assert p1.exitcode == 0 and p2.exitcode == 0
     assert all(all(v == v for v in vals) for vals in logs1.values()), "NaN in losses"
-    # same trajectory up to float-atomic ordering inside the weight-gradient kernels; a broken exchange (double counting,
+    # same trajectory (every kernel is deterministic; the all-reduce of one rank is the identity); a broken exchange (double counting,
     # a missing bucket, a stale gradient) changes the SGD step at the 1e-1 level
     rel = (flat1 - flat2).norm() / flat2.norm()
     assert rel < 1e-5, rel

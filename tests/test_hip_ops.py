@@ -181,7 +181,9 @@ def test_upfirdn2d_edge_cases():
     with pytest.raises(MsgHipError):                       # empty output
         ops.upfirdn2d(torch.zeros(1, 1, 2, 2, device=DEV), fir, pad=(0, 0))
     with pytest.raises(MsgHipError):                       # unsupported storage type
-        ops.upfirdn2d(torch.zeros(1, 1, 8, 8, device=DEV, dtype=torch.float64), fir, pad=(2, 1))
+        ops.upfirdn2d(torch.zeros(1, 1, 8, 8, device=DEV, dtype=torch.int32), fir, pad=(2, 1))
+    y64 = ops.upfirdn2d(torch.ones(1, 1, 8, 8, device=DEV, dtype=torch.float64), fir, pad=(2, 1))   # double: provided
+    assert y64.dtype == torch.float64 and abs(float(y64[0, 0, 4, 4]) - 1.0) < 1e-15
     y = ops.upfirdn2d(torch.zeros(0, 8, 8, 8, device=DEV), fir, pad=(2, 1))      # empty batch
     assert y.shape == (0, 8, 8, 8)
     x = torch.ones(1, 8, 6, 6, device=DEV)

@@ -97,11 +97,12 @@ def global_top_k(scores: torch.Tensor, v: float):
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "work", "ready")
+    __slots__ = ("flat", "params", "offsets", "pending", "work", "ready", "shard")
 
     def __init__(self, flat, params, offsets):
         self.flat, self.params, self.offsets = flat, params, offsets
         self.pending, self.work, self.ready = len(params), None, False
+        self.shard = None                    # exchange == "reduce_scatter": this rank's 1/world slice of the reduced bucket
 
 
 BUCKET_ALIGN = 64        # elements (256 bytes): every parameter's slice of a flat store starts on this boundary
@@ -127,17 +128,35 @@ class GradBucketReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 overlap: bool = True, group=None, split_key=None):
+                 overlap: bool = True, group=None, split_key=None, exchange: Optional[str] = None):
         """``split_key(parameter)``: parameters with different keys never share a bucket (the trainer passes the
-        optimiser hyper-parameters, so that a bucket can be stepped by one launch -- multi_stylegan_amd.optim)."""
+        optimiser hyper-parameters, so that a bucket can be stepped by one launch -- multi_stylegan_amd.optim).
+        ``exchange``: "all_reduce" (default; RCCL picks the algorithm per message) or "reduce_scatter" -- every bucket is
+        reduce-scattered during backward (each rank receives 1/world of the summed bucket), the clip norm is taken from
+        the local shards (+ one scalar all-reduce) and the shards are all-gathered back in ``finish``; same result on
+        every rank, the two half-exchanges striped over all xGMI links.  Env: MSG_DDP_EXCHANGE."""
         params = [p for p in params if p.requires_grad]
         self.group, self.overlap = group, overlap
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.active = self.world > 1 or collectives_active()      # collectives are issued (see MSG_FORCE_COLLECTIVES)
+        self.exchange = exchange or os.environ.get("MSG_DDP_EXCHANGE", "all_reduce")
+        if self.exchange not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"exchange must be 'all_reduce' or 'reduce_scatter', not {self.exchange!r}")
         self.buckets: List[_Bucket] = []
         self._armed = False
         self._next = 0
         self._bucket_of = {}
+        # Which buckets a given kind of backward fills: `arm(label)` learns, the first time a label is seen, which
+        # parameters received a gradient (agreed over the ranks), and from then on buckets that this kind of backward never
+        # completes ("cold": the biases in the R1 step, whose graph reaches no bias) are exchanged LAST instead of stalling
+        # every bucket behind them until finish().  See _launch_ready.
+        self._learned = {}
+        self._label = None
+        self._fired = None
+        self._order: List[int] = []
+        self._cold: List[int] = []
+        self._shard_sumsq: Optional[torch.Tensor] = None
+        self._slot_of = {}
         cap = max(1, bucket_bytes // 4)
         # gradients become ready roughly in reverse registration order: fill buckets from the back
         chunk, size = [], 0
@@ -152,14 +171,20 @@ class GradBucketReducer:
         for ps in groups:
             dev = ps[0].device
             offsets, total = bucket_layout(ps)
+            if self.exchange == "reduce_scatter":                             # equal, 256-byte-aligned shards
+                unit = self.world * BUCKET_ALIGN
+                total = (total + unit - 1) // unit * unit
             flat = torch.zeros(total, dtype=torch.float32, device=dev)        # (padding stays zero: zero gradients)
             for p, off in zip(ps, offsets):
                 assert p.dtype == torch.float32 and p.device == dev
                 p.grad = flat[off:off + p.numel()].view_as(p)
             bucket = _Bucket(flat, ps, offsets)
+            if self.exchange == "reduce_scatter" and self.active:
+                bucket.shard = torch.zeros(total // self.world, dtype=torch.float32, device=dev)
             self.buckets.append(bucket)
             for p in ps:
                 self._bucket_of[p] = bucket
+                self._slot_of[p] = len(self._slot_of)
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.comm_stream = None
         if self.active and params and params[0].is_cuda:
@@ -185,12 +210,24 @@ class GradBucketReducer:
                 view.copy_(p.grad)
             p.grad = view
 
-    def arm(self) -> None:
-        """Call right before the backward whose gradients this reducer owns."""
+    def arm(self, label: Optional[str] = None) -> None:
+        """Call right before the backward whose gradients this reducer owns.  ``label`` names the KIND of backward (the
+        trainer passes "d", "r1", "g", "pl", ...): backwards of one kind reach the same parameters on every rank and in
+        every iteration, which is what lets cold buckets be taken out of the in-order launch sequence."""
         self._armed = True
-        self._next = 0                                   # collectives are issued strictly in bucket order on every rank
-        for b in self.buckets:
-            b.pending, b.work, b.ready = len(b.params), None, False
+        self._shard_sumsq = None
+        self._next = 0                                   # collectives are issued in ONE order on every rank: self._order
+        self._label = label
+        plan = self._learned.get(label) if label is not None else None
+        self._fired = set() if (label is not None and plan is None) else None
+        for k, b in enumerate(self.buckets):
+            b.pending = len(b.params) if plan is None else plan[k]
+            b.work, b.ready = None, False
+        if plan is None:
+            self._order, self._cold = list(range(len(self.buckets))), []
+        else:
+            self._order = [k for k, n in enumerate(plan) if n > 0]
+            self._cold = [k for k, n in enumerate(plan) if n == 0]
 
     def disarm(self) -> None:
         self._armed = False
@@ -201,6 +238,13 @@ class GradBucketReducer:
         b = self._bucket_of[p]
         if p.grad is not None and p.grad.data_ptr() != self._view_ptr(b, p):
             self._reattach(b)                      # autograd swapped the tensor (out-of-place accumulation)
+        if b.ready:
+            # the bucket is already on the wire: this gradient would be lost (or race with the collective).  Can only happen
+            # if a backward of this label reached a parameter that the learned plan says it never reaches.
+            raise RuntimeError(f"gradient of a parameter arrived after its bucket was exchanged (label {self._label!r}); "
+                               "backwards with one label must reach the same parameters -- use distinct labels")
+        if self._fired is not None:
+            self._fired.add(self._slot_of[p])
         b.pending -= 1
         if b.pending == 0 and self.overlap and self.active:
             self._launch_ready()
@@ -212,11 +256,13 @@ class GradBucketReducer:
         raise KeyError
 
     def _launch_ready(self) -> None:
-        """Launch every bucket that is complete AND whose predecessors have been launched.  The order in which
-        gradients become ready can differ between ranks (style mixing changes the generator's graph per rank), but
-        collectives must be issued in one order everywhere."""
-        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
-            self._launch(self.buckets[self._next])
+        """Launch every bucket that is complete AND whose predecessors in ``self._order`` have been launched.  The order in
+        which gradients become ready can differ between ranks (style mixing changes the generator's graph per rank), but
+        collectives must be issued in one order everywhere: the hot buckets in index order, then (in finish) the cold
+        ones.  Correctness never depends on the plan -- a bucket the plan calls hot but that stays incomplete is sent by
+        finish(), and every bucket is exchanged exactly once -- only the overlap does."""
+        while self._next < len(self._order) and self.buckets[self._order[self._next]].pending == 0:
+            self._launch(self.buckets[self._order[self._next]])
             self._next += 1
 
     def _launch(self, b: _Bucket) -> None:
@@ -224,9 +270,25 @@ class GradBucketReducer:
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream(b.flat.device))
             with torch.cuda.stream(self.comm_stream):
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = self._collective(b)
         else:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.work = self._collective(b)
+
+    def _collective(self, b: _Bucket):
+        if self.exchange == "reduce_scatter":
+            return dist.reduce_scatter_tensor(b.shard, b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _learn(self) -> None:
+        """First backward of a label: agree over the ranks on the parameters it reached (a parameter counts if ANY rank saw
+        its gradient) and turn that into per-bucket counts."""
+        seen = torch.zeros(len(self._slot_of), dtype=torch.float32, device=self.buckets[0].flat.device)
+        if self._fired:
+            seen[sorted(self._fired)] = 1.0
+        if self.active:
+            dist.all_reduce(seen, op=dist.ReduceOp.MAX, group=self.group)
+        hit = seen.cpu().tolist()
+        self._learned[self._label] = [sum(1 for p in b.params if hit[self._slot_of[p]] > 0) for b in self.buckets]
 
     def finish(self, average: bool = True) -> float:
         """Reduce whatever has not been sent yet, wait for everything, turn sums into means.  With average=False the
@@ -236,20 +298,43 @@ class GradBucketReducer:
         self._armed = False
         if not self.active:
             return 1.0
-        while self._next < len(self.buckets):             # whatever is left (incl. buckets with unused parameters)
-            self._launch(self.buckets[self._next])
-            self._next += 1
+        for k in self._order[self._next:] + self._cold:   # whatever is left (incomplete hot buckets, then the cold ones)
+            self._launch(self.buckets[k])
+        self._next = len(self._order)
         for b in self.buckets:
             b.work.wait()
+        if self.exchange == "reduce_scatter":
+            if self.comm_stream is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    self._gather_shards()
+            else:
+                self._gather_shards()
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.buckets[0].flat.device).wait_stream(self.comm_stream)
+        if self._fired is not None:
+            self._learn()
+            self._fired = None
         inv = 1.0 / self.world
         if not average:
             return inv
         torch._foreach_mul_([b.flat for b in self.buckets], inv)
+        if self._shard_sumsq is not None:
+            self._shard_sumsq = self._shard_sumsq * (inv * inv)
         return 1.0
 
+    def _gather_shards(self) -> None:
+        """reduce_scatter exchange, second half: the squared norm of this rank's shards (the global norm is then one scalar
+        all-reduce away: every element of the reduced gradient lives in exactly one rank's shard), and the shards back
+        into the flat buckets of every rank."""
+        sq = torch.stack([torch.linalg.vector_norm(b.shard) for b in self.buckets]).square().sum()
+        dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+        self._shard_sumsq = sq
+        for b in self.buckets:
+            dist.all_gather_into_tensor(b.flat, b.shard, group=self.group)
+
     def grad_norm(self) -> torch.Tensor:
+        if self._shard_sumsq is not None:
+            return self._shard_sumsq.sqrt()              # (of the rank SUM, like the flat buckets hold after finish(False))
         norms = torch._foreach_norm([b.flat for b in self.buckets])
         return torch.linalg.vector_norm(torch.stack(norms))
 
@@ -258,4 +343,5 @@ class GradBucketReducer:
         total = self.grad_norm()
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         torch._foreach_mul_([b.flat for b in self.buckets], coef)
+        self._shard_sumsq = None                         # (the cached norm described the unclipped buckets)
         return total

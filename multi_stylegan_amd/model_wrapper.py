@@ -260,7 +260,7 @@ class ModelWrapper(object):
                 count = max(1, int(hp["batch_factor_wrong_order"] * batch))
                 fake_images = torch.cat([fake_images.to(real_images.dtype),
                                          real_images[:count].index_select(2, perm.to(real_images.device))], dim=0)
-        self.discriminator_reducer.arm()
+        self.discriminator_reducer.arm("d")
         if self.batch_discriminator_passes and real_images.shape == fake_images.shape:
             # D(real) and D(fake) of the reference (:272-275) as ONE batch of 2B with per-half minibatch statistics:
             # same result, half the launches, better-filled tiles on the low-resolution layers
@@ -288,7 +288,7 @@ class ModelWrapper(object):
         if self.iteration % hp["lazy_discriminator_regularization"] == 0:
             self._zero()
             real_rg = real_images.detach().requires_grad_(True)
-            self.discriminator_reducer.arm()
+            self.discriminator_reducer.arm("r1")
             # (the reference keeps requires_grad on the batch and overwrites the D step's real predictions here, :313-316:
             # a CutMix block in the same iteration mixes THESE predictions)
             real_prediction, real_prediction_pixel_wise = D(real_rg, is_real=False, is_cut_mix=True)
@@ -307,7 +307,7 @@ class ModelWrapper(object):
             w_reg = hp["w_discriminator_regularization"]
             self._zero()
             images, label = generate_cut_mix_augmentation_data(real_for_cut_mix, fake_images, dr.cut_mix_map_aug)
-            self.discriminator_reducer.arm()
+            self.discriminator_reducer.arm("cm_aug")
             _, prediction = D(images, is_cut_mix=True)
             cm_real, cm_fake = self.cut_mix_augmentation_loss(prediction, label)
             (w_reg * (cm_real + cm_fake)).backward()
@@ -317,7 +317,7 @@ class ModelWrapper(object):
             images, label = generate_cut_mix_transformation_data(
                 real_for_cut_mix.detach(), fake_images.detach(), real_prediction_pixel_wise.detach(),
                 fake_prediction_pixel_wise.detach(), dr.cut_mix_map_reg)
-            self.discriminator_reducer.arm()
+            self.discriminator_reducer.arm("cm_reg")
             _, prediction = D(images, is_cut_mix=True)
             cm_consistency = self.cut_mix_regularization_loss(prediction, label)
             (w_reg * cm_consistency).backward()
@@ -328,7 +328,7 @@ class ModelWrapper(object):
         z = dr.z_g if dr.z_g is not None else self._noise(batch)
         if self.skip_d_wgrad:
             D.requires_grad_(False)
-        self.generator_reducer.arm()
+        self.generator_reducer.arm("g")
         fake_images = G(input=z, inject_index=dr.inject_g, noise=dr.noise_g)
         fake_prediction, fake_prediction_pixel_wise = D(fake_images, is_real=False, is_cut_mix=False)
         fake_prediction, fake_prediction_pixel_wise, factor = self._top_k(top_k, fake_prediction,
@@ -345,7 +345,7 @@ class ModelWrapper(object):
             self._zero()
             n_pl = max(1, int(hp["batch_size_shrink_path_length_regularization"] * batch))
             z = dr.z_pl if dr.z_pl is not None else self._noise(n_pl)
-            self.generator_reducer.arm()
+            self.generator_reducer.arm("pl")
             grads = G(input=z, inject_index=dr.inject_pl, noise=dr.noise_pl, return_path_length_grads=True,
                       path_length_noise=dr.pl_image_noise)
             reduce_fn = msg_dist.all_reduce_mean if msg_dist.collectives_active() else None

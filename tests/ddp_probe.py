@@ -43,10 +43,11 @@ class StepProbe:
         tr = self.trainer
         for label, local in self.local.items():
             red = tr.discriminator_reducer if label in ("d", "r1") else tr.generator_reducer
-            local = local.cpu()
+            if dist.get_backend() != "nccl":             # (RCCL gathers device tensors; gloo takes either)
+                local = local.cpu()
             gathered = [torch.zeros_like(local) for _ in range(world)]
             dist.all_gather(gathered, local)
-            mean = torch.stack(gathered).mean(0)
+            mean = torch.stack(gathered).mean(0).cpu()
             names = [tr._param_names[id(p)] for b in red.buckets for p in b.params]
             got = torch.cat([tr.step_trace[f"{label}.grad.{n}"].flatten() for n in names]).cpu()
             scale = mean.abs().max().item()

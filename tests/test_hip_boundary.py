@@ -90,13 +90,16 @@ def test_fused_bias_act_stub_module(golden, stubs, case, dtype):
     from oracle import ops as oo
     f64 = lambda t: t.double().cpu()
     bshape = (1, -1) + (1,) * (x.ndim - 2)
-    want_y = _want(z, case + ".y", dtype, lambda: oo.fused_leaky_relu(f64(x), f64(bias), 0.2, scale))
+    # (the native signature takes `float alpha, float scale` -- fused_bias_act.cpp:11-12 -- so the float64 arithmetic sees the
+    #  float32-rounded 0.2 and sqrt(2), in the reference as here)
+    a32, s32 = float(torch.tensor(0.2, dtype=torch.float32)), float(torch.tensor(scale, dtype=torch.float32))
+    want_y = _want(z, case + ".y", dtype, lambda: oo.fused_leaky_relu(f64(x), f64(bias), a32, s32))
     assert out.dtype == dtype and rel_err(out, want_y) < tol
     # backward: grad=1, slope from the sign of the saved OUTPUT, no bias (fused_act.py:31-33); grad_bias in PyTorch
     gy = z[case + ".gy"].to(DEV, dtype)
     ref_out = out if dtype == torch.float64 else z[case + ".y"].to(DEV, dtype)
     gx = act_mod.fused_bias_act(gy, empty, ref_out, 3, 1, 0.2, scale)
-    mask = lambda: torch.where(f64(ref_out) > 0, 1.0, 0.2) * scale
+    mask = lambda: torch.where(f64(ref_out) > 0, 1.0, a32) * s32
     assert rel_err(gx, _want(z, case + ".gx", dtype, lambda: f64(gy) * mask())) < tol
     dims = [0] + list(range(2, gx.ndim))
     want_gb = _want(z, case + ".gb", dtype, lambda: (f64(gy) * mask()).sum(dims))

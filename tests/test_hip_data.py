@@ -109,9 +109,14 @@ def test_pageable_host_feed_does_not_slow_the_step():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
     timed([resident] * 3)                                                 # warm-up
-    t_res = min(timed([resident] * n) for _ in range(2))
-    t_feed = min(timed(DevicePrefetcher([host] * n, DEV)) for _ in range(2))
+    # A / B / A / B: the chip's clock drifts by a per cent or two as it heats up over a few seconds, so the two feeds alternate
+    t_res, t_feed = [], []
+    for _ in range(3):
+        t_res.append(timed([resident] * n))
+        t_feed.append(timed(DevicePrefetcher([host] * n, DEV)))
     t_naive = timed([host] * n)                                           # the reference's way, for the record
-    print(f"resident {1e3 * t_res:.2f} ms/step, prefetched from pageable host memory {1e3 * t_feed:.2f}, "
-          f"`.to(device)` per step {1e3 * t_naive:.2f}")
-    assert t_feed <= 1.02 * t_res, (t_feed, t_res)
+    t_res.append(timed([resident] * n))
+    res, feed = sum(t_res) / len(t_res), sum(t_feed) / len(t_feed)
+    print(f"resident {1e3 * res:.2f} ms/step ({' '.join(f'{1e3 * t:.2f}' for t in t_res)}), prefetched from pageable host "
+          f"memory {1e3 * feed:.2f} ({' '.join(f'{1e3 * t:.2f}' for t in t_feed)}), `.to(device)` per step {1e3 * t_naive:.2f}")
+    assert feed <= 1.01 * res, (feed, res)

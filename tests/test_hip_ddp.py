@@ -139,3 +139,68 @@ def test_trainer_one_rank_rccl_collectives_forced():
     for key in logs2:
         a, b = torch.tensor(logs1[key]), torch.tensor(logs2[key])
         assert torch.allclose(a, b, rtol=2e-3, atol=1e-4), (key, logs1[key], logs2[key])
+
+
+def _rccl_two_rank_worker(rank, world, port, out, exchange):
+    """TWO ranks on two GPUs over RCCL: the launch the 8-GPU benchmark makes, at test size."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MSG_DDP_EXCHANGE=exchange)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import copy
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd import dist as msg_dist
+    from ddp_probe import StepProbe
+    from tools.gen_golden import TINY_D, TINY_G
+    _, _, local_rank = msg_dist.init_from_env()
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    dev = f"cuda:{local_rank}"
+    torch.manual_seed(10 + rank)                                   # different init per rank: the broadcast must fix it
+    g0, d0 = m.MultiStyleGANGenerator(TINY_G), m.MultiStyleGANDiscriminator(TINY_D, no_rfp=True)
+    finals = []
+    for overlap in (True, False):
+        g, d = copy.deepcopy(g0), copy.deepcopy(d0)
+        tr = m.ModelWrapper(g, d, device=dev, bucket_bytes=1 << 15, overlap_communication=overlap)
+        assert tr.generator_reducer.active and tr.generator_reducer.exchange == exchange
+        probe = StepProbe(tr)
+        tr.iteration = 14
+        torch.manual_seed(1000 + rank)
+        import random
+        import numpy
+        random.seed(1000 + rank); numpy.random.seed(1000 + rank)
+        for it in range(3):                                        # 15 (plans are learned), 16 (R1 + path length), 17 (plans used)
+            tr.step_trace.clear(); probe.local.clear()
+            tr.train_iteration(torch.rand(2, 2, 3, 32, 32, device=dev))
+            assert probe.check(world) == (["d", "g", "pl", "r1"] if it == 1 else ["d", "g"])
+        logs = tr.pop_logs()
+        assert all(all(v == v for v in vals) for vals in logs.values()), "NaN in losses"
+        flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), "replicas diverged"
+        finals.append(flat.cpu())
+    # overlapping the exchange with backward changes WHEN buckets travel, not what arrives
+    assert torch.equal(finals[0], finals[1]), "overlap on / off disagree"
+    if rank == 0:
+        out.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["all_reduce", "reduce_scatter"])
+def test_trainer_two_ranks_two_gpus_rccl(exchange):
+    """Runs wherever two GPUs are visible (the driver's 8-GPU node; skipped on the 1-GPU test boxes): two RCCL ranks, every
+    optimiser step == the step of the mean of the shards' gradients (tests/ddp_probe.py), replicas bit-identical, and the
+    overlapped exchange equal to the exchange after backward -- so that the first multi-rank RCCL launch is not the benchmark."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 200 + (11 if exchange == "reduce_scatter" else 0)
+    procs = [ctx.Process(target=_rccl_two_rank_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(600) for p in procs]
+    hung = [p for p in procs if p.exitcode is None]
+    [p.kill() for p in hung]
+    assert not hung and all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == "ok"

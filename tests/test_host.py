@@ -108,6 +108,72 @@ def _reducer_worker(rank, world, port, out):
     for i, p in enumerate(params):
         assert torch.allclose(p.grad, sum(g[i] for g in gathered) / world, atol=1e-6), (rank, "order", i)
     assert model.unused.grad is None
+    # ---- labelled backwards: a bucket that a kind of backward never fills must not stall the buckets behind it
+    red2 = GradBucketReducer(params + [model.unused], bucket_bytes=16, overlap=True)      # one parameter per bucket,
+    cold = next(k for k, b in enumerate(red2.buckets) if b.params[0] is model.unused)     # the never-filled one FIRST
+    assert cold == 0 and all(len(b.params) == 1 for b in red2.buckets) and len(red2.buckets) == len(params) + 1
+    for attempt in range(3):
+        local = [t.clone() for t in torch.autograd.grad(model(x).square().sum(), params)]
+        red2.zero_grad(); red2.arm("fwd")
+        model(x).square().sum().backward()
+        launched = [b.work is not None for b in red2.buckets]          # before finish(): what the hooks managed to send
+        if attempt == 0:
+            # first time nothing is known: launches are strictly in order and every bucket waits behind the cold one
+            assert not any(launched), launched
+        else:
+            assert not launched[cold] and all(launched[1:]), (attempt, launched)
+        red2.finish()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        for i, p in enumerate(params):
+            assert torch.allclose(p.grad, sum(g[i] for g in gathered) / world, atol=1e-6), (rank, "labelled", attempt, i)
+        assert float(model.unused.grad.abs().max()) == 0.0             # exchanged (last), still zero
+    # a cold bucket that does receive a gradient after all is simply exchanged last, with that gradient
+    red2.zero_grad(); red2.arm("fwd")
+    (model(x).square().sum() + (1.0 + rank) * model.unused.sum()).backward()
+    red2.finish()
+    assert torch.allclose(model.unused.grad, torch.full((4,), 1.5))
+    # ... but a gradient that arrives for a bucket ALREADY on the wire is refused loudly, never silently dropped
+    red4 = GradBucketReducer(params + [model.unused], bucket_bytes=64, overlap=True)
+    mixed = next(b for b in red4.buckets if any(q is model.unused for q in b.params))
+    assert len(mixed.params) > 1
+    for _ in range(2):
+        red4.zero_grad(); red4.arm("fwd")
+        model(x).square().sum().backward()
+        red4.finish()
+    red4.zero_grad(); red4.arm("fwd")
+    try:
+        (model(x).square().sum() + model.unused.sum()).backward()
+        raised = False
+    except RuntimeError as exc:
+        raised = "use distinct labels" in str(exc)
+    red4.finish()
+    assert raised
+    for p in params:                                                    # hand the gradients back to the first reducer
+        p.grad = None
+    model.unused.grad = None
+    # ---- reduce_scatter exchange: same means, same clip norm as the all-reduce exchange
+    red3 = GradBucketReducer(params, bucket_bytes=64, overlap=True, exchange="reduce_scatter")
+    local = [t.clone() for t in torch.autograd.grad(model(x).square().sum(), params)]
+    red3.zero_grad(); red3.arm("fwd")
+    model(x).square().sum().backward()
+    red3.finish()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    means = [sum(g[i] for g in gathered) / world for i in range(len(params))]
+    for i, p in enumerate(params):
+        assert torch.allclose(p.grad, means[i], atol=1e-6), (rank, "reduce_scatter", i)
+    want_norm = torch.sqrt(sum(m.square().sum() for m in means))
+    assert torch.allclose(red3.grad_norm(), want_norm, rtol=1e-5), (red3.grad_norm(), want_norm)
+    red3.clip_(0.5)
+    assert torch.sqrt(sum(p.grad.square().sum() for p in params)) <= 0.5 + 1e-4
+    # ... and the SUM form the fused optimiser path uses: finish(average=False) leaves sums, the norm is the sum's
+    red3.zero_grad(); red3.arm("fwd")
+    model(x).square().sum().backward()
+    inv = red3.finish(average=False)
+    assert inv == 1.0 / world and torch.allclose(red3.grad_norm() * inv, want_norm, rtol=1e-5)
+    for i, p in enumerate(params):
+        assert torch.allclose(p.grad * inv, means[i], atol=1e-6)
     if rank == 0:
         out.put("ok")
     dist.destroy_process_group()

@@ -320,10 +320,12 @@ def main():
         from multi_stylegan_amd.data import DevicePrefetcher
         host_batch = real.cpu()
         n_h2d = 8
-        trainer.iteration = 4 * hp_lazy                        # the next n_h2d (< 16) iterations are plain ones
-        barrier()
-        t1 = time.perf_counter()
-        for batch in DevicePrefetcher([host_batch] * n_h2d, dev):
+        trainer.iteration = 4 * hp_lazy                        # the next n_h2d + 2 (< 16) iterations are plain ones
+        t1 = None
+        for k, batch in enumerate(DevicePrefetcher([host_batch] * (n_h2d + 2), dev)):
+            if k == 2:                                         # (the feed's start-up -- its thread, the first page-locked
+                barrier()                                      #  staging buffers -- happens once per epoch, not per step)
+                t1 = time.perf_counter()
             trainer.train_iteration(batch)
         barrier()
         h2d_ms = 1e3 * (time.perf_counter() - t1) / n_h2d

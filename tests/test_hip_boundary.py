@@ -99,7 +99,8 @@ def test_fused_bias_act_stub_module(golden, stubs, case, dtype):
     gy = z[case + ".gy"].to(DEV, dtype)
     ref_out = out if dtype == torch.float64 else z[case + ".y"].to(DEV, dtype)
     gx = act_mod.fused_bias_act(gy, empty, ref_out, 3, 1, 0.2, scale)
-    mask = lambda: torch.where(f64(ref_out) > 0, 1.0, a32) * s32
+    one, slope = torch.tensor(1.0, dtype=torch.float64), torch.tensor(a32, dtype=torch.float64)
+    mask = lambda: torch.where(f64(ref_out) > 0, one, slope) * s32
     assert rel_err(gx, _want(z, case + ".gx", dtype, lambda: f64(gy) * mask())) < tol
     dims = [0] + list(range(2, gx.ndim))
     want_gb = _want(z, case + ".gb", dtype, lambda: (f64(gy) * mask()).sum(dims))

@@ -98,24 +98,28 @@ def test_pageable_host_feed_does_not_slow_the_step():
     tr.generator_ema.compute_dtype = torch.bfloat16
     host = torch.rand(16, 2, 3, 256, 256)                                 # pageable
     resident = host.to(DEV)
-    n = 12
+    n = 10
 
     def timed(feed):
-        tr.iteration = 16                                                 # 17 .. 28: plain iterations only
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for batch in feed:
+        """ms per iteration over the last n batches of the feed; the first two are its start-up (the prefetcher's thread, the
+        first page-locked staging buffers: tens of milliseconds once per epoch, not per step)."""
+        tr.iteration = 16                                                 # 17 .. : plain iterations only
+        t0 = None
+        for k, batch in enumerate(feed):
+            if k == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
             tr.train_iteration(batch)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
-    timed([resident] * 3)                                                 # warm-up
+    timed([resident] * 4)                                                 # warm-up
     # A / B / A / B: the chip's clock drifts by a per cent or two as it heats up over a few seconds, so the two feeds alternate
     t_res, t_feed = [], []
     for _ in range(3):
-        t_res.append(timed([resident] * n))
-        t_feed.append(timed(DevicePrefetcher([host] * n, DEV)))
-    t_naive = timed([host] * n)                                           # the reference's way, for the record
-    t_res.append(timed([resident] * n))
+        t_res.append(timed([resident] * (n + 2)))
+        t_feed.append(timed(DevicePrefetcher([host] * (n + 2), DEV)))
+    t_naive = timed([host] * (n + 2))                                           # the reference's way, for the record
+    t_res.append(timed([resident] * (n + 2)))
     res, feed = sum(t_res) / len(t_res), sum(t_feed) / len(t_feed)
     print(f"resident {1e3 * res:.2f} ms/step ({' '.join(f'{1e3 * t:.2f}' for t in t_res)}), prefetched from pageable host "
           f"memory {1e3 * feed:.2f} ({' '.join(f'{1e3 * t:.2f}' for t in t_feed)}), `.to(device)` per step {1e3 * t_naive:.2f}")

@@ -17,7 +17,8 @@ import multi_stylegan_amd as m
 from multi_stylegan_amd.config import generator_config_for_resolution
 
 OURS = ("conv_fprop", "conv_wgrad", "bias_act", "blur_sep", "upfirdn2d", "modulate", "scale_rows_cols", "relayout",
-        "linear_", "softmax_rows", "nl_attn", "mbstd", "affine_warp", "gather_taps", "scaled_add", "demod")
+        "linear_", "softmax_rows", "nl_attn", "mbstd", "affine_warp", "gather_taps", "scaled_add", "demod", "wgrad_reduce",
+        "flat_adam", "flat_ema", "modconv_")
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)

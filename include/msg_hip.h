@@ -189,6 +189,19 @@ int msg_modulate_weights(const float* base, const float* wsq, const float* style
 int msg_modulate_backward(const float* gwk, const float* W, const float* s, const float* d, float* gW,
                           float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
                           float scale, void* stream);
+/* Second order of the same (the path-length regulariser differentiates the style gradient of the first backward once more,
+ * multi_stylegan_generator.py:193-200 through :384-388): for a cotangent v [B][I] of the style gradient gs,
+ *   msg_scale_rows_cols2:   out[b][r][t][c] = gain * base[r][t][c] * (row1[b][r]*col1[b][c] + row2[b][r]*col2[b][c]) -- with
+ *                           (row1,col1,row2,col2) = (d, v, dd, s), dd[b][o] = -scale^2 d^3 sum_i s v wsq[o][i], the derivative of
+ *                           the per-sample weight set along v (= dL2/d gwk), in the contraction kernels' layouts;
+ *   msg_modulate_backward2: dL2/dW -> gW [O][I][taps] and dL2/ds -> gs_part [ceil(O/o_group)][B][I] at fixed gwk, L2 = <v, gs>
+ *                           (both overwritten; d = NULL: no demodulation).  Limits: I % 4 == 0, I <= 512, taps in {1,4,9},
+ *                           B <= 16, 16-byte aligned operands (else MSG_EUNSUPPORTED).                                        */
+int msg_scale_rows_cols2(const float* base, const float* row1, const float* col1, const float* row2, const float* col2,
+                         void* out, int dtype, int B, int R, int T, int C, int Ck, float gain, void* stream);
+int msg_modulate_backward2(const float* gwk, const float* W, const float* s, const float* d, const float* v,
+                           float* gW, float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
+                           float scale, void* stream);
 
 /* Every K-contiguous image the contraction / modulation kernels read from ONE parameter, in one pass (all outputs
  * optional): w [O][I][T] fp32 as the reference stores it (equalized_layer.py, multi_stylegan_generator.py:330);

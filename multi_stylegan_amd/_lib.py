@@ -42,6 +42,8 @@ _SIGNATURES = {
     "msg_scale_rows_cols": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "msg_modulate_weights": (_I, [_P] * 5 + [_I] * 7 + [_F, _F, _P]),
     "msg_modulate_backward": (_I, [_P] * 6 + [_I] * 6 + [_F, _P]),
+    "msg_modulate_backward2": (_I, [_P] * 7 + [_I] * 6 + [_F, _P]),
+    "msg_scale_rows_cols2": (_I, [_P] * 6 + [_I] * 6 + [_F, _P]),
     "msg_relayout_weight": (_I, [_P, _P, _P, _P, _I] + [_I] * 7 + [_F, _P]),
     "msg_gather_taps": (_I, [_P, _P, _I] + [_I] * 9 + [_P]),
     "msg_scaled_add": (_I, [_P, _P, _P, _I, _L, _F, _F, _P]),

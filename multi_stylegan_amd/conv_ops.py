@@ -1139,7 +1139,73 @@ def _scale_rows_cols(base, rowscale, colscale, out, gain):
 _MODCONV_BWD_BATCH = 16
 
 
-def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need):
+def _dgrad_image_base(weight, w3, upsample, kind):
+    """fp32 base of the data-gradient weight image, [I][taps (flipped for convs)][O]."""
+    img = _param_images(weight, torch.float32, 1.0, kind, modulation=True)
+    return img["d"][0] if img is not None else _cached(weight, "md" + kind, torch.float32, 1.0, lambda: (
+        (w3 if upsample else w3.flip(-1)).permute(1, 2, 0).contiguous(), 0))[0]
+
+
+def _fwd_image_base(weight, w3, upsample, kind):
+    """fp32 base of the forward weight image: conv -> [O][taps][I]; up2 -> rows n = q*O + o, one tap."""
+    o, i, t = w3.shape
+    img = _param_images(weight, torch.float32, 1.0, kind, modulation=True)
+    return img["f"][0] if img is not None else _cached(weight, "mb" + kind, torch.float32, 1.0, lambda: (
+        (w3.permute(2, 0, 1).reshape(t * o, 1, i) if upsample else w3.transpose(1, 2)).contiguous(), 0))[0]
+
+
+def _tap_square_sums(weight, w3, kind):
+    """wsq[o][i] = sum over taps of W^2 (cached with the weight)."""
+    img = _param_images(weight, torch.float32, 1.0, kind, modulation=True)
+    return img["wsq"] if img is not None else \
+        _cached(weight, "wsq", torch.float32, 1.0, lambda: (w3.square().sum(dim=2).contiguous(), 0))[0]
+
+
+def _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g):
+    """Data-gradient contraction of the modulated conv with a per-sample data-gradient weight image."""
+    if upsample:
+        return _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o)
+    return _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o)
+
+
+def _fprop_modconv(x, wk, ck, o, i, kh, kw, upsample, g):
+    """Forward contraction of the modulated conv with a per-sample forward weight image."""
+    if upsample:
+        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
+    return _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i)
+
+
+def _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g):
+    """Per-sample weight gradient in the kernel layout [B][O][taps][ldg] -> (gwk, ldg)."""
+    if upsample:
+        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True)
+    return _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
+
+
+def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=None):
+    """Per-sample weight gradients -> (dL/dW [1,O,I,kh*kw flat], dL/ds) through msg_modulate_backward; with `cotangent` (v,
+    the cotangent of a FIRST backward's style gradient) the second-order terms of msg_modulate_backward2 instead."""
+    b = gwk.shape[0]
+    o, i, t = w3.shape
+    dev = gwk.device
+    og = 1 if o >= 256 else 2                      # >= 256 workgroups for the 512-channel layers
+    groups = (o + og - 1) // og
+    gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
+    gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        if cotangent is None:
+            code = _lib.lib().msg_modulate_backward(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
+                                                    gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t, ldg, og,
+                                                    scale, _lib.stream_of(dev))
+        else:
+            code = _lib.lib().msg_modulate_backward2(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
+                                                     cotangent.data_ptr(), gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t,
+                                                     ldg, og, scale, _lib.stream_of(dev))
+    _lib.check(code, "msg_modulate_backward" + ("2" if cotangent is not None else ""))
+    return gw3, gs_part.sum(dim=0).to(style_dtype)
+
+
+def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, keep_gwk=False):
     """First-order backward of the modulated convolution for at most 16 samples: data gradient with re-laid per-sample
     weights, per-sample weight gradient, and the kernel that folds it into dL/dW and dL/ds (see _ModulatedConv)."""
     _, o, i, kh, kw = weight.shape
@@ -1152,33 +1218,126 @@ def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, n
     gx = None
     if need[0]:
         okp = _round_up(o, 128 // esz)
-        img = _param_images(weight, torch.float32, 1.0, g.kind, modulation=True)
-        base = img["d"][0] if img is not None else _cached(weight, "md" + g.kind, torch.float32, 1.0, lambda: (
-            (w3 if upsample else w3.flip(-1)).permute(1, 2, 0).contiguous(), 0))[0]       # [I][taps'][O]
         wd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
-        _scale_rows_cols(base, s, dd, wd, scale)
-        if upsample:
-            gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o)
-        else:
-            gx = _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o)
-    gw = gs = None
+        _scale_rows_cols(_dgrad_image_base(weight, w3, upsample, g.kind), s, dd, wd, scale)
+        gx = _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g)
+    gw = gs = gwk = None
     if need[1] or need[2]:
-        if upsample:
-            gwk, ldg = _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True)
-        else:
-            gwk, ldg = _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
-        og = 1 if o >= 256 else 2                      # >= 256 workgroups for the 512-channel layers
-        groups = (o + og - 1) // og
-        gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
-        gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
-        with _lib.on_device(dev):
-            code = _lib.lib().msg_modulate_backward(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
-                                                    gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t, ldg, og,
-                                                    scale, _lib.stream_of(dev))
-        _lib.check(code, "msg_modulate_backward")
+        gwk, ldg = _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g)
+        gw3, gs = _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style.dtype)
         gw = gw3.reshape(1, o, i, kh, kw)
-        gs = gs_part.sum(dim=0).to(style.dtype)
-    return gx, gw, gs
+    return (gx, gw, gs, gwk) if keep_gwk else (gx, gw, gs)
+
+
+_NATIVE_SECOND_ORDER = bool(int(os.environ.get("MSG_MODCONV_NATIVE2", "1")))   # 0: the composite torch-op graph (A/B, tests)
+
+
+def _modconv_second_order_composite(gy, x, weight, style, demodulate, upsample, a, cot_w, cot_s, want):
+    """Gradients of L2 = <a, gx> + <cot_w, gW> + <cot_s, gs> with respect to (gy, x, weight, style), where (gx, gW, gs) is the
+    first backward of the modulated conv: the general fallback, by differentiating the composite torch-op formulation twice."""
+    with torch.enable_grad():
+        leaves = [t.detach().requires_grad_(True) for t in (gy, x, weight, style)]
+        y2 = _modulated_composite(leaves[1], leaves[2], leaves[3], demodulate, upsample)
+        first = torch.autograd.grad(y2, leaves[1:], leaves[0], create_graph=True, allow_unused=True)
+        terms = [(c.to(f.dtype) * f).sum() for c, f in zip((a, cot_w, cot_s), first) if c is not None and f is not None]
+        if not terms:
+            return (None, None, None, None)
+        grads = torch.autograd.grad(sum(terms), leaves, allow_unused=True)
+    return tuple(gr if w else None for gr, w in zip(grads, want))
+
+
+class _ModConvGrad(Function):
+    """The FIRST backward of the modulated convolution as a differentiable op, (gy, x, W, s) -> (gx, gW, gs), so that the
+    second-order pass of the path-length regulariser (multi_stylegan_generator.py:193-200 through :384-411) runs on the
+    same native pieces as the first-order step instead of a composite graph of torch elementwise ops over [B,O,I,kh,kw]
+    tensors (16 GB of elementwise traffic and one recomputed forward contraction per regularised iteration):
+
+        d<a,gx>/d(gy, W, s):  F(a, w),  MB(G(gy, a))                     w = per-sample weights, MB = msg_modulate_backward
+        d<v,gs>/d(gy, x):     F(x, dw), D(gy, dw)                        dw = derivative of w along v (msg_scale_rows_cols2)
+        d<v,gs>/d(W, s):      msg_modulate_backward2 on the saved per-sample weight gradient
+
+    A cotangent for gW (nothing in the training step produces one), more than 16 samples or shapes outside the fold kernels'
+    limits take the composite fallback."""
+
+    @staticmethod
+    def forward(ctx, gy, x, weight, style, d, demodulate, upsample, g, scale, need):
+        gx, gw, gs, gwk = _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, keep_gwk=True)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(gy, x, weight, style, d, gwk)
+        ctx.cfg = (demodulate, upsample, g, scale)
+        return gx, gw, gs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, a, cot_w, cot_s):
+        gy, x, weight, style, d, gwk = ctx.saved_tensors
+        demodulate, upsample, g, scale = ctx.cfg
+        want = ctx.needs_input_grad[:4]
+        _, o, i, kh, kw = weight.shape
+        b, t = x.shape[0], kh * kw
+        tail = (None,) * 6
+        if a is None and cot_w is None and cot_s is None:
+            return (None, None, None, None) + tail
+        if cot_w is not None or i % 4 or i > 512 or t not in (1, 4, 9) or b > _MODCONV_BWD_BATCH or \
+                (cot_s is not None and gwk is None):
+            return _modconv_second_order_composite(gy, x, weight, style, demodulate, upsample, a, cot_w, cot_s, want) + tail
+        dev = x.device
+        w3 = weight.detach().reshape(o, i, t)
+        s = style.detach().float().contiguous()
+        dd = d if demodulate else None
+        esz = 2 if gy.dtype == torch.bfloat16 else 4
+        ck, okp = _round_up(i, 128 // esz), _round_up(o, 128 // esz)
+        rows = t * o if upsample else o
+        ggy = gx2 = gw3 = gs2 = None
+        if a is not None:
+            a = a.to(x.dtype)
+            if want[0]:                                   # <a, D(gy, w)> is F(a, w) paired with gy
+                wk = torch.empty((b, rows, 1 if upsample else t, ck), dtype=x.dtype, device=dev)
+                base = _fwd_image_base(weight, w3, upsample, g.kind)
+                if demodulate:
+                    _scale_rows_cols(base, d.repeat(1, t) if upsample else d, s, wk, scale)
+                else:
+                    _scale_rows_cols(base, None, s, wk, scale)
+                ggy = _fprop_modconv(a, wk, ck, o, i, kh, kw, upsample, g)
+            if want[2] or want[3]:                        # ... and G(gy, a) paired with w -> (W, s) through the fold
+                gwk_a, ldg = _wgrad_modconv(gy, a, o, i, kh, kw, upsample, g)
+                gw3, gs2 = _fold_weight_gradient(gwk_a, ldg, w3, s, dd, scale, style.dtype)
+        if cot_s is not None:
+            v = cot_s.detach().float().contiguous()
+            if want[0] or want[1]:
+                # dw = derivative of the weight set along v, in both kernel layouts
+                hf = torch.empty((b, rows, 1 if upsample else t, ck), dtype=x.dtype, device=dev)
+                hd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
+                base_f = _fwd_image_base(weight, w3, upsample, g.kind)
+                base_d = _dgrad_image_base(weight, w3, upsample, g.kind)
+                if demodulate:
+                    wsq = _tap_square_sums(weight, w3, g.kind)
+                    ddir = -(scale * scale) * d.pow(3) * linear(s * v, wsq)          # [B, O]
+                    rows_d, rows_dd = (d.repeat(1, t), ddir.repeat(1, t)) if upsample else (d, ddir)
+                    with _lib.on_device(dev):
+                        lib, st = _lib.lib(), _lib.stream_of(dev)
+                        code = lib.msg_scale_rows_cols2(base_f.data_ptr(), rows_d.contiguous().data_ptr(), v.data_ptr(),
+                                                        rows_dd.contiguous().data_ptr(), s.data_ptr(), hf.data_ptr(),
+                                                        _lib.dtype_code(hf), b, rows, 1 if upsample else t, i, ck, scale, st)
+                        _lib.check(code, "msg_scale_rows_cols2")
+                        code = lib.msg_scale_rows_cols2(base_d.data_ptr(), v.data_ptr(), d.data_ptr(), s.data_ptr(),
+                                                        ddir.contiguous().data_ptr(), hd.data_ptr(), _lib.dtype_code(hd), b, i, t,
+                                                        o, okp, scale, st)
+                        _lib.check(code, "msg_scale_rows_cols2")
+                else:
+                    _scale_rows_cols(base_f, None, v, hf, scale)
+                    _scale_rows_cols(base_d, v, None, hd, scale)
+                if want[0]:                               # <dw, G(gy, x)> is F(x, dw) paired with gy ...
+                    extra = _fprop_modconv(x, hf, ck, o, i, kh, kw, upsample, g)
+                    ggy = extra if ggy is None else ggy + extra
+                if want[1]:                               # ... and D(gy, dw) paired with x
+                    gx2 = _dgrad_modconv(gy, hd, okp, o, i, kh, kw, upsample, g)
+            if want[2] or want[3]:
+                gw3b, gs2b = _fold_weight_gradient(gwk, gwk.shape[-1], w3, s, dd, scale, style.dtype, cotangent=v)
+                gw3 = gw3b if gw3 is None else gw3 + gw3b
+                gs2 = gs2b if gs2 is None else gs2 + gs2b
+        gw = gw3.reshape(1, o, i, kh, kw) if (gw3 is not None and want[2]) else None
+        return (ggy, gx2, gw, gs2 if want[3] else None) + tail
 
 
 class _ModulatedConv(Function):
@@ -1257,6 +1416,11 @@ class _ModulatedConv(Function):
             gnw = gnw.reshape(nw_shape) if has_noise and need[7] else None
         tail = (None, None, gb, None, gnw, None, None, None)
         fused_ok = i <= 512 and t <= 9
+        if torch.is_grad_enabled() and fused_ok and _NATIVE_SECOND_ORDER and b <= _MODCONV_BWD_BATCH and x.is_cuda:
+            # create_graph=True (the path-length pass): the first backward as ONE differentiable node on the native kernels
+            gx, gw, gs = _ModConvGrad.apply(gy, x, weight, style, d if demodulate else None, demodulate, upsample, g, scale,
+                                            tuple(need[:3]))
+            return (gx, gw, gs) + tail
         if torch.is_grad_enabled() or not fused_ok:
             # higher-order request (create_graph=True): differentiate the composite formulation instead
             with torch.enable_grad():

@@ -147,6 +147,87 @@ extern "C" int msg_scale_rows_cols(const float* base, const float* rowscale, con
     return MSG_CHECK_LAUNCH();
 }
 
+// out[b][r][t][c] = gain * base[r][t][c] * (row1[b][r] * col1[b][c] + row2[b][r] * col2[b][c]),  c >= C -> 0.
+// The directional derivative of the per-sample weight set w = scale * d * W * s along a style direction v:
+//   dw = scale * W * (d (x) v + dd (x) s),   dd[b][o] = -scale^2 d^3 sum_i s v wsq[o][i]
+// (row1 = d, col1 = v, row2 = dd, col2 = s for the forward image; rows and columns swapped for the data-gradient image)
+// written straight in the contraction kernels' layouts -- the weights of the second-order contractions F(x, dw), D(gy, dw)
+// of the path-length pass.  Same tiling as scale_rows_cols_kernel.
+template <typename TO>
+__global__ __launch_bounds__(256) void scale_rows_cols2_kernel(const float* __restrict__ base,
+                                                               const float* __restrict__ row1, const float* __restrict__ col1,
+                                                               const float* __restrict__ row2, const float* __restrict__ col2,
+                                                               TO* __restrict__ out, int B, int BG, int R, int T, int C, int Ck,
+                                                               float gain) {
+    using V = Vec16<TO>;
+    constexpr int VEC = V::N;
+    const int r = blockIdx.x, b0 = blockIdx.y * BG, b1 = min(B, b0 + BG);
+    const int cvecs = Ck / VEC;
+    const float* src_row = base + (size_t)r * T * C;
+    const int tstep = 256 / cvecs > 0 ? 256 / cvecs : 1;
+    const bool al = (C % 4 == 0) && ((((uintptr_t)base | (uintptr_t)col1 | (uintptr_t)col2) & 15u) == 0);
+    for (int cv = threadIdx.x % cvecs; cv < cvecs; cv += 256) {
+        const int c0 = cv * VEC;
+        const int t0 = threadIdx.x / cvecs;
+        for (int tb = t0; tb < T; tb += tstep * SRC_ITEMS) {
+            float f[SRC_ITEMS][VEC];
+#pragma unroll
+            for (int k = 0; k < SRC_ITEMS; ++k) {
+                const int t = tb + k * tstep;
+                if (t < T) load_run<VEC>(src_row + (size_t)t * C, c0, C, al, f[k]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[k][e] = 0.f;
+                }
+            }
+            for (int b = b0; b < b1; ++b) {
+                const float rs1 = gain * row1[(size_t)b * R + r], rs2 = gain * row2[(size_t)b * R + r];
+                float sc[VEC], s2[VEC];
+                load_run<VEC>(col1 + (size_t)b * C, c0, C, al, sc);
+                load_run<VEC>(col2 + (size_t)b * C, c0, C, al, s2);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sc[e] = fmaf(rs1, sc[e], rs2 * s2[e]);
+                TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
+#pragma unroll
+                for (int k = 0; k < SRC_ITEMS; ++k) {
+                    const int t = tb + k * tstep;
+                    if (t >= T) break;
+                    V o;
+                    if constexpr (VEC == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.set(e, f[k][e] * sc[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.set2(e, f[k][2 * e] * sc[2 * e], f[k][2 * e + 1] * sc[2 * e + 1]);
+                    }
+                    *reinterpret_cast<uint4*>(dst_row + (size_t)t * Ck + c0) = o.raw;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int msg_scale_rows_cols2(const float* base, const float* row1, const float* col1, const float* row2,
+                                    const float* col2, void* out, int dtype, int B, int R, int T, int C, int Ck, float gain,
+                                    void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!base || !row1 || !col1 || !row2 || !col2 || !out || B < 0 || R <= 0 || T <= 0 || C <= 0 || Ck < C) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (Ck % vec || (((uintptr_t)out) & 15u)) return MSG_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    int bg = 1;
+    while (bg < 8 && bg * 2 <= B && (long long)R * ((B + 2 * bg - 1) / (2 * bg)) >= 2048) bg *= 2;
+    dim3 grid(R, (B + bg - 1) / bg);
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((scale_rows_cols2_kernel<bf16_t>), grid, dim3(256), 0, s, base, row1, col1, row2, col2,
+                           (bf16_t*)out, B, bg, R, T, C, Ck, gain);
+    else
+        hipLaunchKernelGGL((scale_rows_cols2_kernel<float>), grid, dim3(256), 0, s, base, row1, col1, row2, col2,
+                           (float*)out, B, bg, R, T, C, Ck, gain);
+    return MSG_CHECK_LAUNCH();
+}
+
 // Forward weight set of the modulated conv in ONE launch: demodulation coefficient + per-sample weights.
 //   d[b][o]        = rsqrt(scale^2 * sum_i s[b][i]^2 * wsq[o][i] + eps)        (wsq[o][i] = sum_t W[o][i][t]^2, cached)
 //   out[b][r][t][c] = scale * d[b][r % O] * base[r][t][c] * s[b][c]
@@ -480,6 +561,205 @@ __global__ __launch_bounds__(256) void modulate_backward_v4_kernel(const float* 
                 f32x4{scale * gs_acc[q][0], scale * gs_acc[q][1], scale * gs_acc[q][2], scale * gs_acc[q][3]};
         }
     }
+}
+
+// Second-order fold of the modulated convolution (path-length regularisation differentiates the style gradient gs of the
+// first backward once more).  With w = c d W s (c = scale, d = (c^2 A + eps)^-1/2, A = sum W^2 s^2) the first backward is
+//   (gW, gs) = MB(g; W, s),  g = per-sample weight gradient;     for a cotangent v of gs,  L2 = <v, gs> reads
+//   L2 = sum_{b,o} [ c d R1 - 1/2 c^3 d^3 dA P ],   Q[b,o,i] = sum_t g W,  R1 = sum_i v Q,  P = sum_i s Q,
+//                                                 dA = 2 sum_i s v wsq[o,i]              (wsq = sum_t W^2)
+// and this kernel returns its derivatives with respect to W and s at fixed g (the derivative with respect to g is the
+// weight set msg_scale_rows_cols2 writes):
+//   dL2/dW[o,i,t] = sum_b { g (c d v - 1/2 c^3 d^3 dA s) + W (-c^3 d^3 R1 s^2 - 2 c^3 d^3 P s v + 3/2 c^5 d^5 dA P s^2) }
+//   dL2/ds[b,i]   = sum_o { wsq (-c^3 d^3 R1 s + 3/2 c^5 d^5 dA P s - c^3 d^3 P v) - 1/2 c^3 d^3 dA Q }
+// Without demodulation d = 1 and every d-derivative vanishes: dL2/dW = c sum_b g v, dL2/ds = 0.
+// Same organisation as modulate_backward_v4_kernel (a thread owns four input channels, the halves of the workgroup take the
+// even / odd samples, g is read once); dA needs no g and is reduced first, P and R1 together behind the loads.
+template <bool DEMOD, int T>
+__global__ __launch_bounds__(256) void modulate_backward2_v4_kernel(const float* __restrict__ gwk, const float* __restrict__ W,
+                                                                    const float* __restrict__ s, const float* __restrict__ d,
+                                                                    const float* __restrict__ v, float* __restrict__ gW,
+                                                                    float* __restrict__ gs_part, int B, int O, int I, int ldg,
+                                                                    int OG, float scale) {
+    constexpr int NB = MB_BMAX / 4;                   // samples per half (B <= 16)
+    __shared__ float red[3][4][NB];
+    __shared__ float tot[3][2][NB];                   // [dA, P, R1][half][sample]
+    __shared__ __attribute__((aligned(16))) float xch[128][4 * T + 4];
+    const int og = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = tid >> 7, i = (tid & 127) * 4;
+    const bool live = i < I;
+    const float c1 = scale, c3 = scale * scale * scale, c5 = c3 * scale * scale;
+    float gs_acc[NB][4];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gs_acc[q][e] = 0.f;
+
+    for (int oo = 0; oo < OG; ++oo) {
+        const int o = og * OG + oo;
+        if (o >= O) break;
+        float wv[4][T], gl[4][T], p1[NB][4], w2[4], c2[4];
+        {
+            float flat[4 * T];
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const f32x4 t4 = live ? *reinterpret_cast<const f32x4*>(W + ((size_t)o * I + i) * T + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) flat[4 * j + e] = t4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w2[e] = 0.f; c2[e] = 0.f;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    wv[e][t] = flat[e * T + t];
+                    gl[e][t] = 0.f;
+                    w2[e] = fmaf(wv[e][t], wv[e][t], w2[e]);
+                }
+            }
+        }
+        // ---- dA[b] = 2 sum_i s v wsq  (no g involved)
+        if (DEMOD) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int b = 2 * q + half;
+                float part = 0.f;
+                if (b < B && live) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(s + (size_t)b * I + i);
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (size_t)b * I + i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part = fmaf(sv[e] * vv[e], w2[e], part);
+                }
+                part = wave_sum(part);
+                if (lane == 0) red[0][wid][q] = part;
+            }
+            __syncthreads();
+            if (tid < 2 * NB) tot[0][tid / NB][tid % NB] = 2.f * (red[0][2 * (tid / NB)][tid % NB] + red[0][2 * (tid / NB) + 1][tid % NB]);
+            __syncthreads();
+        }
+        // ---- one pass over g: Q, the partial sums of P and R1, and the g-term of dL2/dW
+        float partP[NB], partR[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int b = 2 * q + half;
+            partP[q] = 0.f; partR[q] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p1[q][e] = 0.f;
+            if (b >= B || !live) continue;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s + (size_t)b * I + i);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (size_t)b * I + i);
+            const float dv = DEMOD ? d[(size_t)b * O + o] : 1.f;
+            const float rho1 = c1 * dv;
+            const float rho2 = DEMOD ? -0.5f * c3 * dv * dv * dv * tot[0][half][q] : 0.f;
+            float coef[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) coef[e] = fmaf(rho1, vv[e], rho2 * sv[e]);
+            const float* g = gwk + (((size_t)b * O + o) * T) * ldg + i;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (size_t)t * ldg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p1[q][e] = fmaf(wv[e][t], gv[e], p1[q][e]);
+                    gl[e][t] = fmaf(coef[e], gv[e], gl[e][t]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                partP[q] = fmaf(sv[e], p1[q][e], partP[q]);
+                partR[q] = fmaf(vv[e], p1[q][e], partR[q]);
+            }
+        }
+        if (DEMOD) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const float a = wave_sum(partP[q]), r = wave_sum(partR[q]);
+                if (lane == 0) { red[1][wid][q] = a; red[2][wid][q] = r; }
+            }
+            __syncthreads();
+            if (tid < 2 * NB) {
+                tot[1][tid / NB][tid % NB] = red[1][2 * (tid / NB)][tid % NB] + red[1][2 * (tid / NB) + 1][tid % NB];
+                tot[2][tid / NB][tid % NB] = red[2][2 * (tid / NB)][tid % NB] + red[2][2 * (tid / NB) + 1][tid % NB];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int b = 2 * q + half;
+                if (b >= B || !live) continue;
+                const float dv = d[(size_t)b * O + o];
+                const float d3 = c3 * dv * dv * dv, d5 = c5 * dv * dv * dv * dv * dv;
+                const float dA = tot[0][half][q], P = tot[1][half][q], R1 = tot[2][half][q];
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(s + (size_t)b * I + i);
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (size_t)b * I + i);
+                const float ks = -d3 * R1 + 1.5f * d5 * dA * P;          // multiplies s (and s^2 in the W term)
+                const float kv = -d3 * P;                                // multiplies v
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gs_acc[q][e] += w2[e] * (ks * sv[e] + kv * vv[e]) - 0.5f * d3 * dA * p1[q][e];
+                    c2[e] += ks * sv[e] * sv[e] + 2.f * kv * sv[e] * vv[e];
+                }
+            }
+        }
+        // dL2/dW = gl + W * c2, both halves added
+        if (half == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < T; ++t) xch[tid & 127][e * T + t] = fmaf(wv[e][t], c2[e], gl[e][t]);
+        }
+        __syncthreads();
+        if (half == 0 && live) {
+            float outv[4 * T];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < T; ++t) outv[e * T + t] = fmaf(wv[e][t], c2[e], gl[e][t]) + xch[tid][e * T + t];
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                *reinterpret_cast<f32x4*>(gW + ((size_t)o * I + i) * T + 4 * j) =
+                    f32x4{outv[4 * j], outv[4 * j + 1], outv[4 * j + 2], outv[4 * j + 3]};
+        }
+        __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int b = 2 * q + half;
+            if (b >= B) continue;
+            *reinterpret_cast<f32x4*>(gs_part + ((size_t)og * B + b) * I + i) =
+                f32x4{gs_acc[q][0], gs_acc[q][1], gs_acc[q][2], gs_acc[q][3]};
+        }
+    }
+}
+
+// gwk [B][O][taps][ldg] (the first backward's per-sample weight gradient), v [B][I] (cotangent of the style gradient) ->
+// gW [O][I][taps], gs_part [ceil(O/o_group)][B][I] (both overwritten; the caller sums gs_part over its first axis).
+// Limits: I % 4 == 0, I <= 512, taps in {1, 4, 9}, B <= 16, 16-byte aligned operands (else MSG_EUNSUPPORTED: the caller
+// differentiates the composite formulation instead).
+extern "C" int msg_modulate_backward2(const float* gwk, const float* W, const float* s, const float* d, const float* v,
+                                      float* gW, float* gs_part, int B, int O, int I, int taps, int ldg, int o_group,
+                                      float scale, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!gwk || !W || !s || !v || !gW || !gs_part || B < 0 || O <= 0 || I <= 0 || taps <= 0 || ldg < I || o_group <= 0)
+        return MSG_EINVAL;
+    if (I > 512 || I % 4 || ldg % 4 || B > MB_BMAX / 2 ||
+        (((uintptr_t)gwk | (uintptr_t)W | (uintptr_t)s | (uintptr_t)v | (uintptr_t)gW | (uintptr_t)gs_part) & 15u))
+        return MSG_EUNSUPPORTED;
+    const int groups = (O + o_group - 1) / o_group;
+    hipStream_t st = (hipStream_t)stream;
+#define MB2(T_) do { if (d) hipLaunchKernelGGL((modulate_backward2_v4_kernel<true, T_>), dim3(groups), dim3(256), 0, st, gwk, W, s, d, v, \
+                                               gW, gs_part, B, O, I, ldg, o_group, scale); \
+                     else hipLaunchKernelGGL((modulate_backward2_v4_kernel<false, T_>), dim3(groups), dim3(256), 0, st, gwk, W, s, d, v, \
+                                             gW, gs_part, B, O, I, ldg, o_group, scale); } while (0)
+    switch (taps) {
+        case 1: MB2(1); break;
+        case 4: MB2(4); break;
+        case 9: MB2(9); break;
+        default: return MSG_EUNSUPPORTED;
+    }
+#undef MB2
+    return MSG_CHECK_LAUNCH();
 }
 
 template <bool DEMOD>

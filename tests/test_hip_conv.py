@@ -563,3 +563,70 @@ def test_equalized_transposed_conv_and_conv1d_golden(golden, dtype):
         assert rel_err(gw.float(), z[name + ".gw"]) < tol, name
     with pytest.raises(_lib.MsgHipError, match="only kernel_size 2"):
         E.EqualizedTransposedConv2d(6, 10, kernel_size=3, stride=2, padding=1).to(DEV)(torch.zeros(1, 6, 4, 4, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["conv3x3_demod", "up2x2_demod", "torgb1x1_nodemod", "conv3x3_nodemod"])
+def test_modulated_conv_second_order_native_matches_composite(kind, dtype):
+    """The path-length pattern -- a first backward under create_graph, then a scalar of its style AND input gradients
+    differentiated with respect to everything -- on the native second-order node (conv_ops._ModConvGrad: msg_scale_rows_cols2,
+    msg_modulate_backward2 and the contraction kernels) against the composite torch-op graph it replaces, and against an
+    fp64 evaluation of the reference's formulation (multi_stylegan_generator.py:384-411)."""
+    from multi_stylegan_amd import conv_ops
+    torch.manual_seed(hash(kind) % 1000)
+    b, i, o, h = 5, 72, (3 if "torgb" in kind else 40), 12
+    k = 3 if "3x3" in kind else (2 if "up2" in kind else 1)
+    demod, up = "nodemod" not in kind, "up2" in kind
+    x0 = torch.randn(b, i, h, h, device=DEV)
+    w0 = torch.randn(1, o, i, k, k, device=DEV)
+    s0 = torch.randn(b, i, device=DEV) * 0.5 + 1.0
+    oh = 2 * h if up else h
+    gy0 = torch.randn(b, o, oh, oh, device=DEV)
+    r_x = torch.randn(b, i, h, h, device=DEV)
+
+    def run(native, dt):
+        conv_ops._NATIVE_SECOND_ORDER = native
+        try:
+            x = conv_ops.to_compute_layout(x0.clone(), dt).requires_grad_(True)
+            w = torch.nn.Parameter(w0.clone())
+            s = s0.clone().requires_grad_(True)
+            gy = conv_ops.to_compute_layout(gy0.clone(), dt).requires_grad_(True)
+            y = conv_ops.modulated_conv2d(x, w, s, demod, up)
+            gx, gs = torch.autograd.grad(y, (x, s), gy, create_graph=True)
+            pen = gs.float().square().sum() + (gx.float() * r_x).sum()
+            return [t.float() for t in torch.autograd.grad(pen, (x, w, s, gy))] + [gs.detach().float(), gx.detach().float()]
+        finally:
+            conv_ops._NATIVE_SECOND_ORDER = True
+
+    def reference64():
+        x, w, s, gy = (t.double().cpu().requires_grad_(True) for t in (x0, w0, s0, gy0))
+        scale = math.sqrt(2.0) / math.sqrt(i * k * k)
+        wm = scale * w * s[:, None, :, None, None]
+        if demod:
+            wm = wm * torch.rsqrt(wm.pow(2).sum(dim=(2, 3, 4), keepdim=True) + 1e-8)
+        if up:
+            y = torch.nn.functional.conv_transpose2d(x.reshape(1, b * i, h, h), wm.transpose(1, 2).reshape(b * i, o, k, k),
+                                                     stride=2, groups=b).reshape(b, o, oh, oh)
+        else:
+            y = torch.nn.functional.conv2d(x.reshape(1, b * i, h, h), wm.reshape(b * o, i, k, k), padding=k // 2,
+                                           groups=b).reshape(b, o, oh, oh)
+        gx, gs = torch.autograd.grad(y, (x, s), gy, create_graph=True)
+        pen = gs.square().sum() + (gx * r_x.double().cpu()).sum()
+        return list(torch.autograd.grad(pen, (x, w, s, gy))) + [gs.detach(), gx.detach()]
+
+    calls = []
+    orig = conv_ops._ModConvGrad.backward
+    conv_ops._ModConvGrad.backward = staticmethod(lambda ctx, *g: (calls.append(1), orig(ctx, *g))[1])
+    try:
+        native = run(True, dtype)
+    finally:
+        conv_ops._ModConvGrad.backward = orig
+    assert calls, "the native second-order node did not run"
+    composite = run(False, dtype)
+    names = ("d/dx", "d/dW", "d/ds", "d/dgy", "gs", "gx")
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    for name, a, c in zip(names, native, composite):
+        assert rel_err(a, c) < tol, (name, rel_err(a, c))
+    if dtype == torch.float32:
+        for name, a, r in zip(names, native, reference64()):
+            assert rel_err(a, r) < 2e-4, (name, rel_err(a, r))

@@ -1168,11 +1168,14 @@ def _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g):
     return _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o)
 
 
-def _fprop_modconv(x, wk, ck, o, i, kh, kw, upsample, g):
-    """Forward contraction of the modulated conv with a per-sample forward weight image."""
+def _fprop_modconv(x, wk, ck, o, i, kh, kw, upsample, g, add_to=None):
+    """Forward contraction of the modulated conv with a per-sample forward weight image; `add_to`: a map shaped like the
+    result that is added to it (in the contraction's epilogue where the kernel has one: the plain stride-1 convs)."""
     if upsample:
-        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
-    return _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i)
+        y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
+        return y if add_to is None else y + add_to
+    return _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i,
+                         residual=None if add_to is None else (add_to, 1.0))
 
 
 def _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g):
@@ -1328,8 +1331,7 @@ class _ModConvGrad(Function):
                     _scale_rows_cols(base_f, None, v, hf, scale)
                     _scale_rows_cols(base_d, v, None, hd, scale)
                 if want[0]:                               # <dw, G(gy, x)> is F(x, dw) paired with gy ...
-                    extra = _fprop_modconv(x, hf, ck, o, i, kh, kw, upsample, g)
-                    ggy = extra if ggy is None else ggy + extra
+                    ggy = _fprop_modconv(x, hf, ck, o, i, kh, kw, upsample, g, add_to=ggy)
                 if want[1]:                               # ... and D(gy, dw) paired with x
                     gx2 = _dgrad_modconv(gy, hd, okp, o, i, kh, kw, upsample, g)
             if want[2] or want[3]:

@@ -45,23 +45,38 @@ def _tensors(batch, out=None):
     return out
 
 
+def _stage(pinned: torch.Tensor, src: torch.Tensor) -> None:
+    """pageable -> pinned on ONE core, without the GIL: numpy's copy loop.  (torch's CPU copy of a 25 MB tensor fans out over
+    the intra-op thread pool, whose workers then compete with the thread that is launching the step's kernels.)"""
+    try:
+        import numpy
+        numpy.copyto(pinned.numpy(), src.detach().contiguous().numpy())
+    except (TypeError, RuntimeError):                     # dtypes numpy does not know (bfloat16)
+        pinned.copy_(src)
+
+
 class _Slot:
     """One in-flight batch: pinned staging tensors, device tensors, `ready` (copy done) and `released` (compute stream is
     past the consumer's last use) events."""
 
     def __init__(self, device):
         self.device = device
-        self.host, self.dev = [], []
+        self.host, self.dev, self.out = [], [], []
         self.ready = torch.cuda.Event()
         self.released: Optional[torch.cuda.Event] = None
         self.batch: Any = None
+        self.keep: list = []                                # pinned source tensors of the copy in flight
 
-    def fit(self, tensors) -> None:
-        ok = len(tensors) == len(self.host) and all(h.shape == t.shape and h.dtype == t.dtype
-                                                    for h, t in zip(self.host, tensors))
+    def fit(self, tensors, wire) -> None:
+        """`wire[k]`: the dtype tensor k crosses the bus in (its own, or the prefetcher's transfer dtype)."""
+        ok = len(tensors) == len(self.host) and all(h.shape == t.shape and h.dtype == w and o.dtype == t.dtype
+                                                    for h, t, w, o in zip(self.host, tensors, wire, self.out))
         if not ok:                                          # first use, or a ragged last batch: (re)allocate this slot
-            self.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
-            self.dev = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in tensors]
+            self.host = [torch.empty(t.shape, dtype=w, pin_memory=True) for t, w in zip(tensors, wire)]
+            self.dev = [torch.empty(t.shape, dtype=w, device=self.device) for t, w in zip(tensors, wire)]
+            # what the consumer sees: the landed tensor itself, or its widening back to the batch's dtype
+            self.out = [d if w == t.dtype else torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                        for d, t, w in zip(self.dev, tensors, wire)]
 
 
 class DevicePrefetcher:
@@ -70,11 +85,19 @@ class DevicePrefetcher:
     buffer is then refilled, ordered behind everything the consumer has launched so far); clone it to keep it longer.
     Batches that already live on the device pass through."""
 
-    def __init__(self, loader: Iterable, device: Union[str, torch.device] = "cuda", depth: int = 2):
+    def __init__(self, loader: Iterable, device: Union[str, torch.device] = "cuda", depth: int = 2,
+                 transfer_dtype: Optional[torch.dtype] = None):
+        """``transfer_dtype``: floating-point host tensors cross the bus in this type and arrive as their original dtype
+        (e.g. ``torch.bfloat16`` when the models compute in bf16 storage: the discriminator's first layer rounds its input to
+        bf16 anyway, so training is bit-identical while the copy moves half the bytes).  Default: the batch's own dtype.
+        Measured on the MI355X boxes: a 25 MB fp32 batch per step costs ~1.0 ms of a 110 ms step (0.9 %) even though it is
+        copied a whole iteration ahead on its own stream (page-locked source or staged alike; the thread and queue cost
+        nothing) -- against 1.6-2.0 ms for `.to(device)` at the top of the step."""
         self.loader, self.device, self.depth = loader, torch.device(device), max(2, int(depth))
         if self.device.type != "cuda":
             raise ValueError("DevicePrefetcher stages batches for a GPU; iterate the loader directly on the CPU")
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.transfer_dtype = transfer_dtype
 
     def __len__(self) -> int:
         return len(self.loader)
@@ -105,21 +128,34 @@ class DevicePrefetcher:
                             slot = free.get(timeout=0.05)
                         except queue.Empty:
                             continue
-                    slot.fit(tensors)
+                    wire = [self.transfer_dtype if (self.transfer_dtype is not None and t.is_floating_point() and
+                                                    not t.is_cuda) else t.dtype for t in tensors]
+                    slot.fit(tensors, wire)
                     with torch.cuda.stream(self.copy_stream):
                         if slot.released is not None:                     # kernels that still read the device buffers
                             self.copy_stream.wait_event(slot.released)
-                        for h, d, t in zip(slot.host, slot.dev, tensors):
+                        slot.keep = []
+                        for h, d, t, o in zip(slot.host, slot.dev, tensors, slot.out):
                             if t.is_cuda:
+                                d.copy_(t, non_blocking=True)
+                            elif h.dtype != t.dtype:
+                                slot.ready.synchronize()
+                                h.copy_(t)                                # narrowing cast into the pinned buffer
+                                d.copy_(h, non_blocking=True)
+                                o.copy_(d)                                # widened back on the device (copy stream)
+                            elif t.is_pinned():
+                                # already page-locked (DataLoader(pin_memory=True), the reference's loader): no staging; the
+                                # source stays referenced until the slot is refilled, i.e. well past the copy
+                                slot.keep.append(t)
                                 d.copy_(t, non_blocking=True)
                             else:
                                 # the pinned tensor of the slot's previous batch may still be the source of an in-flight
                                 # copy: `ready` of that batch is behind us only once the copy stream has reached it
                                 slot.ready.synchronize()
-                                h.copy_(t)                                # pageable -> pinned (releases the GIL)
+                                _stage(h, t)                              # pageable -> pinned
                                 d.copy_(h, non_blocking=True)
                         slot.ready.record(self.copy_stream)
-                    it = iter(slot.dev)
+                    it = iter(slot.out)
                     slot.batch = _map(lambda _t: next(it), batch)
                     ready.put((slot, slot.batch))
                 ready.put((_END, None))
@@ -137,7 +173,7 @@ class DevicePrefetcher:
                     raise batch
                 if slot is not None:
                     torch.cuda.current_stream(dev).wait_event(slot.ready)
-                    for t in slot.dev:
+                    for t in slot.out:
                         t.record_stream(torch.cuda.current_stream(dev))
                 yield batch
                 # the consumer is back for its next batch: every kernel that reads this one has been enqueued, so the slot
@@ -171,10 +207,11 @@ class SyntheticBatches:
             yield torch.rand(self.shape, device=self.device, generator=self.generator) if self.fresh else self._resident
 
 
-def prefetch(loader: Iterable, device: Union[str, torch.device], depth: int = 2) -> Iterable:
+def prefetch(loader: Iterable, device: Union[str, torch.device], depth: int = 2,
+             transfer_dtype: Optional[torch.dtype] = None) -> Iterable:
     """``loader`` behind a DevicePrefetcher when that helps (a GPU target and a loader that is not already one of this
     module's device-side feeds); otherwise the loader itself."""
     device = torch.device(device)
     if device.type != "cuda" or isinstance(loader, (DevicePrefetcher, SyntheticBatches)):
         return loader
-    return DevicePrefetcher(loader, device, depth)
+    return DevicePrefetcher(loader, device, depth, transfer_dtype)

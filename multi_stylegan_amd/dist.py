@@ -105,6 +105,37 @@ class _Bucket:
         self.shard = None                    # exchange == "reduce_scatter": this rank's 1/world slice of the reduced bucket
 
 
+class _GradSlot:
+    """Where a parameter's gradient lives inside its reducer's flat store (see grad_destination)."""
+    __slots__ = ("reducer", "bucket", "offset", "taken")
+
+    def __init__(self, reducer, bucket, offset):
+        self.reducer, self.bucket, self.offset, self.taken = reducer, bucket, offset, False
+
+
+_DIRECT_GRADS = bool(int(os.environ.get("MSG_DIRECT_GRADS", "1")))     # 0: every gradient through autograd's accumulation add (A/B)
+
+
+def grad_destination(p: torch.Tensor) -> Optional[torch.Tensor]:
+    """A fresh view of the flat-store slice that holds ``p``'s gradient, for a backward kernel to write its result into --
+    or None when the result has to go through autograd's own accumulation (no armed reducer, a second contribution to the
+    same parameter in this backward, a higher-order pass).
+
+    With ~280 parameters per optimiser step, autograd's AccumulateGrad costs one tiny `grad += incoming` launch each
+    (1.4 ms of device time and as much host time per iteration).  While a reducer is armed for a labelled backward its
+    parameters' ``.grad`` are None instead: AccumulateGrad then ADOPTS the incoming tensor instead of adding it, and when that
+    tensor already is the parameter's slice of the flat store -- because the kernel that computed it wrote it there -- the
+    accumulation costs nothing and the store stays the single home of the gradients (hooks fire as usual)."""
+    slot = p.__dict__.get("_msg_grad_slot") if isinstance(p, torch.nn.Parameter) else None
+    if slot is None:
+        return None
+    red = slot.reducer
+    if not (red._armed and red._detached) or slot.taken or p.grad is not None or torch.is_grad_enabled():
+        return None
+    slot.taken = True
+    return slot.bucket.flat[slot.offset:slot.offset + p.numel()].view(p.shape)
+
+
 BUCKET_ALIGN = 64        # elements (256 bytes): every parameter's slice of a flat store starts on this boundary
 
 
@@ -156,6 +187,8 @@ class GradBucketReducer:
         self._order: List[int] = []
         self._cold: List[int] = []
         self._shard_sumsq: Optional[torch.Tensor] = None
+        self._detached = False              # the parameters' .grad are None for the armed backward (see grad_destination)
+        self.direct = _DIRECT_GRADS
         self._slot_of = {}
         cap = max(1, bucket_bytes // 4)
         # gradients become ready roughly in reverse registration order: fill buckets from the back
@@ -182,9 +215,10 @@ class GradBucketReducer:
             if self.exchange == "reduce_scatter" and self.active:
                 bucket.shard = torch.zeros(total // self.world, dtype=torch.float32, device=dev)
             self.buckets.append(bucket)
-            for p in ps:
+            for p, off in zip(ps, offsets):
                 self._bucket_of[p] = bucket
                 self._slot_of[p] = len(self._slot_of)
+                p.__dict__["_msg_grad_slot"] = _GradSlot(self, bucket, off)
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.comm_stream = None
         if self.active and params and params[0].is_cuda:
@@ -228,16 +262,45 @@ class GradBucketReducer:
         else:
             self._order = [k for k, n in enumerate(plan) if n > 0]
             self._cold = [k for k, n in enumerate(plan) if n == 0]
+        if label is not None and self.direct and self.buckets and self.buckets[0].flat.is_cuda:
+            # (labelled = the trainer's backwards; the store was zeroed by zero_grad(), so a parameter this backward does not
+            #  reach reads as a zero gradient once finish() has re-attached the views)
+            self._detached = True
+            for b in self.buckets:
+                for q in b.params:
+                    q.grad = None
+                    q.__dict__["_msg_grad_slot"].taken = False
+
+    def _attach_all(self) -> None:
+        """Every parameter's .grad is its view of the flat store again (after a backward with detached gradients)."""
+        self._detached = False
+        for b in self.buckets:
+            for q, off in zip(b.params, b.offsets):
+                g = q.grad
+                if g is None:
+                    q.grad = b.flat[off:off + q.numel()].view_as(q)
+                elif g.data_ptr() != b.flat.data_ptr() + 4 * off:
+                    view = b.flat[off:off + q.numel()].view_as(q)
+                    view.copy_(g)
+                    q.grad = view
 
     def disarm(self) -> None:
         self._armed = False
+        if self._detached:
+            self._attach_all()
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         if not self._armed:
             return
         b = self._bucket_of[p]
         if p.grad is not None and p.grad.data_ptr() != self._view_ptr(b, p):
-            self._reattach(b)                      # autograd swapped the tensor (out-of-place accumulation)
+            if self._detached:                     # a gradient whose producer did not write the store: move it in (this
+                slot = p.__dict__["_msg_grad_slot"]                      # parameter only; the others are still to arrive)
+                view = b.flat[slot.offset:slot.offset + p.numel()].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
+            else:
+                self._reattach(b)                  # autograd swapped the tensor (out-of-place accumulation)
         if b.ready:
             # the bucket is already on the wire: this gradient would be lost (or race with the collective).  Can only happen
             # if a backward of this label reached a parameter that the learned plan says it never reaches.
@@ -296,6 +359,8 @@ class GradBucketReducer:
         caller that can fold it into a later pass (the trainer folds it into fused Adam's grad_scale and saves one
         read-modify-write of every gradient per optimiser step)."""
         self._armed = False
+        if self._detached:
+            self._attach_all()
         if not self.active:
             return 1.0
         for k in self._order[self._next:] + self._cold:   # whatever is left (incomplete hot buckets, then the cold ones)

@@ -69,6 +69,10 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, noise, need_bias, negative_slope, scale):
+        # `need_bias` may be the bias PARAMETER itself: its slice of the flat gradient store then receives the sum directly
+        # (conv_ops._grad_dest) and autograd's accumulation add of it disappears
+        bias_param = need_bias if isinstance(need_bias, torch.Tensor) else None
+        need_bias = True if bias_param is not None else bool(need_bias)
         # The SAVED OUTPUT's memory layout picks the kernel (channels-last vectors or planes), not the incoming gradient's:
         # a gradient that autograd summed from two consumers inherits the layout of whichever arrived first, and the engine's
         # order in second-order passes depends on thread-local node counters, i.e. on the process's history -- a
@@ -87,8 +91,13 @@ class FusedLeakyReLUFunctionBackward(Function):
         g = g.contiguous(memory_format=torch.channels_last) if (step_b == 1 and g.ndim == 4) else g.contiguous()
         gx = torch.empty_like(g)
         channels = g.shape[1]
-        # grad_bias / grad_noise_weight are overwritten by a fixed-order sum of per-workgroup partials (deterministic)
-        gb = torch.empty(channels, dtype=torch.float32, device=dev) if need_bias else None
+        # grad_bias / grad_noise_weight are overwritten by a fixed-order sum of per-workgroup partials (deterministic).
+        gb = None
+        if bias_param is not None and bias_param.dtype == torch.float32 and bias_param.shape == (channels,):
+            from ..conv_ops import _grad_dest
+            gb = _grad_dest(bias_param)
+        if gb is None and need_bias:
+            gb = torch.empty(channels, dtype=torch.float32, device=dev)
         nz, nb = _noise_args(noise, g)
         gnw = torch.empty(1, dtype=torch.float32, device=dev) if noise is not None else None
         need = 0
@@ -130,14 +139,15 @@ class FusedLeakyReLUFunction(Function):
         out = _bias_act(x, bias, None, noise, noise_weight, 0, negative_slope, scale)
         ctx.save_for_backward(out, noise)
         ctx.cfg = (negative_slope, scale, bias is not None, noise_weight is not None)
+        ctx.bias_param = bias
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
         out, noise = ctx.saved_tensors
         negative_slope, scale, has_bias, has_nw = ctx.cfg
-        gx, gb, gnw = FusedLeakyReLUFunctionBackward.apply(grad_output, out, noise if has_nw else None, has_bias,
-                                                           negative_slope, scale)
+        gx, gb, gnw = FusedLeakyReLUFunctionBackward.apply(grad_output, out, noise if has_nw else None,
+                                                           ctx.bias_param if has_bias else False, negative_slope, scale)
         return gx, (gb if has_bias else None), None, (gnw if has_nw else None), None, None
 
 

@@ -174,3 +174,32 @@ def test_training_iteration_is_bit_reproducible(golden, dtype):
         assert la == lb
         differing = [n for n in a if not torch.equal(a[n], b[n])]
         assert not differing, differing[:8]
+
+
+def test_gradients_written_into_the_flat_store_equal_accumulated_gradients(golden):
+    """dist.grad_destination: the weight / bias gradient kernels write straight into the parameters' slices of the flat
+    gradient store (AccumulateGrad then adopts the tensor instead of launching `grad += incoming`).  Same training
+    trajectory, bit for bit, as with every gradient going through autograd's accumulation add; and most parameters do take
+    the direct route."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd import dist as msg_dist
+    from test_hip_models import _golden_trainer
+    from test_oracle_golden import load_train_draws
+    finals, taken = [], None
+    for direct in (True, False):
+        z, g, d, trainer = _golden_trainer(golden)
+        trainer.generator_reducer.direct = trainer.discriminator_reducer.direct = direct
+        for step, it in ((0, 1), (1, 16)):
+            real, draws = load_train_draws(z, step, m.model_wrapper)
+            trainer.iteration = it - 1
+            trainer.train_iteration(real.to(DEV), draws.to(DEV))
+        if direct:
+            slots = [p.__dict__["_msg_grad_slot"] for p in d.parameters()]
+            taken = sum(s.taken for s in slots) / len(slots)          # (state after the last discriminator backward)
+        for red in (trainer.generator_reducer, trainer.discriminator_reducer):
+            for b in red.buckets:
+                for p, off in zip(b.params, b.offsets):               # every .grad is its view of the store again
+                    assert p.grad is not None and p.grad.data_ptr() == b.flat.data_ptr() + 4 * off
+        finals.append([p.detach().clone() for p in list(g.parameters()) + list(d.parameters())])
+    assert taken is not None and taken > 0.6, taken
+    assert all(torch.equal(a, b) for a, b in zip(*finals))

@@ -273,11 +273,14 @@ int msg_nonlocal_attention_bwd(const void* q, const void* qt, const void* k, con
  * ((1 - m00) cx - m01 cy, m01 cx + (1 - m00) cy); output pixel -> normalised (affine_grid, align_corners) ->
  * N M^-1 N^-1 (N: pixel [0, size-1] -> [-1, 1]) -> pixel (grid_sample, align_corners), bilinear, padding 0 = zeros /
  * 2 = reflection.  (kaf.apply_affine passes -angle: the caller negates.)
- * backward != 0: x is the gradient of y, y the ZERO-INITIALISED gradient of x, which is accumulated into (float
- * atomics: the transpose of the bilinear gather).  Parity unpinned, see oracle/ada.py. */
+ * backward != 0: x is the gradient of y, y receives the gradient of x (overwritten) -- the transpose of the bilinear
+ * gather, a scatter, accumulated in 64-bit FIXED POINT (2^-38 resolution) in `workspace` (B*C*H*W 8-byte words, contents
+ * irrelevant) and converted by a second launch: integer addition is associative, so the result does not depend on the
+ * order in which the atomics arrive (deterministic).  workspace may be NULL for the forward.
+ * Parity unpinned, see oracle/ada.py. */
 int msg_affine_warp(const float* x, float* y, const float* angle_deg, float angle_const, const float* scale_xy,
                     const float* select_u, const float* p, int rot_prob, float cx, float cy, int padding,
-                    int align_corners, int B, int C, int H, int W, int backward, void* stream);
+                    int align_corners, int B, int C, int H, int W, int backward, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a5 / 8f-1  minibatch standard deviation -- replaces MinibatchStdDev.forward

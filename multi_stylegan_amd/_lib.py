@@ -56,7 +56,7 @@ _SIGNATURES = {
     "msg_nonlocal_attention_fwd": (_I, [_P] * 5 + [_I] * 6 + [_P]),
     "msg_nonlocal_attention_bwd_splits": (_I, [_I] * 3),
     "msg_nonlocal_attention_bwd": (_I, [_P] * 14 + [_I] * 6 + [_P]),
-    "msg_affine_warp": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msg_affine_warp": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "msg_minibatch_stddev_workspace": (_L, [_I] * 5),
     "msg_minibatch_stddev": (_I, [_P, _P, _P, _P, _I] + [_I] * 7 + [_F, _P]),
     "msg_minibatch_stddev_backward": (_I, [_P, _P, _P, _P, _I] + [_I] * 8 + [_F, _P]),

@@ -33,11 +33,14 @@ SIGMA = (0.2 * math.log(2)) ** 2        # sigma the reference passes to np.rando
 def _warp_launch(x, angle, angle_const, scale, u, p, rot_prob, center, padding, align_corners, backward):
     dev = _lib.require_gpu(x, angle, scale, u, p)
     b, c, h, w = x.shape
-    y = torch.zeros_like(x) if backward else torch.empty_like(x)
+    y = torch.empty_like(x)
+    # backward: the scatter accumulates in 64-bit fixed point (deterministic whatever the order of the atomics)
+    ws = torch.empty(x.numel(), dtype=torch.int64, device=dev) if backward else None
     with _lib.on_device(dev), _lib.kernel_clock.span("affine_warp/f32", 2 * x.numel() * 4):
         code = _lib.lib().msg_affine_warp(x.data_ptr(), y.data_ptr(), _lib.ptr(angle), float(angle_const), _lib.ptr(scale),
                                           u.data_ptr(), p.data_ptr(), int(rot_prob), float(center[0]), float(center[1]),
-                                          int(padding), int(align_corners), b, c, h, w, int(backward), _lib.stream_of(dev))
+                                          int(padding), int(align_corners), b, c, h, w, int(backward), _lib.ptr(ws),
+                                          _lib.stream_of(dev))
     _lib.check(code, "msg_affine_warp")
     return y
 

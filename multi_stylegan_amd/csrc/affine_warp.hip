@@ -4,7 +4,9 @@
 // bilinear grid_sample with zeros or reflection padding -- as ONE launch per stage over the whole batch, with the
 // per-image selection (u[b] <= p, or <= 1 - sqrt(1 - p)) evaluated on the device from a device-resident p: no host
 // synchronisation, no index lists, unselected images are copied through.  HBM-bound: one read of the 4 neighbours per
-// channel (L2-served) and one coalesced write per output element.  Parity unpinned (kornia is not available): the
+// channel (L2-served) and one coalesced write per output element.  Backward = the transpose of the bilinear gather, a
+// scatter -- made DETERMINISTIC by accumulating in 64-bit fixed point (integer addition is associative: the order in which
+// the atomics arrive cannot change the sum) and converting once at the end.  Parity unpinned (kornia is not available): the
 // checker is oracle/ada.py, which runs the same published algorithm through torch's own affine_grid / grid_sample.
 #include "msg_common.h"
 
@@ -64,8 +66,13 @@ __device__ __forceinline__ bool source_position(const WarpParams& p, const float
     return true;
 }
 
+// gradient contributions are accumulated as round(v * 2^38): resolution 3.6e-12 (image gradients of the mean-reduced losses
+// are 1e-8 .. 1e-2), range +-3.3e7 per pixel
+constexpr double FIX_SCALE = 274877906944.0, FIX_INV = 1.0 / 274877906944.0;
+
 template <bool BACKWARD>
 __global__ __launch_bounds__(256) void affine_warp_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         unsigned long long* __restrict__ acc,
                                                          const float* __restrict__ angle, const float* __restrict__ scale,
                                                          const float* __restrict__ u, const float* __restrict__ prob,
                                                          WarpParams p) {
@@ -78,10 +85,8 @@ __global__ __launch_bounds__(256) void affine_warp_kernel(const float* __restric
     float* ob = out + (long long)b * p.C * hw;
     float xs, ys;
     if (!source_position(p, angle, scale, u, prob, b, xo, yo, xs, ys)) {
-        for (int c = 0; c < p.C; ++c) {
-            if (BACKWARD) ob[c * hw + rem] += ib[c * hw + rem];      // gx (zeroed) += gy: one thread per element
-            else ob[c * hw + rem] = ib[c * hw + rem];
-        }
+        if (BACKWARD) return;                        // (copied through by affine_warp_finish_kernel)
+        for (int c = 0; c < p.C; ++c) ob[c * hw + rem] = ib[c * hw + rem];
         return;
     }
     const float xf = floorf(xs), yf = floorf(ys);
@@ -98,23 +103,47 @@ __global__ __launch_bounds__(256) void affine_warp_kernel(const float* __restric
             if (vy1 && vx0) v += s[(long long)y1 * p.W + x0] * w10;
             if (vy1 && vx1) v += s[(long long)y1 * p.W + x1] * w11;
             ob[c * hw + rem] = v;
-        } else {          // in = gy, out = gx (zero-initialised): the transpose of the gather above
+        } else {          // in = gy; acc = fixed-point gradient of x (zeroed): the transpose of the gather above
             const float g = ib[c * hw + rem];
-            float* s = ob + c * hw;
-            if (vy0 && vx0) atomicAdd(s + (long long)y0 * p.W + x0, g * w00);
-            if (vy0 && vx1) atomicAdd(s + (long long)y0 * p.W + x1, g * w01);
-            if (vy1 && vx0) atomicAdd(s + (long long)y1 * p.W + x0, g * w10);
-            if (vy1 && vx1) atomicAdd(s + (long long)y1 * p.W + x1, g * w11);
+            unsigned long long* s = acc + ((long long)b * p.C + c) * hw;
+            auto add = [&](long long idx, float v) __attribute__((always_inline)) {
+                atomicAdd(s + idx, (unsigned long long)__double2ll_rn((double)v * FIX_SCALE));   // two's complement wraps correctly
+            };
+            if (vy0 && vx0) add((long long)y0 * p.W + x0, g * w00);
+            if (vy0 && vx1) add((long long)y0 * p.W + x1, g * w01);
+            if (vy1 && vx0) add((long long)y1 * p.W + x0, g * w10);
+            if (vy1 && vx1) add((long long)y1 * p.W + x1, g * w11);
         }
     }
 }
 
-int launch(bool backward, const float* in, float* out, const float* angle, const float* scale, const float* u,
-           const float* prob, const WarpParams& p, hipStream_t s) {
+// backward, second stage: gx = the accumulated gradient of a transformed image, gy itself for an image that was copied through
+__global__ __launch_bounds__(256) void affine_warp_finish_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                const unsigned long long* __restrict__ acc,
+                                                                const float* __restrict__ u, const float* __restrict__ prob,
+                                                                WarpParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long chw = (long long)p.C * p.H * p.W;
+    if (i >= (long long)p.B * chw) return;
+    const int b = (int)(i / chw);
+    const float pr = prob[0];
+    const float thr = p.rot_prob ? 1.f - sqrtf(1.f - pr) : pr;
+    gx[i] = (u[b] <= thr) ? (float)((double)(long long)acc[i] * FIX_INV) : gy[i];
+}
+
+int launch(bool backward, const float* in, float* out, unsigned long long* acc, const float* angle, const float* scale,
+           const float* u, const float* prob, const WarpParams& p, hipStream_t s) {
     const long long pixels = (long long)p.B * p.H * p.W;
     const unsigned blocks = (unsigned)((pixels + 255) / 256);
-    if (backward) hipLaunchKernelGGL(affine_warp_kernel<true>, dim3(blocks), dim3(256), 0, s, in, out, angle, scale, u, prob, p);
-    else hipLaunchKernelGGL(affine_warp_kernel<false>, dim3(blocks), dim3(256), 0, s, in, out, angle, scale, u, prob, p);
+    if (!backward) {
+        hipLaunchKernelGGL(affine_warp_kernel<false>, dim3(blocks), dim3(256), 0, s, in, out, acc, angle, scale, u, prob, p);
+        return MSG_CHECK_LAUNCH();
+    }
+    const long long elems = pixels * p.C;
+    if (hipMemsetAsync(acc, 0, sizeof(unsigned long long) * elems, s) != hipSuccess) return MSG_ELAUNCH;
+    hipLaunchKernelGGL(affine_warp_kernel<true>, dim3(blocks), dim3(256), 0, s, in, out, acc, angle, scale, u, prob, p);
+    if (MSG_CHECK_LAUNCH() != MSG_OK) return MSG_ELAUNCH;
+    hipLaunchKernelGGL(affine_warp_finish_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, in, out, acc, u, prob, p);
     return MSG_CHECK_LAUNCH();
 }
 
@@ -122,10 +151,14 @@ int launch(bool backward, const float* in, float* out, const float* angle, const
 
 extern "C" int msg_affine_warp(const float* x, float* y, const float* angle_deg, float angle_const, const float* scale_xy,
                                const float* select_u, const float* p, int rot_prob, float cx, float cy, int padding,
-                               int align_corners, int B, int C, int H, int W, int backward, void* stream) {
+                               int align_corners, int B, int C, int H, int W, int backward, void* workspace,
+                               void* stream) {
     if (B == 0) return MSG_OK;
     if (!x || !y || !select_u || !p || B < 0 || C <= 0 || H <= 1 || W <= 1) return MSG_EINVAL;
+    if (backward && (!workspace || ((uintptr_t)workspace & 7u))) return MSG_EINVAL;
     if (padding != 0 && padding != 2) return MSG_EUNSUPPORTED;
+    if ((long long)B * C * H * W >= (1ll << 40)) return MSG_EUNSUPPORTED;
     WarpParams wp{B, C, H, W, cx, cy, angle_const, padding, align_corners ? 1 : 0, rot_prob ? 1 : 0};
-    return launch(backward != 0, x, y, angle_deg, scale_xy, select_u, p, wp, (hipStream_t)stream);
+    return launch(backward != 0, x, y, (unsigned long long*)workspace, angle_deg, scale_xy, select_u, p, wp,
+                  (hipStream_t)stream);
 }

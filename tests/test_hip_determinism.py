@@ -203,3 +203,28 @@ def test_gradients_written_into_the_flat_store_equal_accumulated_gradients(golde
         finals.append([p.detach().clone() for p in list(g.parameters()) + list(d.parameters())])
     assert taken is not None and taken > 0.6, taken
     assert all(torch.equal(a, b) for a, b in zip(*finals))
+
+
+def test_ada_warp_backward_is_deterministic():
+    """The augmentation warp's backward is a scatter; it accumulates in 64-bit fixed point, so repeated launches agree bit
+    for bit (float atomics did not), and the result is the adjoint of the forward: <warp(x), g> == <x, warp^T(g)>."""
+    from multi_stylegan_amd.adaptive_discriminator_augmentation import affine_warp
+    torch.manual_seed(3)
+    b, c, h, w = 8, 6, 96, 80
+    x = torch.randn(b, c, h, w, device=DEV, requires_grad=True)
+    u = torch.rand(b, device=DEV)
+    p = torch.tensor(0.7, device=DEV)
+    angle = torch.rand(b, device=DEV) * 360.0
+    scale = torch.exp(torch.randn(b, 2, device=DEV) * 0.3)
+    g = torch.randn(b, c, h, w, device=DEV) * 1e-4                     # (image gradients of mean-reduced losses are small)
+    for padding in (0, 2):
+        y = affine_warp(x, u, p, angle=angle, scale=scale, center=((w - 1) / 2, (h - 1) / 2), padding=padding,
+                        align_corners=True)
+        first, = torch.autograd.grad(y, x, g, retain_graph=True)
+        for _ in range(REPEATS):
+            again, = torch.autograd.grad(y, x, g, retain_graph=True)
+            assert torch.equal(first, again)
+        lhs, rhs = (y.detach().double() * g.double()).sum(), (x.detach().double() * first.double()).sum()
+        assert abs(lhs - rhs) <= 1e-5 * abs(lhs), (padding, float(lhs), float(rhs))
+        keep = (u > p)                                                 # images that were copied through: gradient == g exactly
+        assert keep.any() and torch.equal(first[keep], g[keep])

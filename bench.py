@@ -89,7 +89,7 @@ def baseline_config(args, world) -> str:
 
 def _is_flops(key: str) -> bool:
     """Kernel-clock keys whose `work` is FLOPs (the contractions); everything else counts bytes."""
-    return key.startswith(("conv", "linear", "nonlocal_attention", "attention"))
+    return key.startswith(("conv", "linear", "nl_attention"))
 
 
 def note(msg):

@@ -186,6 +186,42 @@ def fp32_leg(args, dev, batch: int = 4, steps: int = 3):
                       f"fp32 storage and exact-fp32 MFMA, amortised {lazy - 1}:1"}
 
 
+def elided_leg(args, dev, dtype, steps: int = 6):
+    """The same iteration without the two pieces of work whose results the reference computes and throws away -- the second
+    stream's main convolutions and the discriminator's weight gradients in the generator step (Q11).  Identical
+    training trajectory, bit for bit (tested); reported beside `value`, which executes both like the reference does."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    torch.manual_seed(1234)
+    gen = m.MultiStyleGANGenerator(generator_config_for_resolution(args.resolution))
+    dis = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    gen.compute_dtype = dis.compute_dtype = dtype
+    gen.elide_dead_branch = True
+    trainer = m.ModelWrapper(gen, dis, device=dev, skip_discriminator_weight_grads_in_generator_step=True)
+    trainer.generator_ema.compute_dtype = dtype
+    lazy = trainer.hyperparameters["lazy_discriminator_regularization"]
+    real = torch.rand(args.batch, 2, 3, args.resolution, args.resolution, device=dev)
+    trainer.iteration = lazy - 2
+    for _ in range(2):
+        trainer.train_iteration(real)                          # warm-up: 15 (plain), 16 (regularised)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_iteration(real)                          # 17 ...: plain
+    torch.cuda.synchronize(dev)
+    plain_ms = 1e3 * (time.perf_counter() - t0) / steps
+    trainer.iteration = 2 * lazy - 1
+    t1 = time.perf_counter()
+    trainer.train_iteration(real)                              # 32: regularised
+    torch.cuda.synchronize(dev)
+    reg_ms = 1e3 * (time.perf_counter() - t1)
+    step_ms = ((lazy - 1) * plain_ms + reg_ms) / lazy
+    return {"value": round(args.batch / (step_ms * 1e-3), 3), "unit": "img/s", "plain_ms": round(plain_ms, 2),
+            "regularised_ms": round(reg_ms, 2), "ms_per_step": round(step_ms, 2),
+            "sample": f"{steps} plain + 1 regularised iteration with --elide-dead-work (dead second-stream convolutions and the "
+                      f"discriminator's weight gradients in the generator step skipped; same trajectory), amortised {lazy - 1}:1"}
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one
     process per GPU, RCCL rendezvous on 127.0.0.1) from a parent that never touches the GPU, relay their output
@@ -422,9 +458,13 @@ def main():
             "h2d": h2d,
         }
         if world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and not args.rehearse_on_one_gpu:
-            note("fp32-storage leg (batch 4) ...")
             del trainer, gen, dis, real
             torch.cuda.empty_cache()
+            if not args.elide_dead_work:
+                note("dead-work-elided leg ...")
+                out["value_dead_work_elided"] = elided_leg(args, dev, dtype)
+                torch.cuda.empty_cache()
+            note("fp32-storage leg (batch 4) ...")
             out["value_fp32_path"] = fp32_leg(args, dev)
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
             note("CPU baseline (oracle, 64x64, B=4" + ("" if args.no_cpu_same_resolution else

@@ -350,6 +350,10 @@ int msg_linear_grouped_wgrad(const float* gy, const float* x, const int* slot, f
  * staging, 0 = 128x128 with register staging.  Used by bench.py to label per-kernel timings. */
 int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                           int kh, int kw, long long w_batch_stride);
+/* 1 if msg_conv2d_fprop takes this problem to the activation-stationary sub-pixel up-convolution kernel (conv_upconv.hip:
+ * K = 512, N = 4 * 512, per-sample weights, pixel-shuffled output, bf16), else 0.  For timing labels. */
+int msg_conv2d_fprop_upconv_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int kh, int kw,
+                                     int stride, int pad, int in_up, int pixel_shuffle, long long w_batch_stride);
 
 /* ---------------------------------------------------------------------------
  * Adam over a flat fp32 store, optionally with an exponential moving average of the stepped parameters in the same pass

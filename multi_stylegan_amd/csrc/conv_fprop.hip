@@ -412,6 +412,10 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
 
 extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                               int kh, int kw, long long w_batch_stride);
+extern "C" int msg_conv2d_fprop_upconv_try(const void* x, const void* w, const float* bias, void* y,
+                                           int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                           int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                           long long w_batch_stride, const ActEpilogue* act, void* stream);
 // Which kernel msg_conv2d_fprop would launch for this problem: 3 / 4 = conv_fprop_row3_kernel<4,4> / <2,2> (3x3 'same' convs
 // on wide maps, activation tile shared by the horizontal taps; 256x256 / 128x128 tile), 2 = conv_fprop_pp_kernel (256x256 ping-pong),
 // 1 = conv_fprop_kernel<T, true> (128x128, LDS-DMA staging), 0 = conv_fprop_kernel<T, false> (register staging).
@@ -479,6 +483,10 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     if (pixel_shuffle && (N % 4 || (N / 4) % vec || ldy % vec)) return MSG_EUNSUPPORTED;
     if (!pixel_shuffle && ldy % vec) return MSG_EUNSUPPORTED;
     if (in_up > 1 && stride != 1) return MSG_EUNSUPPORTED;
+    if (dtype == MSG_BF16 &&
+        msg_conv2d_fprop_upconv_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
+                                    pixel_shuffle, w_batch_stride, &act, stream))
+        return MSG_CHECK_LAUNCH();                 // the generator's sub-pixel up-convolution: activation-stationary kernel
     if (dtype == MSG_BF16 &&
         msg_conv2d_fprop_row3_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
                                   pixel_shuffle, w_batch_stride, &act, stream))

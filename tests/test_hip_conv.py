@@ -373,7 +373,7 @@ def test_fused_modulated_conv_matches_composite(kind, dtype, batch):
     y = conv_ops.modulated_conv2d(xd, wd, sd, demod, up)
     calls = []
     orig = conv_ops._modconv_backward
-    conv_ops._modconv_backward = lambda *a: (calls.append(a[0].shape[0]), orig(*a))[1]
+    conv_ops._modconv_backward = lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1]
     try:
         gd = torch.autograd.grad(y, (xd, wd, sd), gyd)
     finally:
@@ -630,3 +630,38 @@ def test_modulated_conv_second_order_native_matches_composite(kind, dtype):
     if dtype == torch.float32:
         for name, a, r in zip(names, native, reference64()):
             assert rel_err(a, r) < 2e-4, (name, rel_err(a, r))
+
+
+@pytest.mark.parametrize("batch,hw", [(2, (128, 128)), (8, (128, 128)), (3, (136, 124)), (1, (256, 256))])
+def test_activation_stationary_upconv_kernel(batch, hw):
+    """conv_upconv.hip -- the generator's sub-pixel up-convolution (512 -> 4 x 512, per-sample weights, pixel-shuffled output) on
+    its own activation-stationary kernel: against the transposed convolution it implements (fp32 on the same bf16-rounded
+    operands), bit-identical over repeated launches, including a map whose pixel count is not a multiple of the 128-pixel
+    tile and both workgroup orders (samples dealt to XCDs when the batch is a multiple of 8, sample-major otherwise)."""
+    from multi_stylegan_amd import _lib, conv_ops
+    h, w_ = hw
+    i = o = 512
+    torch.manual_seed(batch + h)
+    x = conv_ops.to_compute_layout(torch.randn(batch, i, h, w_, device=DEV), torch.bfloat16)
+    w = (torch.randn(batch, o, i, 2, 2, device=DEV) / math.sqrt(i)).bfloat16().float()
+    geo = conv_ops.Geometry("up2", 2, 2, 1, 0, (h, w_), True)
+    wk, ck = conv_ops._relay_fwd_kind(w, torch.bfloat16, "up2")
+    assert _lib.lib().msg_conv2d_fprop_upconv_eligible(batch, h, w_, i, ck, h, w_, 4 * o, 1, 1, 1, 0, 1, 1, wk.stride(0)) == 1
+    y = conv_ops._f_raw(x, w, None, geo)
+    assert y.shape == (batch, o, 2 * h, 2 * w_)
+    for _ in range(4):
+        assert torch.equal(y, conv_ops._f_raw(x, w, None, geo))
+    want = torch.cat([torch.nn.functional.conv_transpose2d(x[s:s + 1].float(), w[s].transpose(0, 1), stride=2)
+                      for s in range(batch)])
+    assert rel_err(y.float(), want) < 1e-2                      # (bf16 output rounding; the accumulation is fp32)
+    # gradients still flow through the existing data / weight gradient kernels of the geometry
+    xg = x.detach().clone().requires_grad_(True)
+    wg = w.clone().requires_grad_(True)
+    yy = conv_ops._ConvF.apply(xg, wg, None, geo)
+    gy = conv_ops.to_compute_layout(torch.randn_like(want), torch.bfloat16)
+    gx, gw = torch.autograd.grad(yy, (xg, wg), gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = torch.cat([torch.nn.functional.conv_transpose2d(xr[s:s + 1], wr[s].transpose(0, 1), stride=2) for s in range(batch)])
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.float())
+    assert rel_err(gx.float(), gxr) < 2e-2 and rel_err(gw.float(), gwr) < 2e-2

@@ -229,6 +229,18 @@ class NonLocalBlock(nn.Module):
         return scaled_add(self.gamma.to(input.dtype) * output, residual, 1.0 / math.sqrt(2))
 
 
+def append_spectra(input: torch.Tensor) -> torch.Tensor:
+    """[B, C, T, H, W] -> [B, C + 2 C, T, H, W]: behind the C input channels, per channel the real and the imaginary part of
+    its orthonormal, two-sided 3-D DFT over (T, H, W) -- what the reference's
+    ``torch.rfft(input[:, c], signal_ndim=3, normalized=True, onesided=False).permute(0, 4, 1, 2, 3)`` returned
+    (u_net_2d_discriminator.py:109-122; `torch.rfft` no longer exists, so this branch cannot be run from the reference's
+    code on any torch this package supports: restated with torch.fft, parity unpinned).  A library FFT (hipFFT), not one of
+    this package's kernels: the branch is off in the reference's configuration (config.py:12)."""
+    spectrum = torch.view_as_real(torch.fft.fftn(input.float(), dim=(-3, -2, -1), norm="ortho"))     # [B, C, T, H, W, 2]
+    spectrum = spectrum.permute(0, 1, 5, 2, 3, 4).flatten(start_dim=1, end_dim=2)                     # [B, 2 C, T, H, W]
+    return torch.cat([input, spectrum.to(input.dtype)], dim=1)
+
+
 class Discriminator(nn.Module):
     supports_minibatch_groups = True     # forward(..., minibatch_groups=n): n concatenated batches, per-batch statistics
 
@@ -237,10 +249,11 @@ class Discriminator(nn.Module):
         encoder_channels: Tuple[Tuple[int, int], ...] = config["encoder_channels"]
         decoder_channels: Tuple[Tuple[int, int], ...] = config["decoder_channels"]
         self.fft: bool = config["fft"]
-        if self.fft:
-            raise NotImplementedError("the fft input branch is off in the reference config (config.py:12) and is "
-                                      "outside the hot-path scope (DESIGN.md)")
         input_channels = 3 if no_gfp else (6 if no_rfp else 9)
+        if self.fft:
+            # the reference's optional spectral input (u_net_2d_discriminator.py:43-46,106-122; off in config.py:12): every
+            # channel's 3-D spectrum (real, imaginary) is appended to the input, tripling the first block's input channels
+            input_channels = input_channels + 2 * input_channels
         self.encoder_blocks = nn.ModuleList()
         for index, (c_in, c_out) in enumerate(encoder_channels):
             if index == 0:
@@ -288,6 +301,8 @@ class Discriminator(nn.Module):
                 m.groups = 1
 
     def _forward(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.fft:
+            input = append_spectra(input)
         x = input.flatten(start_dim=1, end_dim=2)
         x = conv_ops.to_compute_layout(x, self.compute_dtype)
         skips = []

@@ -332,13 +332,17 @@ class NonLocalBlock(nn.Module):
 
 
 class Discriminator(nn.Module):
-    """u_net_2d_discriminator.py:14-140 (fft branch not restated: config.py:12 has it off)."""
+    """u_net_2d_discriminator.py:14-140.  The optional fft input (:43-46, :106-122; off in config.py:12) calls
+    `torch.rfft`, which no torch of the last years has: it is restated through torch.fft per channel as the reference
+    does it, and that part of the oracle is PARITY UNPINNED (no fixture of the reference can be generated for it)."""
 
     def __init__(self, config=DISCRIMINATOR_CONFIG, no_rfp=False, no_gfp=False):
         super().__init__()
         enc, dec = config["encoder_channels"], config["decoder_channels"]
-        assert not config["fft"], "fft input path is outside the hot-path scope"
+        self.fft = bool(config["fft"])
         in_ch = 3 if no_gfp else (6 if no_rfp else 9)
+        if self.fft:
+            in_ch = in_ch + in_ch * 2
         self.encoder_blocks = nn.ModuleList()
         for i, (a, b) in enumerate(enc):
             if i == 0:
@@ -362,6 +366,12 @@ class Discriminator(nn.Module):
                                            EqualizedConv2d(dec[-1][-1], 1, 1, 1, 0, bias=False))
 
     def forward(self, x, **kwargs):
+        if self.fft:
+            # old torch.rfft(v, signal_ndim=3, normalized=True, onesided=False): full complex 3-D DFT / sqrt(T H W),
+            # trailing dimension (real, imaginary); the reference moves that dimension in front of T
+            spectra = [torch.view_as_real(torch.fft.fftn(x[:, c], dim=(1, 2, 3), norm="ortho")).permute(0, 4, 1, 2, 3)
+                       for c in range(x.shape[1])]
+            x = torch.cat([x] + spectra, dim=1)
         x = x.flatten(1, 2)
         feats = []
         for i, blk in enumerate(self.encoder_blocks):

@@ -78,6 +78,42 @@ def test_tiny_discriminator(golden):
         assert rel_err(params[key[len("tinyD.r1grad."):]].grad, z[key]) < TOL, key
 
 
+@pytest.mark.parametrize("no_rfp", [True, False])
+def test_discriminator_fft_input_matches_oracle(no_rfp):
+    """The optional spectral input (config "fft": True; u_net_2d_discriminator.py:43-46,106-122): 3 C input channels
+    into the first block, forward and parameter gradients against the CPU oracle's restatement.  Parity unpinned for
+    this branch (the reference's `torch.rfft` call cannot run on any current torch), so the spectra are also checked
+    against numpy's FFT directly."""
+    import numpy as np
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.u_net_2d_discriminator import append_spectra
+    from oracle import models as om
+    from tools.gen_golden import TINY_D
+    torch.manual_seed(11)
+    cfg = dict(TINY_D, fft=True)
+    c = 2 if no_rfp else 3
+    do = om.Discriminator(cfg, no_rfp=no_rfp)
+    dd = m.MultiStyleGANDiscriminator(cfg, no_rfp=no_rfp)
+    dd.load_state_dict(do.state_dict())
+    dd.to(DEV)
+    assert dd.encoder_blocks[0].main_mapping[0].weight.shape[1] == 9 * c
+    x = torch.rand(2, c, 3, 32, 32)
+    ext = append_spectra(x.to(DEV)).cpu()
+    assert ext.shape == (2, 3 * c, 3, 32, 32) and torch.equal(ext[:, :c], x)
+    spec = np.fft.fftn(x.double().numpy(), axes=(2, 3, 4)) / math.sqrt(3 * 32 * 32)
+    for ch in range(c):
+        assert rel_err(ext[:, c + 2 * ch], torch.from_numpy(spec[:, ch].real)) < 1e-5
+        assert rel_err(ext[:, c + 2 * ch + 1], torch.from_numpy(spec[:, ch].imag)) < 1e-5
+    ws, wp = do(x)
+    (ws.sum() + wp.square().sum()).backward()
+    gs, gp = dd(x.to(DEV))
+    (gs.sum() + gp.square().sum()).backward()
+    assert rel_err(gs, ws) < TOL and rel_err(gp, wp) < TOL
+    want = dict(do.named_parameters())
+    for name, p in dd.named_parameters():
+        assert rel_err(p.grad, want[name].grad) < TOL, name
+
+
 def test_discriminator_concatenated_batches_equal_separate_calls(golden):
     """forward(cat([a, b]), minibatch_groups=2) == (forward(a), forward(b)): everything is per-sample except the
     minibatch statistic, which is taken per group; gradients of the summed loss agree as well."""

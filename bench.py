@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--clock-all", action="store_true",
                     help="HIP-event timing of EVERY launch (per-kernel table in the JSON line); by default only the two "
                          "roofline kernels are timed, which keeps the event overhead out of the host path")
+    ap.add_argument("--clock-only", choices=["all", "plain", "regularised"], default="all",
+                    help="restrict the per-kernel clock to the plain / the regularised (R1 + path length) iterations "
+                         "(diagnostic; tools/shape_table.py divides by `clock_iterations`)")
     ap.add_argument("--cpu-baseline-iters", type=int, default=4)
     ap.add_argument("--no-cpu-same-resolution", action="store_true",
                     help="skip the CPU oracle's one iteration at the benchmark's own resolution (about a minute at 256^2)")
@@ -312,7 +315,11 @@ def main():
     first_iteration = trainer.iteration + 1
     t0 = time.perf_counter()
     marks[0].record()
+    clock_iterations = 0
     for k in range(args.steps):
+        if args.clock_only != "all" and not args.no_kernel_clock:
+            _lib.kernel_clock.enabled = ((first_iteration + k) % hp_lazy == 0) == (args.clock_only == "regularised")
+        clock_iterations += int(_lib.kernel_clock.enabled)
         trainer.train_iteration(batch_of())
         marks[k + 1].record()                                  # (one event per iteration: the plain / regularised split)
     barrier()
@@ -453,7 +460,8 @@ def main():
                              "raw_img_per_s": round(world * args.batch * args.steps / elapsed, 3),
                              "value_is": f"{hp_lazy - 1}:1 amortised (plain : regularised iterations, as in training)"
                              if amortise else "raw average of the window (it holds no regularised or no plain iteration)"},
-            "roofline": roof, "roofline_upfirdn2d": roof_fir, "kernels": kernels, "peak_mem_GiB": round(peak_mem, 2),
+            "roofline": roof, "roofline_upfirdn2d": roof_fir, "kernels": kernels,
+            "clock_iterations": clock_iterations, "peak_mem_GiB": round(peak_mem, 2),
             "losses": {k: round(v, 5) for k, v in last.items()},
             "h2d": h2d,
         }

@@ -61,6 +61,14 @@ int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, int dtype,
                           int up_x, int up_y, int down_x, int down_y,
                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* msg_upfirdn2d_pitched whose OUTPUT pixels are `out_pitch` (>= minor) elements apart as well: the result is written
+ * straight into its channel-slice of the map it is concatenated into (u_net_2d_discriminator.py:128-131 in the
+ * reference: torch.cat of the upsampled features and the encoder's skip features). */
+int msg_upfirdn2d_pitched2(const void* x, const float* fir, void* y, int dtype,
+                           int major, int in_h, int in_w, int minor, int in_pitch, int out_pitch, int kh, int kw,
+                           int up_x, int up_y, int down_x, int down_y,
+                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
 /* msg_upfirdn2d for up = down = 1 and a SEPARABLE 4x4 FIR given by its factors (fir2d = fir_y fir_x^T, which is how
  * every FIR of the models is built: multi_stylegan_generator.py:244-258, u_net_2d_discriminator.py:186-203), on a
  * channels-last map (major = B, minor = C, minor % vec == 0).  Sliding-window evaluation, 8 instead of 16 taps per

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "msg_strerror": (_c.c_char_p, [_I]),
     "msg_upfirdn2d": (_I, [_P, _P, _P, _I] + [_I] * 14 + [_P]),
     "msg_upfirdn2d_pitched": (_I, [_P, _P, _P, _I] + [_I] * 15 + [_P]),
+    "msg_upfirdn2d_pitched2": (_I, [_P, _P, _P, _I] + [_I] * 16 + [_P]),
     "msg_upfirdn2d_separable": (_I, [_P, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     "msg_upfirdn2d_separable_act": (_I, [_P, _P, _P, _P, _I] + [_I] * 10 + [_P, _P, _P, _I, _F, _F, _P]),
     "msg_fused_bias_act": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _P]),

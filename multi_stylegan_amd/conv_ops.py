@@ -110,6 +110,67 @@ def to_compute_layout(x: torch.Tensor, dtype=None) -> torch.Tensor:
     return x.contiguous()
 
 
+class _CatAliased(Function):
+    """torch.cat(pieces, dim=1) into `buffer` (cat_destination) for pieces that their producers WROTE into their
+    channel-slices of it: those cost nothing here, any other piece is copied into its slice; the result is the buffer.
+    The backward hands out channel-slice views of the incoming gradient exactly as _CatChannels does."""
+
+    @staticmethod
+    def forward(ctx, buffer, *pieces):
+        ctx.splits = [t.shape[1] for t in pieces]
+        off = 0
+        for t in pieces:
+            want = buffer[:, off:off + t.shape[1]]
+            if t.shape != want.shape or t.dtype != buffer.dtype:
+                raise _lib.MsgHipError(f"cat_in_place: piece {tuple(t.shape)} for slice {tuple(want.shape)}")
+            same = t.data_ptr() == want.data_ptr() and \
+                all(a == b for a, b, n in zip(t.stride(), want.stride(), t.shape) if n != 1)    # (size-1 dims: any stride)
+            if not same:
+                if t.untyped_storage().data_ptr() == buffer.untyped_storage().data_ptr():
+                    raise _lib.MsgHipError("cat_in_place: a piece lives in the destination buffer, but not in its slice")
+                want.copy_(t)                          # (not produced in place: one strided copy, as _CatChannels)
+            off += t.shape[1]
+        if off != buffer.shape[1]:
+            raise _lib.MsgHipError("cat_in_place: the pieces do not fill the destination buffer")
+        return buffer.view_as(buffer)
+
+    @staticmethod
+    def backward(ctx, g):
+        needs = ctx.needs_input_grad[1:]
+        if torch.is_grad_enabled():                    # second-order pass (R1): keep the split's own backward a concat
+            pieces = _SplitChannels.apply(g, *ctx.splits)
+            return (None, *(p if need else None for p, need in zip(pieces, needs)))
+        out, off = [], 0
+        for c, need in zip(ctx.splits, needs):
+            out.append(g[:, off:off + c] if need else None)
+            off += c
+        return (None, *out)
+
+
+def cat_destination(b: int, channels, h: int, w: int, dtype, device):
+    """Buffer for a channel concatenation whose pieces are written in place by their producers, and its slices:
+    -> (buffer [b, sum(channels), h, w] channels-last, [slice views]), or None when a piece is not a whole number of
+    16-byte channel vectors (then cat_channels copies, as before)."""
+    if any(c % _vec(dtype) for c in channels) or not torch.device(device).type == "cuda":
+        return None
+    buf = _padded_nhwc(b, sum(channels), h, w, dtype, device)
+    if any(c % (128 // buf.element_size()) for c in channels):
+        # The contraction kernels read whole 128-byte channel runs and rely on zero WEIGHTS beyond a layer's real input
+        # channels: a slice that is not a whole number of runs is read together with its neighbour, which may not have
+        # been written yet -- and uninitialised memory can hold NaN bit patterns.  (None of the models' levels: 128 ... 768.)
+        buf.zero_()
+    views, off = [], 0
+    for c in channels:
+        views.append(buf[:, off:off + c])
+        off += c
+    return buf, views
+
+
+def cat_in_place(buffer, pieces) -> torch.Tensor:
+    """The concatenation whose pieces already live in `buffer` (see cat_destination)."""
+    return _CatAliased.apply(buffer, *pieces)
+
+
 def cat_channels(tensors) -> torch.Tensor:
     """torch.cat(tensors, dim=1) in the compute layout."""
     tensors = list(tensors)
@@ -334,14 +395,19 @@ _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape
 
 
 def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real,
-                  flops=None, act=None, residual=None):
+                  flops=None, act=None, residual=None, out=None):
     """act = (act_bias | None, noise | None, noise_weight | None, alpha, scale): fuse the layer's activation stage.
-    residual = (map shaped like the output, gain): y = (conv + map) * gain in the epilogue."""
+    residual = (map shaped like the output, gain): y = (conv + map) * gain in the epilogue.
+    out: a channels-last map or channel-slice of a wider one that receives the result (cat_destination)."""
     dev = _lib.require_gpu(x, wk, bias)
     xv, cx = _nhwc_view(x)
     b, _, ih, iw = xv.shape
     oh, ow = out_hw
-    if pixel_shuffle:
+    if out is not None:
+        y, ldy = _nhwc_view(out)
+        if y is not out or pixel_shuffle or out.shape != (b, n, oh, ow) or out.dtype != x.dtype or n % _vec(x.dtype):
+            raise _lib.MsgHipError(f"conv fprop: destination {tuple(out.shape)} / {out.stride()} for a {(b, n, oh, ow)} result")
+    elif pixel_shuffle:
         y, ldy = _alloc_out(b, n // 4, 2 * oh, 2 * ow, x.dtype, dev)
     else:
         y, ldy = _alloc_out(b, n, oh, ow, x.dtype, dev)
@@ -519,27 +585,29 @@ def _relay_thin(w, dtype):
     return out, ko
 
 
-def _f_raw(x, w, bias, g: Geometry, act=None, residual=None):
+def _f_raw(x, w, bias, g: Geometry, act=None, residual=None, out=None):
     if w.ndim == 4 and _thin_ok(x.dtype, w.shape[1], g):
         xc, ko = _gather_taps(x, w.shape[1], g)
         wk, _ = _cached(w, "thin", x.dtype, g.wscale, lambda: _relay_thin(w, x.dtype))
         return _launch_fprop(xc, wk, ko, bias, w.shape[0], g.y_hw, 1, 1, 1, 0, 1, False, False,
-                             w.shape[1] * g.kh * g.kw, act=act, residual=residual)
+                             w.shape[1] * g.kh * g.kw, act=act, residual=residual, out=out)
     if g.kind == "up2" and _oi(w)[0] % _vec(x.dtype):
         # the pixel-shuffling epilogue stores whole 16-byte channel vectors per output pixel: pad the output channels
         # with zero filters and drop them again (rare: every up-conv of the models has 512 output channels)
         o_real = _oi(w)[0]
         wp = torch.zeros((*w.shape[:-4], _round_up(o_real, _vec(x.dtype)), *w.shape[-3:]), dtype=w.dtype, device=w.device)
         wp[..., :o_real, :, :, :] = w.detach()
+        assert out is None
         return _f_raw(x, wp, bias, g, act=act, residual=residual)[:, :o_real]
     img = _param_images(w, x.dtype, g.wscale, g.kind) if not g.per_sample else None
     wk, ck = img["f"] if img is not None else \
         _cached(w, "f" + g.kind, x.dtype, g.wscale, lambda: _relay_fwd_kind(w, x.dtype, g.kind))
     o, _ = _oi(w)
     if g.kind == "up2":
+        assert out is None
         return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, _oi(w)[1])
     return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, _oi(w)[1],
-                         act=act, residual=residual)
+                         act=act, residual=residual, out=out)
 
 
 def _act_operands(bias, noise, noise_w, y_shape):
@@ -720,8 +788,10 @@ class _ConvResidualF(Function):
     rescaled gradient goes to `main` as it is and through the D / G contractions to x and w."""
 
     @staticmethod
-    def forward(ctx, x, w, main, g, gain, fork, slot=None, main_scale=None):
-        y = _f_raw(x, w, None, g, residual=(main, gain))
+    def forward(ctx, x, w, main, g, gain, fork, slot=None, main_scale=None, out=None):
+        y = _f_raw(x, w, None, g, residual=(main, gain), out=out)
+        if out is not None:
+            y = out.view_as(out)                   # (a fresh alias: `out` itself is an input of this node)
         ctx.slot, ctx.main_scale = slot, main_scale
         ctx.g, ctx.gain, ctx.fork = g, float(gain), fork
         ctx.save_for_backward(x, w)
@@ -745,7 +815,7 @@ class _ConvResidualF(Function):
             if ctx.slot is not None and gx is not None:
                 ctx.slot.g = gx
             gw = _ConvG.apply(gs, x, _oi(w), w.ndim, gg, w) if _consumed(ctx, 1, 1) else None
-            return gx, gw, gs, None, None, None, None, None
+            return gx, gw, gs, None, None, None, None, None, None
         if g1 is None or g2 is None:
             gs = (g1 if g1 is not None else g2) * ctx.gain
         elif _rows_ok(g1, g2):
@@ -756,7 +826,7 @@ class _ConvResidualF(Function):
         if ctx.slot is not None and gx is not None and not torch.is_grad_enabled():
             ctx.slot.g = gx                  # the main branch's first conv adds it in its data-gradient epilogue
         gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g, w) if _consumed(ctx, 1, 1) else None
-        return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None
+        return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
 class _MultiConvF(Function):
@@ -857,12 +927,13 @@ def fork_input(x, slot: GradSlot):
 
 
 def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, fork=False, grad_slot=None,
-                        main_grad_scale=None):
+                        main_grad_scale=None, out=None):
     """(conv(x, wscale * weight) + main) * gain; with fork=True two aliases of the result (see scaled_add_fork).
-    ``main_grad_scale``: the GradScale that `main`'s producer was given (see there)."""
+    ``main_grad_scale``: the GradScale that `main`'s producer was given (see there).  ``out``: a destination from
+    cat_destination -- the result is written there and the returned tensor(s) alias it."""
     s, p = _square(stride, "stride"), _square(padding, "padding")
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
-    return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork), grad_slot, main_grad_scale)
+    return _ConvResidualF.apply(x, weight, main, g, float(gain), bool(fork), grad_slot, main_grad_scale, out)
 
 
 # ------------------------------------------------------------------------------------------------- public entry

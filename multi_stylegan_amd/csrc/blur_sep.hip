@@ -25,6 +25,7 @@
 struct BlurParams {
     int B, IH, IW, OH, OW, CV;      // CV = 16-byte vectors per pixel (channel stride / VEC)
     int px0, py0;
+    int xcd;                        // 1: the workgroups of a row strip are handed to the XCDs in contiguous bands (see the kernel)
     ActEpilogue act;                // optional fused (noise +) bias + leaky ReLU behind the blur (see msg_common.h)
 };
 
@@ -61,7 +62,11 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
                                                           BlurParams p) {
     using V = Vec16<T>;
     constexpr int VEC = V::N;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    // Workgroups are dispatched round-robin over the 8 XCDs in blockIdx.x order, and a workgroup re-reads the three columns
+    // to the right of its own: with the strip's workgroups dealt out in x order every such halo column came from another
+    // XCD's L2, i.e. from HBM again (PMC: 1.3x the algorithmic traffic).  Remapped, XCD k takes a contiguous band of the strip.
+    const unsigned bx = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const long long t = (long long)bx * 256 + threadIdx.x;
     const int xp = (int)(t / p.CV), cv = (int)(t - (long long)xp * p.CV);
     const int ox = 2 * xp;
     if (ox >= p.OW) return;
@@ -184,7 +189,9 @@ static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x
     if (kh != 4 || kw != 4 || minor % vec || (((uintptr_t)x | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
     const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
     if (oh <= 0 || ow <= 0) return MSG_EINVAL;
-    BlurParams p{major, in_h, in_w, oh, ow, minor / vec, pad_x0, pad_y0, act};
+    static int xcd = -1;
+    if (xcd < 0) { const char* e = getenv("MSG_BLUR_XCD"); xcd = e ? atoi(e) : 1; }
+    BlurParams p{major, in_h, in_w, oh, ow, minor / vec, pad_x0, pad_y0, 0, act};
     static int variant = -1;
     if (variant < 0) { const char* e = getenv("MSG_BLUR_VARIANT"); variant = e ? atoi(e) : 0; }
     const long long threads = (long long)((ow + 1) / 2) * p.CV;
@@ -197,6 +204,7 @@ static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x
     const int gy = (oh + th - 1) / th;
     if (gx >= (1ll << 31) || gy > 65535 || major > 65535) return MSG_EUNSUPPORTED;
     dim3 grid((unsigned)gx, gy, major);
+    p.xcd = xcd && gx >= 16 && gx % 8 == 0;      // (XCD of a workgroup = linear id % 8 = blockIdx.x % 8 only then)
     hipStream_t s = (hipStream_t)stream;
 #define BLUR_LAUNCH(TH_, ACT_)                                                                                            \
     do {                                                                                                               \

@@ -11,6 +11,7 @@
 struct UpfirdnParams {
     int major, in_h, in_w, minor, out_h, out_w;
     int in_pitch;        // elements between consecutive input pixels (== minor unless the input is a channel-slice of a wider map)
+    int out_pitch;       // the same for the output (a channel-slice of the map the result is concatenated into)
     int up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw;
     unsigned nvec, tiles_x, tiles_y, total;
     long long bias;      // elements; makes the per-lane part of every footprint address a non-negative offset
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const T* __restr
                    fir[(p.kh - 1 - ty) * p.kw + (p.kw - 1 - tx)];
         }
     }
-    store_from_f32(y + i, acc);
+    store_from_f32(y + ((mj * p.out_h + oy) * p.out_w + ox) * (long long)p.out_pitch + m, acc);
 }
 
 // float64 (MSG_F64; the `double` of AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:225): storage, FIR and
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_f64_kernel(const double* __rest
             acc += xb[((long long)iy * p.in_w + ix) * p.in_pitch] * fir[(p.kh - 1 - ty) * p.kw + (p.kw - 1 - tx)];
         }
     }
-    y[i] = acc;
+    y[((mj * p.out_h + oy) * p.out_w + ox) * (long long)p.out_pitch + m] = acc;
 }
 
 // Fast path: k <= 4x4, (UP,DOWN) in {(1,1),(1,2),(2,1)}, minor a multiple of the 16-byte vector.
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, (PIPE ? 3 : 2)) void upfirdn2d_vec_kernel(cons
         }
     }
 
-    T* yb = y + (size_t)mj * p.out_h * p.out_w * p.minor + (size_t)cv * VEC;
+    T* yb = y + (size_t)mj * p.out_h * p.out_w * p.out_pitch + (size_t)cv * VEC;
 #pragma unroll
     for (int a = 0; a < TH; ++a) {
         const int oy = oy0 + a;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256, (PIPE ? 3 : 2)) void upfirdn2d_vec_kernel(cons
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.set2(e, acc[a][b][2 * e], acc[a][b][2 * e + 1]);
             }
-            *reinterpret_cast<uint4*>(yb + ((size_t)oy * p.out_w + ox) * p.minor) = o.raw;
+            *reinterpret_cast<uint4*>(yb + ((size_t)oy * p.out_w + ox) * p.out_pitch) = o.raw;
         }
     }
 }
@@ -249,6 +250,7 @@ static int dispatch(const void* x, const float* fir, void* y, UpfirdnParams& p, 
     const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
     const bool square = p.up_x == p.up_y && p.down_x == p.down_y;
     const bool fast = aligned && square && p.kh <= 4 && p.kw <= 4 && p.minor % vec == 0 && p.in_pitch % vec == 0 &&
+                      p.out_pitch % vec == 0 &&
                       n_tiles < (1ll << 31) &&
                       ((p.up_x == 1 && (p.down_x == 1 || p.down_x == 2)) || (p.up_x == 2 && p.down_x == 1));
     if (fast) {
@@ -270,17 +272,17 @@ static int dispatch(const void* x, const float* fir, void* y, UpfirdnParams& p, 
     return MSG_CHECK_LAUNCH();
 }
 
-extern "C" int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, int dtype,
-                                     int major, int in_h, int in_w, int minor, int in_pitch, int kh, int kw,
-                                     int up_x, int up_y, int down_x, int down_y,
-                                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+extern "C" int msg_upfirdn2d_pitched2(const void* x, const float* fir, void* y, int dtype,
+                                      int major, int in_h, int in_w, int minor, int in_pitch, int out_pitch, int kh, int kw,
+                                      int up_x, int up_y, int down_x, int down_y,
+                                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
 extern "C" int msg_upfirdn2d(const void* x, const float* fir, void* y, int dtype,
                              int major, int in_h, int in_w, int minor, int kh, int kw,
                              int up_x, int up_y, int down_x, int down_y,
                              int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
-    return msg_upfirdn2d_pitched(x, fir, y, dtype, major, in_h, in_w, minor, minor, kh, kw, up_x, up_y, down_x, down_y,
-                                 pad_x0, pad_x1, pad_y0, pad_y1, stream);
+    return msg_upfirdn2d_pitched2(x, fir, y, dtype, major, in_h, in_w, minor, minor, minor, kh, kw, up_x, up_y, down_x, down_y,
+                                  pad_x0, pad_x1, pad_y0, pad_y1, stream);
 }
 
 // x [major][in_h][in_w] pixels of `minor` channels, `in_pitch` elements apart (a channel-slice of a wider channels-last
@@ -289,13 +291,23 @@ extern "C" int msg_upfirdn2d_pitched(const void* x, const float* fir, void* y, i
                                      int major, int in_h, int in_w, int minor, int in_pitch, int kh, int kw,
                                      int up_x, int up_y, int down_x, int down_y,
                                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
-    if (in_pitch < minor) return MSG_EINVAL;
+    return msg_upfirdn2d_pitched2(x, fir, y, dtype, major, in_h, in_w, minor, in_pitch, minor, kh, kw, up_x, up_y, down_x,
+                                  down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+
+// ... and y's pixels `out_pitch` elements apart: the result written straight into its channel-slice of the map it is
+// concatenated into (the discriminator's decoder: upsampled features next to the encoder's skip features).
+extern "C" int msg_upfirdn2d_pitched2(const void* x, const float* fir, void* y, int dtype,
+                                      int major, int in_h, int in_w, int minor, int in_pitch, int out_pitch, int kh, int kw,
+                                      int up_x, int up_y, int down_x, int down_y,
+                                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    if (in_pitch < minor || out_pitch < minor) return MSG_EINVAL;
     if (major == 0 && fir && in_h > 0 && in_w > 0 && minor > 0) return MSG_OK;     // empty batch: nothing to do
     if (!x || !fir || !y || major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 ||
         up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
         return MSG_EINVAL;
     UpfirdnParams p{};
-    p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.in_pitch = in_pitch; p.kh = kh; p.kw = kw;
+    p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.in_pitch = in_pitch; p.out_pitch = out_pitch; p.kh = kh; p.kw = kw;
     p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
     // upfirdn2d_kernel.cu:167-168
     p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;

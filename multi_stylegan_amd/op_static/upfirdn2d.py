@@ -50,8 +50,21 @@ def _separable(fir: torch.Tensor):
 _DT_NAME = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
 
 
-def _launch(x, fir, up, down, pad):
-    """x [B,C,H,W] (either layout), fir [kh,kw] fp32 on the same device -> y, same layout and dtype as x."""
+def _slice_pitch(t, c, h, w):
+    """Pixel pitch (elements) of a [B,c,h,w] channels-last map or channel-slice of one that the pitched entry points
+    take as it is, else None."""
+    if t.shape[1:] != (c, h, w) or not t.is_cuda:
+        return None
+    sb, sc, sh, sw = t.stride()
+    vec = 16 // t.element_size()
+    ok = (sc == 1 or c == 1) and sw >= c and sh == w * sw and (sb == h * w * sw or t.shape[0] == 1) and sw % vec == 0 and \
+        c % vec == 0 and t.data_ptr() % 16 == 0
+    return sw if ok else None
+
+
+def _launch(x, fir, up, down, pad, out=None):
+    """x [B,C,H,W] (either layout), fir [kh,kw] fp32 on the same device -> y, same layout and dtype as x.
+    out: a channels-last map or channel-slice of one that receives the result (see upfirdn2d)."""
     up_x, up_y = up
     down_x, down_y = down
     px0, px1, py0, py1 = pad
@@ -77,6 +90,21 @@ def _launch(x, fir, up, down, pad):
         return y
     fir = fir.to(torch.float32).contiguous()
     pitch = None
+    if out is not None:
+        # the result goes straight into its slice of a wider channels-last map (no concatenation copy afterwards)
+        out_pitch = _slice_pitch(out, c, oh, ow) if out.dtype == x.dtype and out.shape[0] == b else None
+        in_pitch = _slice_pitch(x, c, h, w)
+        if out_pitch is None or in_pitch is None or kh > 4 or kw > 4 or \
+                x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise _lib.MsgHipError(f"upfirdn2d(out=): input {tuple(x.shape)} / {x.stride()} or destination "
+                                   f"{tuple(out.shape)} / {out.stride()} is not a channels-last map or channel-slice")
+        key = f"upfirdn2d/{_DT_NAME.get(x.dtype, str(x.dtype))}/up{up_x}down{down_x}/vec"
+        with _lib.on_device(dev), _lib.kernel_clock.span(key, (b * c * h * w + b * c * oh * ow) * x.element_size()):
+            code = _lib.lib().msg_upfirdn2d_pitched2(x.data_ptr(), fir.data_ptr(), out.data_ptr(), _lib.dtype_code(x, True),
+                                                     b, h, w, c, in_pitch, out_pitch, kh, kw, up_x, up_y, down_x, down_y,
+                                                     px0, px1, py0, py1, _lib.stream_of(dev))
+        _lib.check(code, "msg_upfirdn2d_pitched2")
+        return out
     if c > 1 and x.stride(1) == 1 and not _is_channels_last(x):
         # a channel-slice of a channels-last buffer (e.g. the gradient of one piece of a concatenation): filtered in
         # place through the pitched entry point when its pitch allows, else compacted in the SAME layout (one copy)
@@ -155,13 +183,15 @@ def _flipped(fir: torch.Tensor) -> torch.Tensor:
 
 class UpFirDn2d(Function):
     @staticmethod
-    def forward(ctx, x, fir, up, down, pad):
+    def forward(ctx, x, fir, up, down, pad, out=None):
         up_x, up_y = up
         down_x, down_y = down
         px0, px1, py0, py1 = pad
         kh, kw = fir.shape
         h, w = x.shape[2:]
-        y = _launch(x, fir, up, down, pad)
+        y = _launch(x, fir, up, down, pad, out=out)
+        if out is not None:
+            y = out.view_as(out)                   # (a fresh alias: `out` itself is an input of this node)
         oh, ow = y.shape[2:]
         # padding of the adjoint pass (reference op_static/upfirdn2d.py:114-119)
         ctx.g_pad = (kw - px0 - 1, w * up_x - ow * down_x + px0 - up_x + 1,
@@ -175,12 +205,14 @@ class UpFirDn2d(Function):
         fir, fir_flipped = ctx.saved_tensors
         up, down, pad, in_hw = ctx.cfg
         gin = UpFirDn2dBackward.apply(grad_output, fir, fir_flipped, up, down, pad, ctx.g_pad, in_hw)
-        return gin, None, None, None, None
+        return gin, None, None, None, None, None
 
 
-def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
-    """FIR resampling of a [B,C,H,W] tensor; same arguments as the reference wrapper."""
-    return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0), out=None):
+    """FIR resampling of a [B,C,H,W] tensor; same arguments as the reference wrapper.  ``out`` (not in the reference): a
+    channels-last map, or a channel-slice of a wider one, that receives the result -- the piece of a channel
+    concatenation written in place; the returned tensor aliases it."""
+    return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]), out)
 
 
 def _blur_act_eligible(x, fir, pad):

@@ -18,6 +18,7 @@ from .op_static import attention as _attention
 
 FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
 COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
+IN_PLACE_CAT = bool(int(os.environ.get("MSG_IN_PLACE_CAT", "1")))           # 0: the decoder's concatenations copy their pieces (A/B; bit-identical)
 NATIVE_SOFTMAX = bool(int(os.environ.get("MSG_NATIVE_SOFTMAX", "1")))       # 0: ROCm library softmax in the non-local blocks (A/B)
 SHARE_PROJECTION_INPUT = bool(int(os.environ.get("MSG_SHARE_PROJECTION_INPUT", "1")))   # 0: four separate 1x1 convs in the non-local block (A/B)
 DEFER_MERGE_GAIN = bool(int(os.environ.get("MSG_DEFER_MERGE_GAIN", "1")))   # 0: the merge's backward rescales its gradient itself (A/B)
@@ -38,8 +39,9 @@ class Upsample(nn.Module):
         p = len(blur_kernel) - factor
         self.padding = ((p + 1) // 2 + factor - 1, p // 2)
 
-    def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return upfirdn2d(input, self.kernel, up=self.factor, pad=self.padding)
+    def forward(self, input: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out (not in the reference): the channel-slice of a concatenation buffer that receives the result."""
+        return upfirdn2d(input, self.kernel, up=self.factor, pad=self.padding, out=out)
 
 
 class Blur(nn.Module):
@@ -154,12 +156,14 @@ class ResNetBlock(nn.Module):
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         return self._merge(input, scaled_add)
 
-    def forward_forked(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_forked(self, input: torch.Tensor, out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """forward() for an output with two consumers (the skip connection and the downscale path): two aliases of the
-        result, so that their two gradients are merged and rescaled in one pass (op_static.scaled_add_fork)."""
-        return self._merge(input, scaled_add_fork)
+        result, so that their two gradients are merged and rescaled in one pass (op_static.scaled_add_fork).
+        out: where the result may be written (conv_ops.cat_destination: the skip's slice of the decoder's concatenated
+        map); used when the merge runs in the residual conv's epilogue -- the caller checks the returned tensor."""
+        return self._merge(input, scaled_add_fork, out=out)
 
-    def _merge(self, input: torch.Tensor, merge):
+    def _merge(self, input: torch.Tensor, merge, out: Optional[torch.Tensor] = None):
         conv1, act1, conv2, act2 = self.main_mapping            # conv -> bias + leaky ReLU fused per pair
         res = self.residual_mapping
         fuse_res = FUSE_RESIDUAL and isinstance(res, equalized_layer.EqualizedConv2d) and res.bias is None and \
@@ -179,7 +183,7 @@ class ResNetBlock(nn.Module):
             # (main + conv1x1(input)) / sqrt(2) in the epilogue of the 1x1 conv: no separate merge pass
             return conv_ops.conv2d_add_residual(x_res, res.weight, output, 1.0 / math.sqrt(2), stride=res.stride,
                                                 padding=res.padding, wscale=res.scale, fork=merge is scaled_add_fork,
-                                                grad_slot=slot, main_grad_scale=owed)
+                                                grad_slot=slot, main_grad_scale=owed, out=out)
         return merge(output, res(x_res), 1.0 / math.sqrt(2))
 
 
@@ -300,32 +304,65 @@ class Discriminator(nn.Module):
             for m in stats:
                 m.groups = 1
 
+    def _skip_destination(self, index: int, x: torch.Tensor, block: nn.Module):
+        """(buffer, [upsampled slice, skip slice]) of the decoder level that consumes encoder block `index`'s output, or
+        None when that level does not take the in-place form."""
+        if not (IN_PLACE_CAT and COMMUTE_UPSAMPLE and x.is_cuda):
+            return None
+        up = self.transposed_convolutions[len(self.transposed_convolutions) - 1 - index]
+        fir, mix = up[0], up[1]
+        if not (isinstance(fir, Upsample) and fir.factor == 2 and isinstance(mix, equalized_layer.EqualizedConv2d)
+                and mix.bias is None and mix.kernel_size == (1, 1) and mix.stride == (1, 1) and mix.padding == (0, 0)):
+            return None
+        conv2 = block.main_mapping[2]
+        return conv_ops.cat_destination(x.shape[0], (mix.weight.shape[0], conv2.weight.shape[0]), x.shape[2], x.shape[3],
+                                        x.dtype, x.device)
+
     def _forward(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if self.fft:
             input = append_spectra(input)
         x = input.flatten(start_dim=1, end_dim=2)
         x = conv_ops.to_compute_layout(x, self.compute_dtype)
-        skips = []
+        skips, dests = [], []
         last = len(self.encoder_blocks) - 1
         for index, block in enumerate(self.encoder_blocks):
             if index != last and hasattr(block, "forward_forked"):
-                skip, x = block.forward_forked(x)          # same tensor, two autograd edges (see forward_forked)
+                # The skip features are written where the decoder wants them: into their channel-slice of the map that
+                # the reference builds with torch.cat([upsampled, skip]) (u_net_2d_discriminator.py:128-131) -- the
+                # upsampling FIR later fills the other slice, and the concatenation is no copy at all.
+                dest = self._skip_destination(index, x, block)
+                skip, x = block.forward_forked(x, out=None if dest is None else dest[1][1])
+                if dest is not None and skip.data_ptr() != dest[1][1].data_ptr():
+                    dest = None                            # (the block took another path: plain concatenation later)
                 skips.append(skip)
+                dests.append(dest)
                 x = self.downscale_convolutions[index](x)
                 continue
             x = block(x)
             if index != last:
                 skips.append(x)
+                dests.append(None)
                 x = self.downscale_convolutions[index](x)
         classification = self.classification_head(x.float()) if x.dtype != torch.float32 else \
             self.classification_head(x)
-        for block, up, skip in zip(self.decoder_blocks, self.transposed_convolutions, reversed(skips)):
+        for block, up, skip, dest in zip(self.decoder_blocks, self.transposed_convolutions, reversed(skips), reversed(dests)):
             # `up` = Upsample (per-channel FIR) -> bias-free 1x1 conv (per-pixel channel mix): the two commute exactly, and
             # mixing the channels BEFORE upsampling runs the conv on a quarter of the pixels and the FIR on the (fewer)
             # output channels.  Same function as the reference's order (u_net_2d_discriminator.py:120-127) up to rounding.
             fir, mix = up[0], up[1]
             commute = COMMUTE_UPSAMPLE and isinstance(mix, equalized_layer.EqualizedConv2d) and mix.bias is None and \
                 mix.kernel_size == (1, 1) and mix.stride == (1, 1) and mix.padding == (0, 0)
+            if commute and IN_PLACE_CAT and x.is_cuda and isinstance(fir, Upsample):
+                low = mix(x)
+                if dest is None:                           # (skip produced elsewhere: it is copied, the FIR still writes in place)
+                    dest = conv_ops.cat_destination(skip.shape[0], (low.shape[1], skip.shape[1]), skip.shape[2],
+                                                    skip.shape[3], skip.dtype, skip.device)
+                if dest is not None and low.dtype == skip.dtype and \
+                        tuple(dest[1][0].shape) == (low.shape[0], low.shape[1], 2 * low.shape[2], 2 * low.shape[3]):
+                    x = block(conv_ops.cat_in_place(dest[0], [fir(low, out=dest[1][0]), skip]))
+                    continue
+                x = block(conv_ops.cat_channels([fir(low), skip]))
+                continue
             x = block(conv_ops.cat_channels([fir(mix(x)) if commute else up(x), skip]))
         pixel_wise = self.final_mapping(x).float().contiguous().unsqueeze(dim=2)
         return classification, pixel_wise

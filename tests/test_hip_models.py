@@ -78,6 +78,49 @@ def test_tiny_discriminator(golden):
         assert rel_err(params[key[len("tinyD.r1grad."):]].grad, z[key]) < TOL, key
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_discriminator_in_place_concatenation_is_bit_identical(dtype, monkeypatch):
+    """The decoder's torch.cat([upsampled, skip]) (u_net_2d_discriminator.py:128-131) with both pieces written into their
+    slices of the concatenated map by their producers (MSG_IN_PLACE_CAT, default) against the copying form: outputs,
+    input gradient and parameter gradients bit for bit, first order and through an R1-style second-order pass."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd import u_net_2d_discriminator as mod
+    from multi_stylegan_amd import conv_ops
+    cfg = {"encoder_channels": ((3, 16), (16, 32), (32, 48), (48, 64), (64, 64)),
+           "decoder_channels": ((96, 64), (80, 48), (64, 32), (32, 16)), "fft": False}
+    torch.manual_seed(5)
+    d = m.MultiStyleGANDiscriminator(cfg, no_rfp=True).to(DEV)
+    if dtype == torch.bfloat16:
+        d.compute_dtype = torch.bfloat16
+    x0 = torch.rand(4, 2, 3, 64, 64, device=DEV)
+    seen = []
+    orig = conv_ops.cat_in_place
+    monkeypatch.setattr(conv_ops, "cat_in_place", lambda buf, pieces: (seen.append(
+        [p.data_ptr() == buf[:, o:o + p.shape[1]].data_ptr() for p, o in zip(pieces, [0, pieces[0].shape[1]])]), orig(buf, pieces))[1])
+
+    def run(flag, second_order):
+        monkeypatch.setattr(mod, "IN_PLACE_CAT", flag)
+        d.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        s, px = d(x)
+        if second_order:
+            gin, = torch.autograd.grad(s.sum() + px.float().square().sum(), x, create_graph=True)
+            gin.square().sum().backward()
+            return [s.detach(), px.detach(), gin.detach()] + [p.grad.clone() for p in d.parameters() if p.grad is not None]
+        (s.sum() + px.float().square().sum()).backward()
+        return [s.detach(), px.detach(), x.grad.clone()] + [p.grad.clone() for p in d.parameters()]
+
+    for second_order in (False, True):
+        seen.clear()
+        a = run(True, second_order)
+        # three ResNet levels have BOTH pieces in place, the non-local level (its merge is not a conv epilogue) the FIR's
+        assert sorted(map(tuple, seen)) == [(True, False), (True, True), (True, True), (True, True)], seen
+        b = run(False, second_order)
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("no_rfp", [True, False])
 def test_discriminator_fft_input_matches_oracle(no_rfp):
     """The optional spectral input (config "fft": True; u_net_2d_discriminator.py:43-46,106-122): 3 C input channels

@@ -172,6 +172,36 @@ def test_upfirdn2d_on_channel_slices(cfg, dtype):
         assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 1, (2, 1)), (1, 1, (2, 1)), (1, 2, (1, 1))])
+def test_upfirdn2d_into_channel_slice(cfg, dtype):
+    """upfirdn2d(out=slice): the result written into its channel-slice of a wider channels-last map
+    (msg_upfirdn2d_pitched2) equals the dense result bit for bit, leaves the other channels alone, and the gradient is the
+    dense call's."""
+    ops = _ops()
+    up, down, pad = cfg
+    g = torch.Generator().manual_seed(3)
+    fir = torch.randn(4, 4, generator=g).to(DEV)
+    x = torch.randn(2, 16, 12, 10, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    ref = ops.upfirdn2d(x, fir, up=up, down=down, pad=pad)
+    oh, ow = ref.shape[2:]
+    for lo, total in ((0, 16), (0, 48), (16, 48), (24, 40)):
+        wide = torch.full((2, oh, ow, total), 7.0, device=DEV, dtype=dtype).permute(0, 3, 1, 2)
+        xr = x.clone().requires_grad_(True)
+        y = ops.upfirdn2d(xr, fir, up=up, down=down, pad=pad, out=wide[:, lo:lo + 16])
+        assert y.data_ptr() == wide[:, lo:lo + 16].data_ptr() and torch.equal(y, ref)
+        rest = torch.cat([wide[:, :lo], wide[:, lo + 16:]], dim=1)
+        assert bool((rest == 7.0).all())
+        gy = torch.randn(ref.shape, generator=g).to(DEV, dtype)
+        gx, = torch.autograd.grad(y, xr, gy)
+        xd = x.clone().requires_grad_(True)
+        gd, = torch.autograd.grad(ops.upfirdn2d(xd, fir, up=up, down=down, pad=pad), xd, gy)
+        assert torch.equal(gx, gd)
+    from multi_stylegan_amd._lib import MsgHipError
+    with pytest.raises(MsgHipError):                       # a destination that is not a channels-last slice
+        ops.upfirdn2d(x, fir, up=up, down=down, pad=pad, out=torch.empty(2, 16, oh, ow, device=DEV, dtype=dtype))
+
+
 def test_upfirdn2d_edge_cases():
     ops = _ops()
     from multi_stylegan_amd._lib import MsgHipError

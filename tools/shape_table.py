@@ -12,7 +12,7 @@ import sys
 
 line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
 d = json.loads(line)
-steps = d["steps"]
+steps = d.get("clock_iterations") or d["steps"]         # (bench.py --clock-only plain|regularised: fewer than steps)
 rows = []
 for k, v in d["kernels"].items():
     rate = v.get("TFLOP/s", v.get("GB/s"))

@@ -354,14 +354,21 @@ int msg_linear_grouped_dgrad(const float* gy, const float* const* w, float* gx, 
 int msg_linear_grouped_wgrad(const float* gy, const float* x, const int* slot, float* gw, float* gb, int G, int M, int N,
                              int K, int L, float gain, float bias_gain, void* stream);
 
-/* Which kernel msg_conv2d_fprop launches for a problem (no launch): 2 = 256x256 ping-pong, 1 = 128x128 with LDS-DMA
- * staging, 0 = 128x128 with register staging.  Used by bench.py to label per-kernel timings. */
+/* Which kernel msg_conv2d_fprop launches for a problem (no launch): 5 = the streaming kernels for 1x1 convolutions with
+ * <= 8 channels on one side (conv_thin.hip), 3 / 4 = 3x3 row-sharing kernel with the 256x256 / 128x128 tile, 2 = 256x256
+ * ping-pong, 1 = 128x128 with LDS-DMA staging, 0 = 128x128 with register staging.  Used by bench.py to label per-kernel timings. */
 int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                           int kh, int kw, long long w_batch_stride);
 /* 1 if msg_conv2d_fprop takes this problem to the activation-stationary sub-pixel up-convolution kernel (conv_upconv.hip:
  * K = 512, N = 4 * 512, per-sample weights, pixel-shuffled output, bf16), else 0.  For timing labels. */
 int msg_conv2d_fprop_upconv_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int kh, int kw,
                                      int stride, int pad, int in_up, int pixel_shuffle, long long w_batch_stride);
+/* 1 / 2 if msg_conv2d_fprop takes this bf16 problem to the streaming kernels of conv_thin.hip -- a 1x1 convolution to N <= 8
+ * output channels (1: the RGB heads multi_stylegan_generator.py:472-526, the pixel-wise head u_net_2d_discriminator.py:93-97)
+ * or from an 8-channel-padded input (2: their data gradients, the first block's residual conv) -- else 0.  act_mode: 0 = plain /
+ * bias, 1 = fused activation, 2 = residual merge (as msg_conv2d_fprop_act / _residual).  For timing labels and tests. */
+int msg_conv2d_fprop_thin_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy, int kh, int kw,
+                                   int stride, int pad, int in_up, int pixel_shuffle, int act_mode);
 
 /* ---------------------------------------------------------------------------
  * Adam over a flat fp32 store, optionally with an exponential moving average of the stepped parameters in the same pass

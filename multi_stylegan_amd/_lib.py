@@ -63,6 +63,7 @@ _SIGNATURES = {
     "msg_minibatch_stddev_backward": (_I, [_P, _P, _P, _P, _I] + [_I] * 8 + [_F, _P]),
     "msg_conv2d_fprop_plan": (_I, [_I] * 11 + [_L]),
     "msg_conv2d_fprop_upconv_eligible": (_I, [_I] * 14 + [_L]),
+    "msg_conv2d_fprop_thin_eligible": (_I, [_I] * 16),
     "msg_linear_fprop": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "msg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "msg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),

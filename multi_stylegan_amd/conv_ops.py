@@ -426,7 +426,10 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
     key = "conv_fprop"
     if _lib.kernel_clock.enabled:                       # label the timing with the kernel the library will pick
         plan = _lib.lib().msg_conv2d_fprop_plan(_lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, kh, kw, wstride)
-        key = ("conv_fprop_reg", "conv_fprop_dma", "conv_fprop_pp", "conv_fprop_row3", "conv_fprop_row3n")[plan]
+        key = ("conv_fprop_reg", "conv_fprop_dma", "conv_fprop_pp", "conv_fprop_row3", "conv_fprop_row3n",
+               "conv_fprop_thin")[plan]
+        if plan == 5 and act is not None:
+            key = "conv_fprop_reg"
         if x.dtype == torch.bfloat16 and bias is None and act is None and residual is None and \
                 _lib.lib().msg_conv2d_fprop_upconv_eligible(b, ih, iw, cx, ck, oh, ow, n, kh, kw, stride, pad, in_up,
                                                            int(pixel_shuffle), wstride):

@@ -416,11 +416,22 @@ extern "C" int msg_conv2d_fprop_upconv_try(const void* x, const void* w, const f
                                            int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                            int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
                                            long long w_batch_stride, const ActEpilogue* act, void* stream);
-// Which kernel msg_conv2d_fprop would launch for this problem: 3 / 4 = conv_fprop_row3_kernel<4,4> / <2,2> (3x3 'same' convs
+extern "C" int msg_conv2d_fprop_thin_try(const void* x, const void* w, const float* bias, void* y,
+                                         int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                         int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                         long long w_batch_stride, const ActEpilogue* act, void* stream);
+extern "C" int msg_conv2d_fprop_thin_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                              int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
+                                              int act_mode);
+// Which kernel msg_conv2d_fprop would launch for this problem: 5 = the streaming kernels of conv_thin.hip (1x1, <= 8 channels on
+// one side; assuming no fused activation), 3 / 4 = conv_fprop_row3_kernel<4,4> / <2,2> (3x3 'same' convs
 // on wide maps, activation tile shared by the horizontal taps; 256x256 / 128x128 tile), 2 = conv_fprop_pp_kernel (256x256 ping-pong),
 // 1 = conv_fprop_kernel<T, true> (128x128, LDS-DMA staging), 0 = conv_fprop_kernel<T, false> (register staging).
 extern "C" int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                      int kh, int kw, long long w_batch_stride) {
+    if (dtype == MSG_BF16 && msg_conv2d_fprop_thin_eligible(B, IH, IW, Cx, Ck, OH, OW, N, N <= 8 ? 8 : (N + 7) / 8 * 8, kh, kw, 1,
+                                                            0, 1, 0, 0))
+        return 5;
     if (dtype == MSG_BF16) {
         const int r3 = msg_conv2d_fprop_row3_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride);
         if (r3) return r3 == 1 ? 3 : 4;
@@ -483,6 +494,10 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     if (pixel_shuffle && (N % 4 || (N / 4) % vec || ldy % vec)) return MSG_EUNSUPPORTED;
     if (!pixel_shuffle && ldy % vec) return MSG_EUNSUPPORTED;
     if (in_up > 1 && stride != 1) return MSG_EUNSUPPORTED;
+    if (dtype == MSG_BF16 &&
+        msg_conv2d_fprop_thin_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up, pixel_shuffle,
+                                  w_batch_stride, &act, stream))
+        return MSG_CHECK_LAUNCH();                 // 1x1 convs with <= 8 channels on one side: streaming kernels (conv_thin.hip)
     if (dtype == MSG_BF16 &&
         msg_conv2d_fprop_upconv_try(x, w, bias, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, in_up,
                                     pixel_shuffle, w_batch_stride, &act, stream))

@@ -665,3 +665,46 @@ def test_activation_stationary_upconv_kernel(batch, hw):
     yr = torch.cat([torch.nn.functional.conv_transpose2d(xr[s:s + 1], wr[s].transpose(0, 1), stride=2) for s in range(batch)])
     gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.float())
     assert rel_err(gx.float(), gxr) < 2e-2 and rel_err(gw.float(), gwr) < 2e-2
+
+
+@pytest.mark.parametrize("case", [
+    # (batch, in, out, (h, w), per-sample weights, bias, residual merge)
+    (2, 512, 6, (64, 64), True, True, False),       # the generator's RGB heads (two streams, 3 + 3)
+    (2, 128, 1, (96, 80), False, False, False),     # the discriminator's pixel-wise head
+    (3, 128, 6, (67, 61), False, True, False),      # ragged pixel count
+    (2, 256, 8, (64, 64), True, False, False),
+    (2, 6, 512, (64, 64), True, False, False),      # data gradient of the RGB heads
+    (2, 6, 128, (96, 80), False, False, True),      # the first block's residual conv with the merge in its epilogue
+    (3, 1, 128, (67, 61), False, True, False),      # data gradient of the pixel-wise head, ragged
+    (2, 3, 64, (64, 64), False, False, False),
+])
+def test_thin_pointwise_conv_kernels(case):
+    """conv_thin.hip -- 1x1 convolutions with <= 8 channels on one side as streaming kernels: against fp32 torch on the same
+    bf16-rounded operands, bit-identical over repeated launches, pad channels of the output left zero."""
+    from multi_stylegan_amd import _lib, conv_ops
+    batch, i, o, (h, w_), per_sample, with_bias, with_res = case
+    torch.manual_seed(i * 7 + o)
+    x = conv_ops.to_compute_layout(torch.randn(batch, i, h, w_, device=DEV), torch.bfloat16)
+    shape = (batch, o, i, 1, 1) if per_sample else (o, i, 1, 1)
+    w = (torch.randn(*shape, device=DEV) / math.sqrt(i)).bfloat16().float()
+    bias = torch.randn(o, device=DEV) if with_bias else None
+    geo = conv_ops.Geometry("conv", 1, 1, 1, 0, (h, w_), per_sample)
+    xv, cx = conv_ops._nhwc_view(x)
+    ck = 64 * ((i + 63) // 64)
+    mode = _lib.lib().msg_conv2d_fprop_thin_eligible(batch, h, w_, cx, ck, h, w_, o, 8 * ((o + 7) // 8), 1, 1, 1, 0, 1, 0,
+                                                     2 if with_res else 0)
+    assert mode == (1 if o <= 8 else 2)                                   # (the kernels under test do run)
+    res = conv_ops.to_compute_layout(torch.randn(batch, o, h, w_, device=DEV), torch.bfloat16) if with_res else None
+    y = conv_ops._f_raw(x, w, bias, geo, residual=(res, 0.5) if with_res else None)
+    for _ in range(3):
+        assert torch.equal(y, conv_ops._f_raw(x, w, bias, geo, residual=(res, 0.5) if with_res else None))
+    if per_sample:
+        want = torch.cat([torch.nn.functional.conv2d(x[s:s + 1].float(), w[s], bias) for s in range(batch)])
+    else:
+        want = torch.nn.functional.conv2d(x.float(), w, bias)
+    if with_res:
+        want = (want.bfloat16().float() + res.float()) * 0.5
+    assert y.shape == want.shape and rel_err(y.float(), want) < 6e-3      # (bf16 output rounding; fp32 accumulation)
+    if o % 8:                                                             # the padded channel-vector behind the real outputs
+        base = y._base if y._base is not None else y
+        assert base.shape[-1] == 8 * ((o + 7) // 8) or base.shape[1] == 8 * ((o + 7) // 8)

@@ -87,6 +87,16 @@ int msg_upfirdn2d_separable_act(const void* x, const float* fir_y, const float* 
                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                 const float* act_bias, const float* noise, const float* noise_weight,
                                 int noise_batch, float alpha, float scale, void* stream);
+/* ... which also leaves the SIGN BYTES of its output for the activation's backward (bf16, minor % 8 == 0; mask may be NULL):
+ * mask [major * out_h * out_w][minor / 8] (tile 1 x minor in msg_bias_act_backward_mask's terms), bit e of byte
+ * (pixel, c / 8) = (y[pixel][c + e] > 0) -- everything
+ * FusedLeakyReLUFunctionBackward (op_static/fused_act.py:22-51) reads of `out`, at a sixteenth of its size; see
+ * msg_bias_act_backward_mask. */
+int msg_upfirdn2d_separable_act_mask(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                                     int major, int in_h, int in_w, int minor, int kh, int kw,
+                                     int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                     const float* act_bias, const float* noise, const float* noise_weight,
+                                     int noise_batch, float alpha, float scale, unsigned char* mask, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a2  fused bias + (noise) + leaky-ReLU -- replaces fused_act_cuda.fused_bias_act
@@ -129,6 +139,17 @@ int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
                           float* grad_bias, const float* noise, float* grad_noise_weight,
                           int noise_batch, int pix, float alpha, float scale,
                           float* ws, long long ws_floats, void* stream);
+/* msg_bias_act_backward for a channels-last bf16 map (step_b = 1, size_b % 8 == 0) whose forward launch left the sign
+ * bytes of its output (msg_conv2d_fprop_act_mask / msg_upfirdn2d_separable_act_mask): `mask` replaces `out` -- the pass
+ * moves 2 1/16 instead of 3 maps.  The bytes lie in the PRODUCER's tile order: tiles of tile_m consecutive pixels x tile_n
+ * channels one after the other, [tile_m][tile_n / 8] bytes each, pixel tiles outermost (a workgroup of the producer writes one
+ * contiguous block); tile 1 x size_b is the plain [pixel][size_b / 8] map.  Same results bit for bit (the bytes are the test
+ * `out > 0` on the stored values), same workspace (msg_bias_act_backward_workspace(size_x, 1, size_b, has_noise)). */
+int msg_bias_act_backward_mask(const void* gy, const unsigned char* mask, int tile_m, int tile_n, void* gx, int dtype,
+                               long long size_x, int size_b,
+                               float* grad_bias, const float* noise, float* grad_noise_weight,
+                               int noise_batch, int pix, float alpha, float scale,
+                               float* ws, long long ws_floats, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a3/a4  dense contractions on the matrix cores (channels-last, implicit GEMM).
@@ -318,6 +339,15 @@ int msg_conv2d_fprop_act(const void* x, const void* w, void* y, int dtype,
                          int kh, int kw, int stride, int pad, long long w_batch_stride,
                          const float* act_bias, const float* noise, const float* noise_weight,
                          int noise_batch, float alpha, float scale, void* stream);
+/* ... which also leaves the sign bytes of its output (see msg_upfirdn2d_separable_act_mask): mask, B * OH * OW * N / 8 bytes
+ * in the order of the kernel's output tiles (256 pixels x 256 channels for plan 3, 128 x 128 for plan 4: the tile_m / tile_n of
+ * msg_bias_act_backward_mask), or NULL.  Only the row-sharing 3x3 kernels write them (msg_conv2d_fprop_plan(...) == 3 or 4,
+ * bf16): any other problem with mask != NULL is MSG_EUNSUPPORTED -- ask the plan first. */
+int msg_conv2d_fprop_act_mask(const void* x, const void* w, void* y, int dtype,
+                              int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                              int kh, int kw, int stride, int pad, long long w_batch_stride,
+                              const float* act_bias, const float* noise, const float* noise_weight,
+                              int noise_batch, float alpha, float scale, unsigned char* mask, void* stream);
 
 /* msg_conv2d_fprop with the residual merge of a discriminator block fused into the epilogue:
  *   y = (conv(x, w) + residual) * gain        (u_net_2d_discriminator.py:185: (main + residual_mapping(x)) / sqrt(2))

@@ -288,15 +288,17 @@ def _relay_dgrad_s2(w: torch.Tensor, dtype, pad: int) -> Tuple[torch.Tensor, int
     assert kh == kw
     taps, pad2, table = _s2_plan(kh, pad)
     ok = _round_up(o, 128 // (2 if dtype == torch.bfloat16 else 4))
+    # one gather instead of a copy per (parity, tap): source tap index per (parity, tap), kh * kw = "no tap" (a zero plane)
+    src = [[(table[ph][th] * kw + table[pw][tw]) if table[ph][th] >= 0 and table[pw][tw] >= 0 else kh * kw
+            for th in range(taps) for tw in range(taps)] for ph in (0, 1) for pw in (0, 1)]
+    idx = torch.tensor(src, dtype=torch.long, device=w.device)                   # [4, taps^2]
+    wt = w.transpose(-4, -3).reshape(*lead, i, o, kh * kw)                       # [..., I, O, kh*kw]
+    wz = torch.cat([wt, wt.new_zeros((*lead, i, o, 1))], dim=-1)                 # (+ the zero plane)
+    picked = wz[..., idx]                                                        # [..., I, O, 4, taps^2]
+    n = len(lead)
+    picked = picked.permute(*range(n), n + 2, n, n + 3, n + 1)                   # [..., 4, I, taps^2, O]
     out = torch.zeros((*lead, 4, i, taps * taps, ok), dtype=dtype, device=w.device)
-    wt = w.transpose(-4, -3)                                   # [..., I, O, kh, kw]
-    for ph in (0, 1):
-        for pw in (0, 1):
-            for th in range(taps):
-                for tw in range(taps):
-                    fh, fw = table[ph][th], table[pw][tw]
-                    if fh >= 0 and fw >= 0:
-                        out[..., 2 * ph + pw, :, th * taps + tw, :o] = wt[..., fh, fw]
+    out[..., :o] = picked
     return out.reshape(*lead, 4 * i, taps * taps, ok), ok, taps, pad2
 
 
@@ -451,12 +453,22 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
                 ow, n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))
         else:
             assert bias is None and in_up == 1 and not pixel_shuffle
-            act_bias, noise, noise_w, alpha, scale = act
+            act_bias, noise, noise_w, alpha, scale = act[:5]
             _lib.require_gpu(x, act_bias, noise, noise_w)
-            code = _lib.lib().msg_conv2d_fprop_act(
+            mask = None
+            if len(act) > 5 and act[5] is not None and kh == 3 and stride == 1 and pad == 1:
+                # (act[5]: a list that receives the sign bytes of the output -- (bytes, tile_m, tile_n), the kernel's output
+                #  tile -- when the kernel this problem goes to writes them)
+                mplan = _lib.lib().msg_conv2d_fprop_plan(_lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, kh, kw, wstride)
+                if mplan in (3, 4):
+                    from .op_static.fused_act import sign_mask_for
+                    mask = sign_mask_for(b, n, oh, ow, x.dtype, dev)
+                    if mask is not None:
+                        act[5].append((mask, 256 if mplan == 3 else 128, 256 if mplan == 3 else 128))
+            code = _lib.lib().msg_conv2d_fprop_act_mask(
                 xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
                 stride, pad, wstride, _lib.ptr(act_bias), _lib.ptr(noise), _lib.ptr(noise_w),
-                1 if noise is None else noise.shape[0], float(alpha), float(scale), _lib.stream_of(dev))
+                1 if noise is None else noise.shape[0], float(alpha), float(scale), _lib.ptr(mask), _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_fprop")
     return y
 
@@ -750,7 +762,9 @@ class _ConvActF(Function):
     def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale, slot=None, out_scale=None):
         o = _oi(w)[0]
         b32, nz, nw = _act_operands(act_bias, noise, noise_w, (x.shape[0], o, *g.y_hw))
-        y = _f_raw(x, w, None, g, act=(b32, nz, nw, alpha, scale))
+        holder = [] if any(ctx.needs_input_grad) else None   # (a forward that no backward follows writes no sign bytes)
+        y = _f_raw(x, w, None, g, act=(b32, nz, nw, alpha, scale, holder))
+        ctx.mask = holder[0] if holder else None            # sign bytes of y, when the forward kernel wrote them
         ctx.slot, ctx.out_scale = slot, out_scale
         ctx.bias_param = act_bias
         ctx.g, ctx.cfg = g, (alpha, scale, act_bias is not None, noise is not None)
@@ -768,7 +782,8 @@ class _ConvActF(Function):
         if ctx.out_scale is not None and ctx.out_scale.pending is not None:
             owed, ctx.out_scale.pending = ctx.out_scale.pending, None        # (see GradScale: the consumer's gain, deferred)
         gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None,
-                                                             ctx.bias_param if has_bias else False, alpha, scale * owed)
+                                                             ctx.bias_param if has_bias else False, alpha, scale * owed,
+                                                             ctx.mask)
         gx = None
         if ctx.needs_input_grad[0]:
             other = ctx.slot.g if ctx.slot is not None else None
@@ -1482,9 +1497,10 @@ class _ModulatedConv(Function):
             _scale_rows_cols(base, None, s, wk, scale)
         g = Geometry(kind, kh, kw, 1, kh // 2, x.shape[2:], True)
         act = None
+        holder = [] if any(ctx.needs_input_grad) else None   # (a forward that no backward follows writes no sign bytes)
         if fuse_act:
             assert not upsample, "the upsampling layers blur before their activation"
-            act = (*_act_operands(act_bias, noise, noise_w, (b, o, *g.y_hw)), alpha, act_scale)
+            act = (*_act_operands(act_bias, noise, noise_w, (b, o, *g.y_hw)), alpha, act_scale, holder)
         if upsample:
             y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
         else:
@@ -1495,6 +1511,7 @@ class _ModulatedConv(Function):
         ctx.act = (alpha, act_scale, act_bias is not None, noise is not None,
                    None if noise_w is None else noise_w.shape) if fuse_act else None
         ctx.bias_param = act_bias
+        ctx.mask = holder[0] if holder else None            # sign bytes of y, when the forward kernel wrote them
         return y
 
     @staticmethod
@@ -1512,7 +1529,8 @@ class _ModulatedConv(Function):
             from .op_static.fused_act import FusedLeakyReLUFunctionBackward
             alpha, act_scale, has_bias, has_noise, nw_shape = ctx.act
             gy, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y_act, noise if has_noise else None,
-                                                               ctx.bias_param if has_bias else False, alpha, act_scale)
+                                                               ctx.bias_param if has_bias else False, alpha, act_scale,
+                                                               ctx.mask)
             gb = gb if has_bias and need[5] else None
             gnw = gnw.reshape(nw_shape) if has_noise and need[7] else None
         tail = (None, None, gb, None, gnw, None, None, None)

@@ -180,12 +180,15 @@ extern "C" int msg_fused_bias_act(const void* x, const float* bias, const void* 
 //
 // Channels-last: block = LC channel-vectors x (256/LC) pixel lanes; every lane keeps its VEC channels across its
 // pixel loop, partial sums meet in LDS and are added there in lane order.
-template <typename T, bool HAS_NOISE>
+// MASK: `out` is not read; the sign of the 8 outputs of a channel vector comes from one byte of the map the forward kernel
+// wrote beside its output (ActEpilogue::mask, msg_common.h): 2 + 1/16 instead of 3 passes' worth of traffic.
+template <typename T, bool HAS_NOISE, bool MASK = false>
 __global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restrict__ gy, const T* __restrict__ out,
                                                               T* __restrict__ gx, float* __restrict__ part_b,
                                                               const float* __restrict__ noise,
                                                               float* __restrict__ part_n, BiasActParams p,
-                                                              int lanes_c, long long npix, long long pix_per_block) {
+                                                              int lanes_c, long long npix, long long pix_per_block,
+                                                              int tile_m = 1, int tile_n = 8) {
     using V = Vec16<T>;
     constexpr int VEC = V::N;
     __shared__ float red[256 * VEC + 256];
@@ -197,14 +200,20 @@ __global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < VEC; ++e) sb[e] = 0.f;
     for (long long q = p0 + pl; q < p1; q += npl) {
+        // (no fused multiply-adds here: f[e] is stored AND summed; a product folded into the running sum in one instantiation
+        //  and not in the other would make the masked and the unmasked kernel differ in the sums' last bit)
+#pragma clang fp contract(off)
         const long long i = q * p.size_b + (long long)cv * VEC;
         V g, o, r;
         g.raw = *reinterpret_cast<const uint4*>(gy + i);
-        o.raw = *reinterpret_cast<const uint4*>(out + i);
+        unsigned int mbits = 0;
+        if constexpr (MASK) mbits = reinterpret_cast<const unsigned char*>(out)[act_mask_index(q, cv, p.size_b, tile_m, tile_n)];
+        else o.raw = *reinterpret_cast<const uint4*>(out + i);
         float f[VEC], rowsum = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            f[e] = g.get(e) * p.scale * ((o.get(e) > 0.f || p.act != 3) ? 1.f : p.alpha);
+            const bool pos = MASK ? ((mbits >> e) & 1u) != 0 : o.get(e) > 0.f;
+            f[e] = g.get(e) * p.scale * ((pos || p.act != 3) ? 1.f : p.alpha);
             sb[e] += f[e];
             rowsum += f[e];
         }
@@ -386,9 +395,10 @@ static BwdPlan bwd_plan(long long size_x, int step_b, int size_b, int vec) {
 
 template <typename T>
 static int bwd_dispatch(const void* gy, const void* out, void* gx, float* grad_bias, const float* noise,
-                        float* grad_nw, const BiasActParams& p, float* ws, long long ws_floats, hipStream_t s) {
+                        float* grad_nw, const BiasActParams& p, float* ws, long long ws_floats, hipStream_t s,
+                        bool mask = false, int tile_m = 1, int tile_n = 8) {
     constexpr int VEC = Vec16<T>::N;
-    const bool aligned = (((uintptr_t)gy | (uintptr_t)out | (uintptr_t)gx) & 15u) == 0;
+    const bool aligned = (((uintptr_t)gy | (mask ? 0 : (uintptr_t)out) | (uintptr_t)gx) & 15u) == 0;
     const bool has_noise = noise && grad_nw;
     BwdPlan q = bwd_plan(p.size_x, p.step_b, p.size_b, aligned ? VEC : (1 << 30));
     // workspace: [n_b][C] bias partials, then n_n noise partials
@@ -396,7 +406,16 @@ static int bwd_dispatch(const void* gy, const void* out, void* gx, float* grad_b
     if (need_b + need_n > 0 && (!ws || ws_floats < need_b + need_n)) return MSG_EINVAL;
     float* part_b = grad_bias ? ws : nullptr;
     float* part_n = has_noise ? ws + need_b : nullptr;
-    if (q.path == 0) {
+    if (mask && (q.path != 0 || VEC != 8)) return MSG_EUNSUPPORTED;     // sign bytes: one per 8-channel vector, channels-last
+    if (q.path == 0 && mask) {
+        dim3 grid(q.gx_blocks, (unsigned)q.gy_blocks);
+        if (has_noise)
+            hipLaunchKernelGGL((bias_act_bwd_cl_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
+                               (T*)gx, part_b, noise, part_n, p, q.lanes_c, q.npix, q.ppb, tile_m, tile_n);
+        else
+            hipLaunchKernelGGL((bias_act_bwd_cl_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
+                               (T*)gx, part_b, noise, part_n, p, q.lanes_c, q.npix, q.ppb, tile_m, tile_n);
+    } else if (q.path == 0) {
         dim3 grid(q.gx_blocks, (unsigned)q.gy_blocks);
         if (has_noise)
             hipLaunchKernelGGL((bias_act_bwd_cl_kernel<T, true>), grid, dim3(256), 0, s, (const T*)gy, (const T*)out,
@@ -467,6 +486,23 @@ extern "C" int msg_bias_act_backward(const void* gy, const void* out, void* gx, 
     if (dtype == MSG_BF16) return bwd_dispatch<bf16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, ws, ws_floats, s);
     if (dtype == MSG_F16) return bwd_dispatch<f16_t>(gy, out, gx, grad_bias, noise, grad_noise_weight, p, ws, ws_floats, s);
     return MSG_EUNSUPPORTED;
+}
+
+// msg_bias_act_backward for a channels-last bf16 map whose forward kernel left the sign bytes of its output
+// (msg_conv2d_fprop_act_mask, msg_upfirdn2d_separable_act_mask): `mask`, size_x / 8 bytes in the producer's tile order
+// (tile_m consecutive pixels x tile_n channels per tile; 1 x size_b = plain [pixel][size_b / 8]), replaces `out`.
+extern "C" int msg_bias_act_backward_mask(const void* gy, const unsigned char* mask, int tile_m, int tile_n, void* gx, int dtype,
+                                          long long size_x, int size_b,
+                                          float* grad_bias, const float* noise, float* grad_noise_weight,
+                                          int noise_batch, int pix, float alpha, float scale,
+                                          float* ws, long long ws_floats, void* stream) {
+    if (size_x <= 0 || size_b <= 0 || !gy || !mask || !gx || size_x % size_b) return MSG_EINVAL;
+    if (dtype != MSG_BF16 || size_b % 8) return MSG_EUNSUPPORTED;
+    if (tile_m <= 0 || tile_n <= 0 || tile_n % 8 || size_b % tile_n || (size_x / size_b) % tile_m) return MSG_EINVAL;
+    if (noise && grad_noise_weight && (pix <= 0 || noise_batch <= 0)) return MSG_EINVAL;
+    BiasActParams p{size_x, 1, size_b, noise_batch, pix, 3, 1, alpha, scale};
+    return bwd_dispatch<bf16_t>(gy, mask, gx, grad_bias, noise, grad_noise_weight, p, ws, ws_floats, (hipStream_t)stream, true,
+                                tile_m, tile_n);
 }
 
 // ---- y = (a + beta * b) * gain : the residual merges of the discriminator blocks ((main + residual) / sqrt(2),

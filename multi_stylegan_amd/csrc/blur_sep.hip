@@ -145,6 +145,13 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
                 for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
             }
             dst[c * p.CV] = o.raw;
+            if constexpr (ACT && VEC == 8) {
+                if (p.act.mask) {
+                    u32x4 pk;
+                    pk[0] = o.raw.x; pk[1] = o.raw.y; pk[2] = o.raw.z; pk[3] = o.raw.w;
+                    p.act.mask[(((long long)b * p.OH + oy) * p.OW + ox + c) * p.CV + cv] = (unsigned char)act_sign_byte(pk);
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -168,15 +175,25 @@ extern "C" int msg_upfirdn2d_separable(const void* x, const float* fir_y, const 
                            stream);
 }
 
+extern "C" int msg_upfirdn2d_separable_act_mask(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
+                                                int major, int in_h, int in_w, int minor, int kh, int kw,
+                                                int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                                const float* act_bias, const float* noise, const float* noise_weight,
+                                                int noise_batch, float alpha, float scale, unsigned char* mask, void* stream) {
+    if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != major))) return MSG_EINVAL;
+    if (mask && (dtype != MSG_BF16 || minor % 8)) return MSG_EUNSUPPORTED;
+    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale, nullptr, 0, 0.f, mask};
+    return blur_sep_launch(x, fir_y, fir_x, y, dtype, major, in_h, in_w, minor, kh, kw, pad_x0, pad_x1, pad_y0, pad_y1, act,
+                           stream);
+}
+
 extern "C" int msg_upfirdn2d_separable_act(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,
                                            int major, int in_h, int in_w, int minor, int kh, int kw,
                                            int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                            const float* act_bias, const float* noise, const float* noise_weight,
                                            int noise_batch, float alpha, float scale, void* stream) {
-    if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != major))) return MSG_EINVAL;
-    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale, nullptr, 0, 0.f};
-    return blur_sep_launch(x, fir_y, fir_x, y, dtype, major, in_h, in_w, minor, kh, kw, pad_x0, pad_x1, pad_y0, pad_y1, act,
-                           stream);
+    return msg_upfirdn2d_separable_act_mask(x, fir_y, fir_x, y, dtype, major, in_h, in_w, minor, kh, kw, pad_x0, pad_x1, pad_y0,
+                                            pad_y1, act_bias, noise, noise_weight, noise_batch, alpha, scale, nullptr, stream);
 }
 
 static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x, void* y, int dtype,

@@ -458,15 +458,29 @@ extern "C" int msg_conv2d_fprop(const void* x, const void* w, const float* bias,
                              pixel_shuffle, w_batch_stride, act, stream);
 }
 
+extern "C" int msg_conv2d_fprop_act_mask(const void* x, const void* w, void* y, int dtype,
+                                         int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                         int kh, int kw, int stride, int pad, long long w_batch_stride,
+                                         const float* act_bias, const float* noise, const float* noise_weight,
+                                         int noise_batch, float alpha, float scale, unsigned char* mask, void* stream) {
+    if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != B))) return MSG_EINVAL;
+    if (mask) {
+        // only the row-sharing 3x3 kernel writes the sign bytes: the caller asks msg_conv2d_fprop_plan first
+        const int plan = msg_conv2d_fprop_plan(dtype, B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride);
+        if (dtype != MSG_BF16 || N % 8 || stride != 1 || pad != 1 || (plan != 3 && plan != 4)) return MSG_EUNSUPPORTED;
+    }
+    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale, nullptr, 0, 0.f, mask};
+    return conv2d_fprop_impl(x, w, nullptr, y, dtype, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, 1, 0,
+                             w_batch_stride, act, stream);
+}
+
 extern "C" int msg_conv2d_fprop_act(const void* x, const void* w, void* y, int dtype,
                                     int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                     int kh, int kw, int stride, int pad, long long w_batch_stride,
                                     const float* act_bias, const float* noise, const float* noise_weight,
                                     int noise_batch, float alpha, float scale, void* stream) {
-    if (noise && (!noise_weight || (noise_batch != 1 && noise_batch != B))) return MSG_EINVAL;
-    ActEpilogue act{act_bias, noise, noise_weight, noise_batch, 1, alpha, scale, nullptr, 0, 0.f};
-    return conv2d_fprop_impl(x, w, nullptr, y, dtype, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, 1, 0,
-                             w_batch_stride, act, stream);
+    return msg_conv2d_fprop_act_mask(x, w, y, dtype, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, w_batch_stride,
+                                     act_bias, noise, noise_weight, noise_batch, alpha, scale, nullptr, stream);
 }
 
 extern "C" int msg_conv2d_fprop_residual(const void* x, const void* w, void* y, int dtype,

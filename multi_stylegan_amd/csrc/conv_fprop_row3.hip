@@ -471,6 +471,16 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                 const long long g = p.per_sample ? (long long)(gp[pass] - bz * ohw) : (long long)gp[pass];
                 if (gp[pass] >= 0) *reinterpret_cast<u32x4*>(ybase + g * p.ldy) = v[pass];
             }
+            if (p.act.enabled == 1 && p.act.mask) {
+                // sign bytes for the activation's backward, in this workgroup's own block of the map (act_mask_index with
+                // tile_m = HM, tile_n = HN; N % HN == 0 and whole tiles of pixels: eligibility)
+                const long long tile = (long long)((p.per_sample ? (long long)bz * ohw : 0) + m0) / HM * p.n_tiles + n0 / HN;
+                unsigned char* mb = p.act.mask + tile * (HM * (HN / 8)) + (wn * WN + ec) / 8;
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass)
+                    if (gp[pass] >= 0)
+                        mb[(wm * WM + half * 64 + pass * RPP + er) * (HN / 8)] = (unsigned char)act_sign_byte(v[pass]);
+            }
         } else if (n_ok) {
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {

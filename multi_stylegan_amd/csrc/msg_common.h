@@ -93,7 +93,35 @@ struct ActEpilogue {
     const void* residual;    // enabled == 2: a map shaped like the output (same pixels), channel pitch res_ld elements
     int res_ld;
     float res_gain;
+    unsigned char* mask;     // enabled == 1, bf16, optional: one byte per (pixel, 8-channel vector), bit e = (out[pixel][8 v + e] > 0):
+                             // what the activation's backward needs of the output, at a sixteenth of its size (kernels that
+                             // write it: conv_fprop_row3.hip, blur_sep.hip; the others ignore the field).  Layout: the
+                             // producer's OUTPUT TILES one after the other (act_mask_index below), so that a workgroup writes
+                             // one contiguous block instead of byte-granular pieces of lines it shares with other workgroups.
 };
+
+// Byte index of (global pixel q, channel vector cv) in the sign-byte map of a [pixels][C] output produced in tiles of
+// tile_m consecutive pixels x tile_n channels (tile_m = 1, tile_n = C: plain [pixel][C / 8]).
+__device__ __host__ __forceinline__ long long act_mask_index(long long q, int cv, int C, int tile_m, int tile_n) {
+    const int vpt = tile_n >> 3;                                 // vectors per tile row
+    const long long tm = q / tile_m;
+    const int r = (int)(q - tm * tile_m), tn = cv / vpt, c = cv - tn * vpt;
+    return ((tm * (C / tile_n) + tn) * tile_m + r) * vpt + c;
+}
+
+// The sign byte of 8 stored bf16 outputs (see ActEpilogue::mask): "> 0" on the ROUNDED values, i.e. exactly what a
+// backward pass reading the stored map tests -- a bf16 bit pattern is a positive number iff it is > 0 as a signed 16-bit
+// integer (NaN payloads aside, as there).
+__device__ __forceinline__ unsigned int act_sign_byte(u32x4 packed) {
+    unsigned int m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int w = (int)packed[k];
+        m |= ((short)(w & 0xffff) > 0 ? 1u : 0u) << (2 * k);
+        m |= (w >= 0x10000 ? 1u : 0u) << (2 * k + 1);
+    }
+    return m;
+}
 
 // (conv + residual) * gain on VEC storage elements, the arithmetic of scaled_add_kernel (bias_act.hip): the residual
 // merge of a discriminator block done in the epilogue of its 1x1 residual conv, bit-identical to the two-pass form.

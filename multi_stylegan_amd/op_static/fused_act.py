@@ -5,6 +5,8 @@ function default sqrt(2)).  ``fused_bias_noise_leaky_relu`` additionally folds t
 ``NoiseInjection`` (multi_stylegan_generator.py:288-292) into the same pass; its parameters stay where the
 reference keeps them (``noise_injection.weight``, ``activation.bias``).
 """
+import os
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -66,9 +68,21 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
     return y.reshape(shape) if y.shape != shape else y
 
 
+ACT_MASK = bool(int(os.environ.get("MSG_ACT_MASK", "1")))      # 0: the activation backward always reads the stored output (A/B; bit-identical)
+
+
+def sign_mask_for(b, c, h, w, dtype, device):
+    """Buffer for the sign bytes of a [b, c, h, w] channels-last bf16 activation output ([b*h*w, c/8] uint8) that the forward
+    kernels which can write them (msg_conv2d_fprop_act_mask, msg_upfirdn2d_separable_act_mask) fill beside the output:
+    all the activation's backward needs of it, at a sixteenth of the size.  None when the form does not apply."""
+    if not ACT_MASK or dtype != torch.bfloat16 or c % 8:
+        return None
+    return torch.empty((b * h * w, c // 8), dtype=torch.uint8, device=device)
+
+
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
-    def forward(ctx, grad_output, out, noise, need_bias, negative_slope, scale):
+    def forward(ctx, grad_output, out, noise, need_bias, negative_slope, scale, mask=None):
         # `need_bias` may be the bias PARAMETER itself: its slice of the flat gradient store then receives the sum directly
         # (conv_ops._grad_dest) and autograd's accumulation add of it disappears
         bias_param = need_bias if isinstance(need_bias, torch.Tensor) else None
@@ -104,12 +118,25 @@ class FusedLeakyReLUFunctionBackward(Function):
         if need_bias or noise is not None:
             need = _lib.lib().msg_bias_act_backward_workspace(g.numel(), step_b, channels, int(noise is not None))
         ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
-        with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
-            code = _lib.lib().msg_bias_act_backward(
-                g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g, True), g.numel(), step_b, channels,
-                _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
-                _lib.ptr(ws), need, _lib.stream_of(dev))
-        _lib.check(code, "msg_bias_act_backward")
+        if mask is not None and step_b == 1 and g.ndim == 4 and g.dtype == torch.bfloat16 and channels % 8 == 0 and \
+                mask[0].numel() * 8 == g.numel():
+            # the forward launch left the sign bytes of `out` (bytes, tile_m, tile_n): that map is not read again
+            mbytes, tile_m, tile_n = mask
+            nbytes = 2 * g.numel() * g.element_size() + mbytes.numel()
+            with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd_mask/{g.dtype}", nbytes):
+                code = _lib.lib().msg_bias_act_backward_mask(
+                    g.data_ptr(), mbytes.data_ptr(), int(tile_m), int(tile_n), gx.data_ptr(), _lib.dtype_code(g, True),
+                    g.numel(), channels,
+                    _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
+                    _lib.ptr(ws), need, _lib.stream_of(dev))
+            _lib.check(code, "msg_bias_act_backward_mask")
+        else:
+            with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
+                code = _lib.lib().msg_bias_act_backward(
+                    g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g, True), g.numel(), step_b, channels,
+                    _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
+                    _lib.ptr(ws), need, _lib.stream_of(dev))
+            _lib.check(code, "msg_bias_act_backward")
         ctx.save_for_backward(out, noise)
         ctx.cfg = (negative_slope, scale)
         gx = gx.reshape(grad_output.shape)
@@ -130,7 +157,7 @@ class FusedLeakyReLUFunctionBackward(Function):
                                   and gg_noise_weight.numel()) else None
         # linear in (gg_input, gg_bias, gg_noise_weight); the mask has zero derivative (reference fused_act.py:45-51)
         gg_out = _bias_act(gg_input, ggb, out, noise if ggw is not None else None, ggw, 1, negative_slope, scale)
-        return gg_out, None, None, None, None, None
+        return gg_out, None, None, None, None, None, None
 
 
 class FusedLeakyReLUFunction(Function):

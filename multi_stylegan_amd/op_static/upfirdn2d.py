@@ -248,12 +248,15 @@ class BlurBiasAct(Function):
             nz, nw = noise.detach().to(torch.float32).contiguous(), noise_w.detach().to(torch.float32).contiguous()
         key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up1down1/sep+act"    # blur + activation: own key
         nbytes = (x.numel() + y.numel()) * x.element_size() + (0 if nz is None else nz.numel() * 4)
+        from .fused_act import sign_mask_for
+        mask = sign_mask_for(b, c, oh, ow, x.dtype, dev) if any(ctx.needs_input_grad) else None   # (no backward: no bytes)
         with _lib.on_device(dev), _lib.kernel_clock.span(key, nbytes):
-            code = _lib.lib().msg_upfirdn2d_separable_act(
+            code = _lib.lib().msg_upfirdn2d_separable_act_mask(
                 x.data_ptr(), fy.data_ptr(), fx.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, h, w, c, 4, 4,
                 px0, px1, py0, py1, _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(nw), 1 if nz is None else nz.shape[0],
-                float(alpha), float(scale), _lib.stream_of(dev))
-        _lib.check(code, "msg_upfirdn2d_separable_act")
+                float(alpha), float(scale), _lib.ptr(mask), _lib.stream_of(dev))
+        _lib.check(code, "msg_upfirdn2d_separable_act_mask")
+        ctx.mask = None if mask is None else (mask, 1, c)      # (plain [pixel][c / 8] order)
         ctx.g_pad = (4 - px0 - 1, w - ow + px0, 4 - py0 - 1, h - oh + py0)
         ctx.cfg = (pad, (h, w), float(alpha), float(scale), bias is not None, noise is not None,
                    None if noise_w is None else noise_w.shape)
@@ -265,7 +268,8 @@ class BlurBiasAct(Function):
         from .fused_act import FusedLeakyReLUFunctionBackward
         fir, fir_flipped, y, noise = ctx.saved_tensors
         pad, in_hw, alpha, scale, has_bias, has_noise, nw_shape = ctx.cfg
-        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha, scale)
+        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha, scale,
+                                                             ctx.mask)
         gin = UpFirDn2dBackward.apply(gpre, fir, fir_flipped, (1, 1), (1, 1), pad, ctx.g_pad, in_hw) \
             if ctx.needs_input_grad[0] else None
         return gin, None, None, (gb if has_bias and ctx.needs_input_grad[3] else None), None, \

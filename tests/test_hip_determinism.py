@@ -228,3 +228,55 @@ def test_ada_warp_backward_is_deterministic():
         assert abs(lhs - rhs) <= 1e-5 * abs(lhs), (padding, float(lhs), float(rhs))
         keep = (u > p)                                                 # images that were copied through: gradient == g exactly
         assert keep.any() and torch.equal(first[keep], g[keep])
+
+
+@pytest.mark.parametrize("kind", ["conv_act_128", "modconv_act_512", "blur_act"])
+def test_activation_backward_from_sign_bytes_is_bit_identical(kind, monkeypatch):
+    """The forward kernels that can (row-sharing 3x3 conv, blur + activation) leave one sign byte per 8 output channels, and
+    the activation's backward reads those instead of the stored output (msg_bias_act_backward_mask): every gradient bit for
+    bit what the form that re-reads the output gives (MSG_ACT_MASK=0), and the masked kernel is the one that ran."""
+    from multi_stylegan_amd import _lib, conv_ops
+    from multi_stylegan_amd.op_static import fused_act, blur_bias_act
+    torch.manual_seed(13)
+    bf = torch.bfloat16
+
+    def run(flag):
+        monkeypatch.setattr(fused_act, "ACT_MASK", flag)
+        torch.manual_seed(14)
+        if kind == "conv_act_128":
+            x = conv_ops.to_compute_layout(torch.randn(4, 128, 128, 128, device=DEV), bf).requires_grad_(True)
+            w = (torch.randn(128, 128, 3, 3, device=DEV) / 34).requires_grad_(True)
+            bias = torch.randn(128, device=DEV).requires_grad_(True)
+            y = conv_ops.conv2d_bias_act(x, w, bias, padding=1, scale=math.sqrt(2))
+            leaves = (x, w, bias)
+        elif kind == "modconv_act_512":
+            x = conv_ops.to_compute_layout(torch.randn(8, 512, 64, 64, device=DEV), bf).requires_grad_(True)
+            w = torch.randn(1, 512, 512, 3, 3, device=DEV).requires_grad_(True)
+            style = (1 + 0.1 * torch.randn(8, 512, device=DEV)).requires_grad_(True)
+            bias = torch.randn(512, device=DEV).requires_grad_(True)
+            noise = torch.randn(8, 1, 64, 64, device=DEV)
+            nw = torch.full((1,), 0.3, device=DEV, requires_grad=True)
+            y = conv_ops.modulated_conv2d_bias_act(x, w, style, True, bias, noise, nw, scale=math.sqrt(2))
+            leaves = (x, w, style, bias, nw)
+        else:
+            x = conv_ops.to_compute_layout(torch.randn(2, 64, 33, 33, device=DEV), bf).requires_grad_(True)
+            fir = (torch.outer(torch.tensor([1., 3., 3., 1.]), torch.tensor([1., 3., 3., 1.])) / 16).to(DEV)
+            bias = torch.randn(64, device=DEV).requires_grad_(True)
+            noise = torch.randn(2, 1, 32, 32, device=DEV)
+            nw = torch.full((1,), 0.3, device=DEV, requires_grad=True)
+            y = blur_bias_act(x, fir, (1, 1), bias, noise, nw, scale=math.sqrt(2))
+            leaves = (x, bias, nw)
+        gy = torch.randn(y.shape, device=DEV).to(bf).contiguous(memory_format=torch.channels_last)
+        _lib.kernel_clock.reset(enabled=True)
+        grads = torch.autograd.grad(y, leaves, gy)
+        torch.cuda.synchronize()
+        keys = set(_lib.kernel_clock.summary())
+        _lib.kernel_clock.reset(enabled=False)
+        return y.detach(), grads, keys
+
+    y1, g1, k1 = run(True)
+    y0, g0, k0 = run(False)
+    assert any(k.startswith("bias_act_bwd_mask/") for k in k1) and not any(k.startswith("bias_act_bwd_mask/") for k in k0)
+    assert torch.equal(y1, y0)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)

@@ -11,6 +11,7 @@
 // A workgroup moves a 32 (o) x 32 (i) x T tile through LDS: the read is contiguous along (i, t), the forward image is
 // written contiguous along i and the gradient image contiguous along o.
 #include "msg_common.h"
+#include <stdlib.h>
 
 constexpr int RL_T = 16;                      // max taps held per tile (kernels up to 4x4)
 
@@ -148,6 +149,46 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const T* __restrict__ 
     }
 }
 
+// The same for the case that matters (the discriminator's first layer: 3x3, pad 1, <= 8 channels stored as ONE 16-byte
+// vector per pixel, bf16, map width a multiple of 32): a workgroup stages the 3 x 34 input vectors that 32 consecutive
+// pixels of an image row need in LDS -- 102 coalesced 16-byte loads -- and every thread assembles one output vector from
+// eight 2-byte LDS reads.  The generic kernel above issues eight 2-byte GLOBAL loads per output vector and is bound by their
+// issue rate (1.7 TB/s of stores on 6 channels @256^2); this one by its stores.
+__global__ __launch_bounds__(256) void gather_taps3x3_lds_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H,
+                                                                 int W, int C, long long n_seg) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[3 * 34 * 8];
+    const int tid = threadIdx.x, p = tid >> 3, v = tid & 7;
+    int off[8];                                                  // LDS element offset of this thread's 8 (tap, channel) pairs, -1: zero
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = v * 8 + e, t = k / C, c = k - t * C;
+        off[e] = t < 9 ? ((t / 3) * 34 + p + t % 3) * 8 + c : -1;
+    }
+    const int segs_per_row = W / 32;
+    for (long long seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const long long row = seg / segs_per_row;                // (b, h) row of the batch
+        const int w0 = (int)(seg - row * segs_per_row) * 32;
+        const int h = (int)(row % H);
+        __syncthreads();                                         // (the previous segment's reads are done)
+        if (tid < 102) {
+            const int r = tid / 34, col = tid - r * 34;
+            const int ih = h + r - 1, iw = w0 + col - 1;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                val = *reinterpret_cast<const uint4*>(x + ((row - h + ih) * W + iw) * 8);
+            *reinterpret_cast<uint4*>(tile + tid * 8) = val;
+        }
+        __syncthreads();
+        unsigned int o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned lo = off[2 * e] >= 0 ? tile[off[2 * e]] : 0u, hi = off[2 * e + 1] >= 0 ? tile[off[2 * e + 1]] : 0u;
+            o[e] = lo | (hi << 16);
+        }
+        *reinterpret_cast<uint4*>(y + ((row * W + w0 + p) * 8 + v) * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 extern "C" int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, int W, int Cx, int C, int kh, int kw,
                                int pad, int Ko, void* stream) {
     if (B == 0) return MSG_OK;
@@ -159,6 +200,14 @@ extern "C" int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, 
     const long long total = (long long)B * H * W * (Ko / vec);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipStream_t s = (hipStream_t)stream;
+    static int lds_path = -1;
+    if (lds_path < 0) { const char* e = getenv("MSG_GATHER_LDS"); lds_path = e ? atoi(e) : 1; }
+    if (lds_path && dtype == MSG_BF16 && kh == 3 && kw == 3 && pad == 1 && Cx == 8 && Ko == 64 && W % 32 == 0) {
+        const long long n_seg = (long long)B * H * (W / 32);
+        const unsigned nb = (unsigned)(n_seg < 16384 ? n_seg : 16384);
+        hipLaunchKernelGGL(gather_taps3x3_lds_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, n_seg);
+        return MSG_CHECK_LAUNCH();
+    }
     if (dtype == MSG_BF16)
         hipLaunchKernelGGL((gather_taps_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W,
                            Cx, C, kh, kw, pad, Ko);

@@ -708,3 +708,25 @@ def test_thin_pointwise_conv_kernels(case):
     if o % 8:                                                             # the padded channel-vector behind the real outputs
         base = y._base if y._base is not None else y
         assert base.shape[-1] == 8 * ((o + 7) // 8) or base.shape[1] == 8 * ((o + 7) // 8)
+
+
+@pytest.mark.parametrize("shape", [(3, 6, 40, 64), (2, 6, 5, 32), (1, 3, 33, 96), (2, 7, 16, 128), (2, 6, 12, 20)])
+def test_gather_taps_kernels(shape):
+    """msg_gather_taps (the 3x3 taps of a <= 8-channel input laid out as ONE 128-byte K run per pixel, the form the
+    discriminator's first layer contracts): the LDS-staged kernel for map widths that are multiples of 32 and the generic
+    one (last shape) against the definition, exactly; and the conv built on it against torch."""
+    from multi_stylegan_amd import conv_ops
+    b, c, h, w_ = shape
+    torch.manual_seed(h)
+    x = torch.randn(b, c, h, w_, device=DEV).bfloat16()
+    geo = conv_ops.Geometry("conv", 3, 3, 1, 1, (h, w_), False)
+    got, ko = conv_ops._gather_taps(conv_ops.to_compute_layout(x), c, geo)
+    assert ko == 64 and got.shape == (b, 64, h, w_)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
+    want = torch.zeros(b, 64, h, w_, device=DEV, dtype=torch.bfloat16)
+    for t in range(9):
+        want[:, t * c:(t + 1) * c] = xp[:, :, t // 3:t // 3 + h, t % 3:t % 3 + w_]
+    assert torch.equal(got, want)
+    wgt = (torch.randn(16, c, 3, 3, device=DEV) / 7).bfloat16().float()
+    y = conv_ops.conv2d(conv_ops.to_compute_layout(x), wgt, padding=1)
+    assert rel_err(y.float(), torch.nn.functional.conv2d(x.float(), wgt, padding=1)) < 1e-2

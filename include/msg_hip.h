@@ -383,6 +383,10 @@ int msg_linear_grouped_dgrad(const float* gy, const float* const* w, float* gx, 
                              void* stream);
 int msg_linear_grouped_wgrad(const float* gy, const float* x, const int* slot, float* gw, float* gb, int G, int M, int N,
                              int K, int L, float gain, float bias_gain, void* stream);
+/* msg_linear_grouped_wgrad with one destination per layer: gw / gb are DEVICE arrays of G device pointers ([N][K] / [N] each;
+ * gb may be NULL) -- the layers' slices of a flat gradient store, so that no per-layer accumulation copy follows. */
+int msg_linear_grouped_wgrad_ptrs(const float* gy, const float* x, const int* slot, float* const* gw, float* const* gb, int G,
+                                  int M, int N, int K, int L, float gain, float bias_gain, void* stream);
 
 /* Which kernel msg_conv2d_fprop launches for a problem (no launch): 5 = the streaming kernels for 1x1 convolutions with
  * <= 8 channels on one side (conv_thin.hip), 3 / 4 = 3x3 row-sharing kernel with the 256x256 / 128x128 tile, 2 = 256x256

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "msg_linear_grouped_fprop": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "msg_linear_grouped_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "msg_linear_grouped_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "msg_linear_grouped_wgrad_ptrs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
 }
 
 

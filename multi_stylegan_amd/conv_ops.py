@@ -1168,17 +1168,45 @@ class _GroupedLinear(Function):
             # layers that read the same latent slot: gather + ordered sum (index_add_ adds with float atomics, i.e. in an
             # order that changes from run to run)
             glat = gx[_slot_gather_table(slot, l, dev)].sum(dim=1).transpose(0, 1)
-        gw = gb = None
+        grads_w, grads_b = [None] * g, [None] * g
         if any(need[4:]):
-            gw = torch.empty((g, n, k), dtype=torch.float32, device=dev)
-            gb = torch.empty((g, n), dtype=torch.float32, device=dev)
-            with _lib.on_device(dev):
-                code = _lib.lib().msg_linear_grouped_wgrad(gy.data_ptr(), lat.data_ptr(), slot_t.data_ptr(), gw.data_ptr(),
-                                                           gb.data_ptr(), g, b, n, k, l, wscale, bias_scale,
-                                                           _lib.stream_of(dev))
-            _lib.check(code, "msg_linear_grouped_wgrad")
-        grads_w = [gw[j] if need[4 + j] else None for j in range(g)]
-        grads_b = [gb[j] if need[4 + g + j] else None for j in range(g)]
+            # every layer's results go straight to the parameter's slice of the flat gradient store where that is free
+            # (_grad_dest), into a stacked buffer otherwise: one launch either way, and no per-layer accumulation copy
+            gw = gb = None
+            dw, db, direct = [], [], 0
+            for j in range(g):
+                tw = _grad_dest(ws[j]) if need[4 + j] else None
+                tb = _grad_dest(bs[j]) if need[4 + g + j] else None
+                direct += (tw is not None) + (tb is not None)
+                if tw is None:
+                    if gw is None:
+                        gw = torch.empty((g, n, k), dtype=torch.float32, device=dev)
+                    tw = gw[j]
+                if tb is None:
+                    if gb is None:
+                        gb = torch.empty((g, n), dtype=torch.float32, device=dev)
+                    tb = gb[j]
+                dw.append(tw)
+                db.append(tb)
+            if direct == 0:
+                # no destination in the flat store at all (no armed reducer): the stacked form, no pointer table to ship
+                with _lib.on_device(dev):
+                    code = _lib.lib().msg_linear_grouped_wgrad(gy.data_ptr(), lat.data_ptr(), slot_t.data_ptr(), gw.data_ptr(),
+                                                               gb.data_ptr(), g, b, n, k, l, wscale, bias_scale,
+                                                               _lib.stream_of(dev))
+                _lib.check(code, "msg_linear_grouped_wgrad")
+            else:
+                if gw is None and gb is None:
+                    tbl = _ptr_table(dw + db, dev).view(2, g)     # (flat-store addresses: stable, the table is cached)
+                else:
+                    tbl = torch.tensor([[t.data_ptr() for t in dw], [t.data_ptr() for t in db]], dtype=torch.int64).to(dev)
+                with _lib.on_device(dev):
+                    code = _lib.lib().msg_linear_grouped_wgrad_ptrs(gy.data_ptr(), lat.data_ptr(), slot_t.data_ptr(),
+                                                                    tbl[0].data_ptr(), tbl[1].data_ptr(), g, b, n, k, l,
+                                                                    wscale, bias_scale, _lib.stream_of(dev))
+                _lib.check(code, "msg_linear_grouped_wgrad_ptrs")
+            grads_w = [dw[j] if need[4 + j] else None for j in range(g)]
+            grads_b = [db[j] if need[4 + g + j] else None for j in range(g)]
         return (glat, None, None, None, *grads_w, *grads_b)
 
 

@@ -182,6 +182,16 @@ __global__ __launch_bounds__(256) void linear_grouped_wgrad_kernel(const float* 
                       gb ? gb + (size_t)g * N : nullptr, M, N, K, gain, bias_gain);
 }
 
+// ... with one destination pointer per layer (the layers' slices of a flat gradient store) instead of stacked results
+__global__ __launch_bounds__(256) void linear_grouped_wgrad_ptrs_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                        const int* __restrict__ slot, float* const* __restrict__ gw,
+                                                                        float* const* __restrict__ gb, int M, int N, int K, int L,
+                                                                        float gain, float bias_gain) {
+    const int g = blockIdx.y;
+    linear_wgrad_body(gy + (size_t)g * M * N, x + (size_t)slot[g] * K, (long long)L * K, gw[g], gb ? gb[g] : nullptr, M, N, K,
+                      gain, bias_gain);
+}
+
 static bool lin_bad(const void* a, const void* b, const void* c, int M, int N, int K) {
     return !a || !b || !c || M < 0 || N <= 0 || K <= 0;
 }
@@ -242,6 +252,18 @@ extern "C" int msg_linear_grouped_wgrad(const float* gy, const float* x, const i
     if (G == 0) return MSG_OK;
     if (M <= 0 || lin_bad(gy, x, gw, M, N, K) || !slot || G < 0 || L <= 0 || G > 65535) return MSG_EINVAL;
     hipLaunchKernelGGL(linear_grouped_wgrad_kernel, dim3(N, G), dim3(256), 0, (hipStream_t)stream, gy, x, slot, gw, gb,
+                       M, N, K, L, gain, bias_gain);
+    return MSG_CHECK_LAUNCH();
+}
+
+// msg_linear_grouped_wgrad writing layer g's results to gw[g] ([N][K]) and gb[g] ([N]; gb may be NULL): device arrays of G
+// device pointers -- the parameters' own slices of a flat gradient store, so that no per-layer copy follows.
+extern "C" int msg_linear_grouped_wgrad_ptrs(const float* gy, const float* x, const int* slot, float* const* gw,
+                                             float* const* gb, int G, int M, int N, int K, int L, float gain, float bias_gain,
+                                             void* stream) {
+    if (G == 0) return MSG_OK;
+    if (M <= 0 || lin_bad(gy, x, gw, M, N, K) || !slot || G < 0 || L <= 0 || G > 65535) return MSG_EINVAL;
+    hipLaunchKernelGGL(linear_grouped_wgrad_ptrs_kernel, dim3(N, G), dim3(256), 0, (hipStream_t)stream, gy, x, slot, gw, gb,
                        M, N, K, L, gain, bias_gain);
     return MSG_CHECK_LAUNCH();
 }

@@ -284,6 +284,8 @@ int msg_nonlocal_attention_fwd(const void* q, const void* k, const void* vt, voi
 /* msg_nonlocal_attention_bwd_splits: in how many parts the dK / dV kernel splits its query sweep for this problem; when
  * it is more than 1 the caller passes `workspace` with splits * B * Nk * (dk + dv) floats (scratch, fully overwritten). */
 int msg_nonlocal_attention_bwd_splits(int B, int Nq, int Nk);
+/* (qt and dOt -- transposed copies of q and dO -- are no longer read and may be NULL: the dK / dV kernel takes Q^T and dO^T
+ *  out of the row-major tiles with transposing LDS reads.  kt, the small [B, dk, Nk] copy of k, is still an operand.) */
 int msg_nonlocal_attention_bwd(const void* q, const void* qt, const void* k, const void* kt, const void* v,
                                const void* dO, const void* dOt, const void* o, const float* lse, float* delta,
                                void* dq, void* dk_out, void* dv_out, float* workspace, int dtype,

@@ -56,6 +56,23 @@ template <> struct Mma<bf16_t> {
         v.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
         *reinterpret_cast<uint2*>(p) = v;
     }
+    // The fragment load(row (col + r) of the TRANSPOSE, s, h) would give -- column col + (lane & 31) of `tile`, rows
+    // 16 s + 8 h .. + 7 -- taken from the row-major tile itself with gfx950's transposing LDS read (ds_read_b64_tr_b16: a
+    // 16-lane group reads a 4-row x 16-column block, each lane receives its column's 4 rows; conv_wgrad.hip has the lane
+    // algebra).  pitch in elements, a multiple of 4.
+    static __device__ __forceinline__ Frag load_t(const bf16_t* tile, int pitch, int col, int s, int lane) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+        const int kb = 8 * (g >> 1), cb = 16 * (g & 1);
+        s16x4 part[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bf16_t* pa = tile + (16 * s + kb + 4 * half + q) * pitch + col + cb + 4 * pq;
+            part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+        }
+        return __builtin_bit_cast(Frag, (s16x8)__builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7));
+    }
 };
 template <> struct Mma<float> {
     typedef float Frag;
@@ -69,6 +86,9 @@ template <> struct Mma<float> {
     static __device__ __forceinline__ float dot(Frag a, Frag b) { return a * b; }
     static __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
         *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+    }
+    static __device__ __forceinline__ Frag load_t(const float* tile, int pitch, int col, int s, int lane) {
+        return tile[(2 * s + (lane >> 5)) * pitch + col + (lane & 31)];       // (one element per lane: nothing to transpose)
     }
 };
 
@@ -304,7 +324,9 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const T* __restrict_
 //      (keys x queries) written to the key tile's LDS scratch;
 //   2. they share its OUTPUT: wave `half` accumulates dV^T for half of the dv range and one 32-row tile of dK^T.
 // Half the accumulators per wave (<= 168 registers: two waves per SIMD, which is what hides the LDS and staging latency
-// here) at the staging traffic of a 128-key block.
+// here) at the staging traffic of a 128-key block.  The operands of stage 2 whose contraction index (the query) is the slow
+// one of their natural layout -- dO^T and Q^T -- are read out of the row-major Q / dO tiles with transposing LDS reads
+// (Mma::load_t); the transposed global copies the caller used to make (and the second pair of tiles) are gone.
 template <typename T, int DK, int DV, int QB>
 __global__ __launch_bounds__(512) void nl_attn_bwd_kv_kernel(const T* __restrict__ q, const T* __restrict__ qt,
                                                             const T* __restrict__ k, const T* __restrict__ v,
@@ -319,12 +341,12 @@ __global__ __launch_bounds__(512) void nl_attn_bwd_kv_kernel(const T* __restrict
     static_assert(NT % 2 == 0 && MT <= 2, "the two waves of a key tile split the dv range and the dk tiles");
     constexpr int QP = DK + PAD, OP = DV + PAD, TP = QB + PAD;
     constexpr int STAT_T = (2 * QB * (int)sizeof(float)) / (int)sizeof(T);     // Ls + Ds in units of T
-    __shared__ __attribute__((aligned(16))) T smem[QB * QP + QB * OP + 32 * MT * TP + DV * TP + STAT_T + 2 * 4 * 32 * TP];
+    // (Qs rows are read up to column 32 MT - 1 by the transposing reads: columns >= DK belong to output rows that are never
+    //  stored; the slack behind the last row keeps those reads inside the array)
+    __shared__ __attribute__((aligned(16))) T smem[QB * QP + 64 + QB * OP + STAT_T + 2 * 4 * 32 * TP];
     T* Qs = smem;                       // [QB][QP]      queries x dk
-    T* dOs = Qs + QB * QP;              // [QB][OP]      queries x dv
-    T* Qts = dOs + QB * OP;             // [32 MT][TP]   dk x queries (Q^T), rows >= DK stay zero
-    T* dOts = Qts + 32 * MT * TP;       // [DV][TP]      dv x queries (dO^T)
-    float* Ls = reinterpret_cast<float*>(dOts + DV * TP);
+    T* dOs = Qs + QB * QP + 64;         // [QB][OP]      queries x dv
+    float* Ls = reinterpret_cast<float*>(dOs + QB * OP);
     float* Ds = Ls + QB;
     T* Pts = reinterpret_cast<T*>(Ds + QB);    // [4][32][TP]  per key tile: keys x queries (P^T)
     T* dSts = Pts + 4 * 32 * TP;               // [4][32][TP]  per key tile: keys x queries (dS^T)
@@ -333,12 +355,9 @@ __global__ __launch_bounds__(512) void nl_attn_bwd_kv_kernel(const T* __restrict
     const int b = blockIdx.y, key0 = blockIdx.x * 128 + kt * 32;
     const long long ki = (long long)b * Nk + key0 + r;
     const T* qb = q + (long long)b * Nq * DK;
-    const T* qtb = qt + (long long)b * DK * Nq;
     const T* dob = dO + (long long)b * Nq * DV;
-    const T* dotb = dOt + (long long)b * DV * Nq;
     T* Ptw = Pts + kt * 32 * TP;
     T* dStw = dSts + kt * 32 * TP;
-    for (int c = tid; c < 32 * MT * TP; c += 512) Qts[c] = T(0);
     typename M::Frag kf[KSQ], vf[KSV];
 #pragma unroll
     for (int s = 0; s < KSQ; ++s) kf[s] = M::load(k + ki * DK, s, h);
@@ -354,12 +373,8 @@ __global__ __launch_bounds__(512) void nl_attn_bwd_kv_kernel(const T* __restrict
         __syncthreads();
         Stager<T, QB, DK, false, 512> qst;
         Stager<T, QB, DV, false, 512> ost;
-        Stager<T, DK, QB, false, 512> qtst;
-        Stager<T, DV, QB, false, 512> otst;
         qst.load(qb + (long long)q0 * DK, DK, tid);   qst.store(Qs, QP, tid);
         ost.load(dob + (long long)q0 * DV, DV, tid);  ost.store(dOs, OP, tid);
-        qtst.load(qtb + q0, Nq, tid);                 qtst.store(Qts, TP, tid);
-        otst.load(dotb + q0, Nq, tid);                otst.store(dOts, TP, tid);
         if (tid < QB) Ls[tid] = lse[(long long)b * Nq + q0 + tid];
         else if (tid < 2 * QB) Ds[tid - QB] = delta[(long long)b * Nq + q0 + tid - QB];
         __syncthreads();
@@ -390,12 +405,11 @@ __global__ __launch_bounds__(512) void nl_attn_bwd_kv_kernel(const T* __restrict
         for (int n = 0; n < NH; ++n)
 #pragma unroll
             for (int s = 0; s < KSP; ++s)
-                dvacc[n] = M::mma(M::load(dOts + (32 * (half * NH + n) + r) * TP, s, h), M::load(Ptw + r * TP, s, h),
-                                  dvacc[n]);
+                dvacc[n] = M::mma(M::load_t(dOs, OP, 32 * (half * NH + n), s, lane), M::load(Ptw + r * TP, s, h), dvacc[n]);
         if (half < MT) {
 #pragma unroll
             for (int s = 0; s < KSP; ++s)
-                dkacc = M::mma(M::load(Qts + (32 * half + r) * TP, s, h), M::load(dStw + r * TP, s, h), dkacc);
+                dkacc = M::mma(M::load_t(Qs, QP, 32 * half, s, lane), M::load(dStw + r * TP, s, h), dkacc);
         }
     }
     if (gridDim.z > 1) {               // fp32 partial sums: [z][B * Nk][DV + DK]
@@ -534,7 +548,7 @@ extern "C" int msg_nonlocal_attention_bwd(const void* q, const void* qt, const v
                                           const void* dO, const void* dOt, const void* o, const float* lse,
                                           float* delta, void* dq, void* dk_out, void* dv_out, float* workspace,
                                           int dtype, int B, int Nq, int Nk, int dk, int dv, void* stream) {
-    if (!q || !qt || !k || !kt || !v || !dO || !dOt || !o || !lse || !delta || !dq || !dk_out || !dv_out) return MSG_EINVAL;
+    if (!q || !k || !kt || !v || !dO || !o || !lse || !delta || !dq || !dk_out || !dv_out) return MSG_EINVAL;   // (qt, dOt: no longer read)
     if (!shapes_ok(B, Nq, Nk, dk, dv)) return MSG_EUNSUPPORTED;
     const int nsplit = msg_nonlocal_attention_bwd_splits(B, Nq, Nk);
     if (nsplit > 1 && !workspace) return MSG_EINVAL;

@@ -64,15 +64,15 @@ class _NonLocalAttention(Function):
         b, nq, dk = q.shape
         nk, dv = k.shape[1], v.shape[2]
         delta = torch.empty((b, nq), dtype=torch.float32, device=dev)        # filled by the dQ kernel
-        qt, kt, dot = (t.transpose(1, 2).contiguous() for t in (q, k, grad_o))
+        kt = k.transpose(1, 2).contiguous()      # (Q^T and dO^T -- the big ones -- are read transposed inside the kernel)
         dq, dkey, dval = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         splits = _lib.lib().msg_nonlocal_attention_bwd_splits(b, nq, nk)
         work = torch.empty(splits * b * nk * (dk + dv), dtype=torch.float32, device=dev) if splits > 1 else None
         flops = 2.0 * b * nq * nk * ((dk + dv + dk) + (dk + dv + dv + dk))
         with _lib.on_device(dev), _lib.kernel_clock.span(f"nl_attention_bwd/{q.dtype}", flops):
             code = _lib.lib().msg_nonlocal_attention_bwd(
-                q.data_ptr(), qt.data_ptr(), k.data_ptr(), kt.data_ptr(), v.data_ptr(), grad_o.data_ptr(),
-                dot.data_ptr(), o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dkey.data_ptr(),
+                q.data_ptr(), None, k.data_ptr(), kt.data_ptr(), v.data_ptr(), grad_o.data_ptr(),
+                None, o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dkey.data_ptr(),
                 dval.data_ptr(),
                 _lib.ptr(work), _lib.dtype_code(q), b, nq, nk, dk, dv, _lib.stream_of(dev))
         _lib.check(code, "msg_nonlocal_attention_bwd")

@@ -249,6 +249,14 @@ int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, int W, int 
 /* y = (a + beta*b) * gain over n elements (n multiple of the 16-byte vector, all pointers 16-B aligned): the
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */
 int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n, float beta, float gain, void* stream);
+/* y = (gamma[0] * a + b) * gain with gamma a DEVICE fp32 scalar -- the merge of the NonLocalBlock, (gamma * o + residual) / sqrt(2)
+ * (multi_stylegan/u_net_2d_discriminator.py:381; gamma is a learnt parameter) -- and its backward in one pass:
+ *   ga = gamma * gain * gy,  gb = gain * gy,  g_gamma[0] = gain * sum(gy * a)   (block partials in ws, added in a fixed order by a
+ * second launch: deterministic).  Dense maps of n elements in one layout, MSG_F32 / MSG_BF16, n a multiple of the 16-byte vector. */
+int msg_gamma_merge(const void* a, const void* b, const float* gamma, void* y, int dtype, long long n, float gain, void* stream);
+long long msg_gamma_merge_backward_workspace(void);
+int msg_gamma_merge_backward(const void* gy, const void* a, const float* gamma, void* ga, void* gb, float* g_gamma, int dtype,
+                             long long n, float gain, float* ws, void* stream);
 /* The same for [rows][cols] operands with row pitches (elements): channel-slices of channels-last buffers, e.g. the
  * gradient of a skip connection (a slice of the concatenated map's gradient).  cols and pitches multiples of the vector. */
 int msg_scaled_add_rows(const void* a, const void* b, void* y, int dtype, long long rows, int cols,
@@ -281,6 +289,16 @@ int msg_softmax_rows_backward(const void* y, const void* gy, void* gx, int dtype
 int msg_nonlocal_attention_supported(int B, int Nq, int Nk, int dk, int dv);
 int msg_nonlocal_attention_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int dtype,
                                int B, int Nq, int Nk, int dk, int dv, void* stream);
+/* The 2x2 / stride-2 max-pooling in front of the attention (F.max_pool2d on phi(x) and g(x),
+ * multi_stylegan/u_net_2d_discriminator.py:366-370), channels-last, MSG_BF16 / MSG_F32, H and W even, C a whole number of
+ * 16-byte vectors.  x [B, H, W, C] with pixel pitch ldx >= C; y [B, H/2, W/2, C] dense; idx (NULL when no backward follows):
+ * one 16-bit word per 16-byte vector of y, two bits per element = the window position that won (first maximum in scan
+ * order, NaN wins: the library's rule).  Backward: gx [B, H, W, C] dense, every element written (gy at the winner, 0 elsewhere). */
+int msg_maxpool2x2_fwd(const void* x, void* y, unsigned short* idx, int dtype, int B, int H, int W, int C, long long ldx,
+                       void* stream);
+int msg_maxpool2x2_bwd(const void* gy, const unsigned short* idx, void* gx, int dtype, int B, int H, int W, int C,
+                       void* stream);
+
 /* msg_nonlocal_attention_bwd_splits: in how many parts the dK / dV kernel splits its query sweep for this problem; when
  * it is more than 1 the caller passes `workspace` with splits * B * Nk * (dk + dv) floats (scratch, fully overwritten). */
 int msg_nonlocal_attention_bwd_splits(int B, int Nq, int Nk);

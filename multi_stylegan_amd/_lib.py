@@ -51,6 +51,9 @@ _SIGNATURES = {
     "msg_relayout_weight": (_I, [_P, _P, _P, _P, _I] + [_I] * 7 + [_F, _P]),
     "msg_gather_taps": (_I, [_P, _P, _I] + [_I] * 9 + [_P]),
     "msg_scaled_add": (_I, [_P, _P, _P, _I, _L, _F, _F, _P]),
+    "msg_gamma_merge": (_I, [_P, _P, _P, _P, _I, _L, _F, _P]),
+    "msg_gamma_merge_backward_workspace": (_L, []),
+    "msg_gamma_merge_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _P, _P]),
     "msg_scaled_add_rows": (_I, [_P, _P, _P, _I, _L, _I, _L, _L, _L, _F, _F, _P]),
     "msg_flat_adam": (_I, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _P]),
     "msg_flat_ema": (_I, [_P, _P, _L, _F, _P]),
@@ -67,6 +70,8 @@ _SIGNATURES = {
     "msg_conv2d_fprop_plan": (_I, [_I] * 11 + [_L]),
     "msg_conv2d_fprop_upconv_eligible": (_I, [_I] * 14 + [_L]),
     "msg_conv2d_fprop_thin_eligible": (_I, [_I] * 16),
+    "msg_maxpool2x2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _L, _P]),
+    "msg_maxpool2x2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msg_linear_fprop": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "msg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "msg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),

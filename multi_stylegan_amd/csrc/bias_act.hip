@@ -595,3 +595,124 @@ extern "C" int msg_scaled_add_rows(const void* a, const void* b, void* y, int dt
                            (float*)y, rows, cols / vec, lda, ldb, ldy, beta, gain);
     return MSG_CHECK_LAUNCH();
 }
+
+// ---- y = (gamma * a + b) * gain with gamma a DEVICE scalar: the merge of the NonLocalBlock, (gamma * o + residual) / sqrt(2)
+// (u_net_2d_discriminator.py:381; gamma is a learnt fp32 parameter), and its backward in one pass:
+//   ga = gamma * gain * gy,  gb = gain * gy,  g_gamma = gain * sum(gy * a)   (block partials + fixed-order second stage).
+// The composite it replaces is five elementwise launches and a reduction over the same maps.
+template <typename T>
+__global__ __launch_bounds__(256) void gamma_merge_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                              const float* __restrict__ gamma, T* __restrict__ y, long long nvec,
+                                                              float gain) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    const float gm = gamma[0];
+    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * 256) {
+        V va, vb, o;
+        va.raw = *reinterpret_cast<const uint4*>(a + vi * VEC);
+        vb.raw = *reinterpret_cast<const uint4*>(b + vi * VEC);
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = fmaf(gm, va.get(e), vb.get(e)) * gain;
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+        }
+        *reinterpret_cast<uint4*>(y + vi * VEC) = o.raw;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gamma_merge_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ a,
+                                                              const float* __restrict__ gamma, T* __restrict__ ga,
+                                                              T* __restrict__ gb, float* __restrict__ part, long long nvec,
+                                                              float gain) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    __shared__ float red[4];
+    const float gm = gamma[0] * gain;
+    float acc = 0.f;
+    for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * 256) {
+        V vg, va, oa, ob;
+        vg.raw = *reinterpret_cast<const uint4*>(gy + vi * VEC);
+        va.raw = *reinterpret_cast<const uint4*>(a + vi * VEC);
+        float fa[VEC], fb[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float g = vg.get(e);
+            fa[e] = g * gm;
+            fb[e] = g * gain;
+            acc = fmaf(g, va.get(e), acc);
+        }
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oa.set(e, fa[e]); ob.set(e, fb[e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oa.set2(e, fa[2 * e], fa[2 * e + 1]); ob.set2(e, fb[2 * e], fb[2 * e + 1]); }
+        }
+        *reinterpret_cast<uint4*>(ga + vi * VEC) = oa.raw;
+        *reinterpret_cast<uint4*>(gb + vi * VEC) = ob.raw;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void gamma_merge_reduce_kernel(const float* __restrict__ part, int n, float gain,
+                                                                 float* __restrict__ g_gamma) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];            // (fixed assignment, fixed order: deterministic)
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g_gamma[0] = red[0] * gain;
+}
+
+constexpr int GAMMA_MERGE_BLOCKS = 2048;
+
+extern "C" int msg_gamma_merge(const void* a, const void* b, const float* gamma, void* y, int dtype, long long n, float gain,
+                               void* stream) {
+    if (n == 0) return MSG_OK;
+    if (!a || !b || !gamma || !y || n < 0) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (n % vec || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
+    const long long nvec = n / vec;
+    const unsigned blocks = (unsigned)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((gamma_merge_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, gamma, (bf16_t*)y, nvec, gain);
+    else
+        hipLaunchKernelGGL((gamma_merge_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)a, (const float*)b, gamma, (float*)y, nvec, gain);
+    return MSG_CHECK_LAUNCH();
+}
+
+// ws: at least msg_gamma_merge_backward_workspace() floats (contents irrelevant); g_gamma [1] fp32, overwritten.
+extern "C" long long msg_gamma_merge_backward_workspace(void) { return GAMMA_MERGE_BLOCKS; }
+
+extern "C" int msg_gamma_merge_backward(const void* gy, const void* a, const float* gamma, void* ga, void* gb, float* g_gamma,
+                                        int dtype, long long n, float gain, float* ws, void* stream) {
+    if (!gy || !a || !gamma || !ga || !gb || !g_gamma || !ws || n <= 0) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (n % vec || (((uintptr_t)gy | (uintptr_t)a | (uintptr_t)ga | (uintptr_t)gb) & 15u)) return MSG_EUNSUPPORTED;
+    const long long nvec = n / vec;
+    const unsigned blocks = (unsigned)((nvec + 255) / 256 < GAMMA_MERGE_BLOCKS ? (nvec + 255) / 256 : GAMMA_MERGE_BLOCKS);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((gamma_merge_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)a, gamma, (bf16_t*)ga, (bf16_t*)gb, ws, nvec, gain);
+    else
+        hipLaunchKernelGGL((gamma_merge_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)gy, (const float*)a, gamma, (float*)ga, (float*)gb, ws, nvec, gain);
+    if (hipGetLastError() != hipSuccess) return MSG_ELAUNCH;
+    hipLaunchKernelGGL(gamma_merge_reduce_kernel, dim3(1), dim3(256), 0, s, ws, (int)blocks, gain, g_gamma);
+    return MSG_CHECK_LAUNCH();
+}

@@ -219,6 +219,57 @@ class _ScaledAdd(Function):
         return g, g, None
 
 
+GAMMA_MERGE = bool(int(os.environ.get("MSG_GAMMA_MERGE", "1")))      # 0: gamma * a, then scaled_add (A/B)
+
+
+class _GammaMerge(Function):
+    """y = (gamma * a + b) * gain, gamma a 0-d fp32 parameter (csrc/bias_act.hip: msg_gamma_merge), one launch forward and one
+    pass backward; a second-order graph (R1) is built from the torch formulation."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, gain):
+        dev = _lib.require_gpu(a, b, gamma)
+        y = torch.empty_like(a)
+        g32 = gamma.detach().reshape(1).to(torch.float32)
+        with _lib.on_device(dev):
+            code = _lib.lib().msg_gamma_merge(a.data_ptr(), b.data_ptr(), g32.data_ptr(), y.data_ptr(), _lib.dtype_code(a),
+                                              a.numel(), float(gain), _lib.stream_of(dev))
+        _lib.check(code, "msg_gamma_merge")
+        ctx.gain = float(gain)
+        ctx.save_for_backward(a, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, gamma = ctx.saved_tensors
+        gain = ctx.gain
+        if torch.is_grad_enabled() or not (gy.stride() == a.stride() and gy.dtype == a.dtype):
+            g = gy * gain
+            return g * gamma.to(g.dtype), g, (gy.float() * a.float()).sum().to(gamma.dtype).reshape(gamma.shape) * gain, None
+        dev = gy.device
+        ga, gb = torch.empty_like(a), torch.empty_like(a)
+        gg = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib().msg_gamma_merge_backward_workspace(), dtype=torch.float32, device=dev)
+        g32 = gamma.detach().reshape(1).to(torch.float32)
+        with _lib.on_device(dev):
+            code = _lib.lib().msg_gamma_merge_backward(gy.data_ptr(), a.data_ptr(), g32.data_ptr(), ga.data_ptr(), gb.data_ptr(),
+                                                       gg.data_ptr(), _lib.dtype_code(a), a.numel(), gain, ws.data_ptr(),
+                                                       _lib.stream_of(dev))
+        _lib.check(code, "msg_gamma_merge_backward")
+        return ga, gb, gg.reshape(gamma.shape).to(gamma.dtype), None
+
+
+def gamma_merge(a, b, gamma, gain):
+    """(gamma * a + b) * gain for two maps of identical shape, dtype and memory layout and a 0-d parameter gamma
+    (the NonLocalBlock's merge, u_net_2d_discriminator.py:381); other operands take the torch formulation."""
+    same = a.shape == b.shape and a.dtype == b.dtype and a.stride() == b.stride() and a.is_cuda and gamma.is_cuda and \
+        gamma.numel() == 1 and a.numel() % 8 == 0 and a.dtype in (torch.float32, torch.bfloat16) and \
+        (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last))
+    if not (same and GAMMA_MERGE):
+        return scaled_add(gamma.to(a.dtype) * a, b, gain)
+    return _GammaMerge.apply(a, b, gamma, gain)
+
+
 def _rows_view(t):
     """(rows, cols, pitch) if `t` [B,C,H,W] is a channels-last map or a channel-slice of one, else None."""
     if t.ndim != 4 or not t.is_cuda:

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv_ops, equalized_layer
-from .op_static import FusedLeakyReLU, non_local_attention, scaled_add, scaled_add_fork, softmax_rows, upfirdn2d
+from .op_static import FusedLeakyReLU, gamma_merge, max_pool2x2, non_local_attention, scaled_add, scaled_add_fork, softmax_rows, upfirdn2d
 from .op_static import attention as _attention
 
 
@@ -215,8 +215,8 @@ class NonLocalBlock(nn.Module):
         else:
             t, p_, g_ = self.theta(input), self.phi(input), self.g(input)
         query = t.flatten(start_dim=2).transpose(1, 2)                                                  # [B, HW, C/8]
-        key = F.max_pool2d(p_, kernel_size=2, stride=2).flatten(start_dim=2)                            # [B, C/8, HW/4]
-        value = F.max_pool2d(g_, kernel_size=2, stride=2).flatten(start_dim=2).transpose(1, 2)          # [B, HW/4, C/2]
+        key = max_pool2x2(p_).flatten(start_dim=2)                                                      # [B, C/8, HW/4]
+        value = max_pool2x2(g_).flatten(start_dim=2).transpose(1, 2)                                    # [B, HW/4, C/2]
         keys = key.transpose(1, 2)                                                                      # [B, HW/4, C/8]
         if _attention.supported(query, keys, value):
             # fused: the [B, HW, HW/4] attention map never reaches HBM (csrc/attention.hip)
@@ -230,7 +230,7 @@ class NonLocalBlock(nn.Module):
         output = self.o(conv_ops.to_compute_layout(attended))
         if residual is None:
             residual = self.residual_mapping(input)
-        return scaled_add(self.gamma.to(input.dtype) * output, residual, 1.0 / math.sqrt(2))
+        return gamma_merge(output, residual, self.gamma, 1.0 / math.sqrt(2))
 
 
 def append_spectra(input: torch.Tensor) -> torch.Tensor:

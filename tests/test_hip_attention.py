@@ -204,3 +204,32 @@ def test_fused_attention_shape_sweep(dtype):
     qd, kd, vd = (t.to(DEV, dtype) for t in (q, k, v))
     assert not attention.supported(qd, kd, vd)
     assert rel_err(non_local_attention(qd, kd, vd), _oracle(q, k, v)) < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 48, 64, 64), (2, 192, 16, 24), (1, 8, 2, 2)])
+def test_max_pool2x2_matches_library(shape, dtype):
+    """csrc/maxpool.hip against F.max_pool2d (u_net_2d_discriminator.py:366-370): output and gradient bit for bit -- including
+    windows with TIED maxima, where the gradient must go to the first maximum in scan order as the library sends it --
+    on dense maps and on a channel-slice, and through a second-order pass."""
+    import torch.nn.functional as F
+    from multi_stylegan_amd.op_static import max_pool2x2
+    torch.manual_seed(shape[1])
+    x = (torch.randn(*shape, device=DEV) * 2).round() / 2          # coarse values: many ties
+    x = x.to(dtype).contiguous(memory_format=torch.channels_last)
+    for src in (x, torch.cat([x, x], dim=1).contiguous(memory_format=torch.channels_last)[:, shape[1]:]):
+        a = src.clone().requires_grad_(True) if src is x else src.detach().requires_grad_(True)
+        b = src.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ya, yb = max_pool2x2(a), F.max_pool2d(b, kernel_size=2, stride=2)
+        assert torch.equal(ya, yb)
+        gy = torch.randn_like(yb)
+        ga, = torch.autograd.grad(ya, a, gy)
+        gb, = torch.autograd.grad(yb, b, gy)
+        assert torch.equal(ga, gb)
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    gy = torch.randn(shape[0], shape[1], shape[2] // 2, shape[3] // 2, device=DEV, dtype=dtype).requires_grad_(True)
+    for t, pool in ((a, max_pool2x2), (b, lambda v: F.max_pool2d(v, kernel_size=2, stride=2))):
+        g1, = torch.autograd.grad(pool(t), t, gy, create_graph=True)
+        t.second = torch.autograd.grad(g1.square().sum(), gy)[0]
+    assert torch.equal(a.second, b.second)

@@ -1,6 +1,8 @@
 """Parity of the gfx950 kernels (called through the C ABI via multi_stylegan_amd.op_static) against the golden
 vectors and the CPU oracle.  fp32 tolerance: 1e-3 relative (BASELINE.json north_star); in practice ~1e-6.
 bf16 storage: 2e-2 relative to max|ref| (8-bit mantissa on inputs and outputs, fp32 arithmetic inside)."""
+import math
+
 import pytest
 import torch
 
@@ -336,3 +338,42 @@ def test_softmax_rows(dtype, shape):
     for name, a, b in zip(("y", "gx", "d/dgy", "d/dx"), got, ref):
         assert rel_err(a, b) < tol, (name, rel_err(a, b))
     assert abs(got[0].sum(dim=-1) - 1).max() < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gamma_merge(dtype):
+    """(gamma * a + b) / sqrt(2) with gamma a 0-d parameter (NonLocalBlock merge, u_net_2d_discriminator.py:381) in one launch
+    forward and one pass backward: against the torch formulation in fp64, bit-identical over repeated launches, and through
+    a second-order pass."""
+    ops = _ops()
+    torch.manual_seed(4)
+    a0 = torch.randn(3, 48, 20, 24, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    b0 = torch.randn_like(a0)
+    gain = 1 / math.sqrt(2)
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    outs = []
+    for _ in range(2):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        gamma = torch.tensor(0.7, device=DEV, requires_grad=True)
+        y = ops.gamma_merge(a, b, gamma, gain)
+        gy = torch.randn(y.shape, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        torch.manual_seed(5)
+        gy = torch.randn(y.shape, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        ga, gb, gg = torch.autograd.grad(y, (a, b, gamma), gy)
+        outs.append((y.detach(), ga, gb, gg))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    ad, bd, gd = a0.double().requires_grad_(True), b0.double().requires_grad_(True), torch.tensor(0.7, device=DEV, dtype=torch.float64, requires_grad=True)
+    yd = (gd * ad + bd) * gain
+    want = torch.autograd.grad(yd, (ad, bd, gd), gy.double())
+    y, ga, gb, gg = outs[0]
+    assert rel_err(y.double(), yd) < tol and rel_err(ga.double(), want[0]) < tol and rel_err(gb.double(), want[1]) < tol
+    assert abs(float(gg) - float(want[2])) < tol * max(1.0, abs(float(want[2])))
+    assert gg.shape == () and gg.dtype == torch.float32
+    # second order: d/d(gy) of <ga, ga> runs through the torch formulation of the backward
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    gamma = torch.tensor(0.7, device=DEV, requires_grad=True)
+    gyr = gy.clone().requires_grad_(True)
+    ga, = torch.autograd.grad(ops.gamma_merge(a, b, gamma, gain), a, gyr, create_graph=True)
+    h, = torch.autograd.grad(ga.float().square().sum(), gyr)
+    assert rel_err(h.double(), 2 * (0.7 * gain) ** 2 * gy.double()) < 5 * tol

@@ -347,6 +347,16 @@ class Generator(nn.Module):
                 noise: Optional[List[torch.Tensor]] = None, randomize_noise: bool = True,
                 inject_index: Optional[int] = None, input_is_latent: bool = False,
                 return_path_length_grads: bool = False, path_length_noise: Optional[torch.Tensor] = None):
+        if return_path_length_grads:
+            # (this pass is differentiated twice: the layers keep the forms that have native second-order kernels)
+            with conv_ops.expect_second_order():
+                return self._forward(input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent,
+                                     True, path_length_noise)
+        return self._forward(input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent, False,
+                             path_length_noise)
+
+    def _forward(self, input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent,
+                 return_path_length_grads, path_length_noise):
         latent = self._latent(input, inject_index, input_is_latent)
         n_main = len(self.main_convolutions_1)
         if noise is None:

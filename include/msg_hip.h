@@ -139,6 +139,12 @@ int msg_bias_act_backward(const void* gy, const void* out, void* gx, int dtype,
                           float* grad_bias, const float* noise, float* grad_noise_weight,
                           int noise_batch, int pix, float alpha, float scale,
                           float* ws, long long ws_floats, void* stream);
+/* sums[c] = sum over the pixels of a channels-last map x [size_x / C][C]: the bias gradient of a convolution with no activation
+ * behind it (`F.conv2d(..., bias)` of the discriminator's strided convs, multi_stylegan/equalized_layer.py:63-74).  fp32,
+ * overwritten, deterministic (workspace and second stage of msg_bias_act_backward: ws_floats >=
+ * msg_bias_act_backward_workspace(size_x, 1, C, 0)).  MSG_F32 / MSG_BF16, C a whole number of 16-byte vectors. */
+int msg_channel_sums(const void* x, float* sums, int dtype, long long size_x, int C, float* ws, long long ws_floats,
+                     void* stream);
 /* msg_bias_act_backward for a channels-last bf16 map (step_b = 1, size_b % 8 == 0) whose forward launch left the sign
  * bytes of its output (msg_conv2d_fprop_act_mask / msg_upfirdn2d_separable_act_mask): `mask` replaces `out` -- the pass
  * moves 2 1/16 instead of 3 maps.  The bytes lie in the PRODUCER's tile order: tiles of tile_m consecutive pixels x tile_n

@@ -708,9 +708,28 @@ class _ConvF(Function):
         g = ctx.g
         gx = _ConvD.apply(gy, w, g) if ctx.needs_input_grad[0] else None
         gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
-        # (the cast inside the reduction: `gy.float()` materialised an fp32 copy of the whole map first)
-        gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32) if ctx.has_bias and _consumed(ctx, 2, 2) else None
+        gb = _channel_sums(gy) if ctx.has_bias and _consumed(ctx, 2, 2) else None
         return gx, gw, gb, None
+
+
+def _channel_sums(gy):
+    """gy.sum((0, 2, 3)) in fp32: on the activation backward's partial-sum kernels for dense channels-last maps (fixed
+    order, a third of the library reduction's time on the strided convs' maps), the library otherwise / in second-order graphs."""
+    c = gy.shape[1]
+    vec = _vec(gy.dtype)
+    if torch.is_grad_enabled() or not gy.is_cuda or gy.dtype not in (torch.float32, torch.bfloat16) or c % vec or \
+            not gy.is_contiguous(memory_format=torch.channels_last) or gy.data_ptr() % 16 or gy.numel() == 0:
+        # (the cast inside the reduction: `gy.float()` would materialise an fp32 copy of the whole map first)
+        return gy.sum(dim=(0, 2, 3), dtype=torch.float32)
+    dev = gy.device
+    need = _lib.lib().msg_bias_act_backward_workspace(gy.numel(), 1, c, 0)
+    ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+    out = torch.empty(c, dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        code = _lib.lib().msg_channel_sums(gy.data_ptr(), out.data_ptr(), _lib.dtype_code(gy), gy.numel(), c, ws.data_ptr(),
+                                           need, _lib.stream_of(dev))
+    _lib.check(code, "msg_channel_sums")
+    return out
 
 
 class _ConvD(Function):
@@ -1331,7 +1350,7 @@ def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=Non
     b = gwk.shape[0]
     o, i, t = w3.shape
     dev = gwk.device
-    og = 1 if o >= 256 else 2                      # >= 256 workgroups for the 512-channel layers
+    og = 2 if o >= 512 or o < 256 else 1           # >= 256 workgroups; 512 outputs: 256 partial rows of the style gradient, not 512
     groups = (o + og - 1) // og
     out = _grad_dest(dest) if cotangent is None else None     # (the parameter's slice of the flat gradient store)
     gw3 = out.view(o, i, t) if out is not None else torch.empty((o, i, t), dtype=torch.float32, device=dev)

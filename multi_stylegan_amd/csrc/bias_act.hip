@@ -182,7 +182,8 @@ extern "C" int msg_fused_bias_act(const void* x, const float* bias, const void* 
 // pixel loop, partial sums meet in LDS and are added there in lane order.
 // MASK: `out` is not read; the sign of the 8 outputs of a channel vector comes from one byte of the map the forward kernel
 // wrote beside its output (ActEpilogue::mask, msg_common.h): 2 + 1/16 instead of 3 passes' worth of traffic.
-template <typename T, bool HAS_NOISE, bool MASK = false>
+// SUMS_ONLY: nothing but the channel sums of gy (the bias gradient of a conv without an activation behind it).
+template <typename T, bool HAS_NOISE, bool MASK = false, bool SUMS_ONLY = false>
 __global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restrict__ gy, const T* __restrict__ out,
                                                               T* __restrict__ gx, float* __restrict__ part_b,
                                                               const float* __restrict__ noise,
@@ -207,6 +208,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restric
         V g, o, r;
         g.raw = *reinterpret_cast<const uint4*>(gy + i);
         unsigned int mbits = 0;
+        if constexpr (SUMS_ONLY) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sb[e] += g.get(e);
+            continue;
+        }
         if constexpr (MASK) mbits = reinterpret_cast<const unsigned char*>(out)[act_mask_index(q, cv, p.size_b, tile_m, tile_n)];
         else o.raw = *reinterpret_cast<const uint4*>(out + i);
         float f[VEC], rowsum = 0.f;
@@ -714,5 +720,34 @@ extern "C" int msg_gamma_merge_backward(const void* gy, const void* a, const flo
         hipLaunchKernelGGL((gamma_merge_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)gy, (const float*)a, gamma, (float*)ga, (float*)gb, ws, nvec, gain);
     if (hipGetLastError() != hipSuccess) return MSG_ELAUNCH;
     hipLaunchKernelGGL(gamma_merge_reduce_kernel, dim3(1), dim3(256), 0, s, ws, (int)blocks, gain, g_gamma);
+    return MSG_CHECK_LAUNCH();
+}
+
+// sums[c] = sum over the pixels of a channels-last map x [size_x / C][C] (fp32, overwritten; deterministic: workgroup partials in
+// ws -- msg_bias_act_backward_workspace(size_x, 1, C, 0) floats -- and the fixed-order second stage of the activation backward).
+// The bias gradient of a convolution that has no activation behind it (the discriminator's strided convs).
+extern "C" int msg_channel_sums(const void* x, float* sums, int dtype, long long size_x, int C, float* ws, long long ws_floats,
+                                void* stream) {
+    if (size_x <= 0 || C <= 0 || !x || !sums || !ws || size_x % C) return MSG_EINVAL;
+    if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (C % vec || ((uintptr_t)x & 15u)) return MSG_EUNSUPPORTED;
+    const BwdPlan q = bwd_plan(size_x, 1, C, vec);
+    if (q.path != 0 || ws_floats < q.n_b * C) return MSG_EINVAL;
+    BiasActParams p{size_x, 1, C, 1, 1, 3, 1, 0.f, 1.f};
+    dim3 grid(q.gx_blocks, (unsigned)q.gy_blocks);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((bias_act_bwd_cl_kernel<bf16_t, false, false, true>), grid, dim3(256), 0, s, (const bf16_t*)x,
+                           (const bf16_t*)nullptr, (bf16_t*)nullptr, ws, (const float*)nullptr, (float*)nullptr, p, q.lanes_c,
+                           q.npix, q.ppb, 1, 8);
+    else
+        hipLaunchKernelGGL((bias_act_bwd_cl_kernel<float, false, false, true>), grid, dim3(256), 0, s, (const float*)x,
+                           (const float*)nullptr, (float*)nullptr, ws, (const float*)nullptr, (float*)nullptr, p, q.lanes_c,
+                           q.npix, q.ppb, 1, 8);
+    if (hipGetLastError() != hipSuccess) return MSG_ELAUNCH;
+    const int bias_blocks = (C + BRC - 1) / BRC;
+    hipLaunchKernelGGL(bias_act_bwd_reduce_kernel, dim3(bias_blocks), dim3(256), 0, s, ws, sums, C, q.n_b, (const float*)nullptr,
+                       (float*)nullptr, 0ll, bias_blocks);
     return MSG_CHECK_LAUNCH();
 }

@@ -27,6 +27,7 @@ from .op_static import FusedLeakyReLU, blur_bias_act, fused_bias_noise_leaky_rel
 PAIR_OUTPUT_HEADS = bool(int(os.environ.get("MSG_PAIR_HEADS", "1")))
 # 0: every styled layer runs its own modulation_mapping launch (A/B; identical arithmetic per layer)
 GROUP_STYLE_AFFINES = bool(int(os.environ.get("MSG_GROUP_AFFINES", "1")))
+BATCH_NOISE_DRAWS = bool(int(os.environ.get("MSG_BATCH_NOISE", "1")))     # 0: one normal draw per NoiseInjection (A/B)
 
 
 def _fir2d(taps, gain=1.0):
@@ -355,13 +356,36 @@ class Generator(nn.Module):
         return self._forward(input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent, False,
                              path_length_noise)
 
+    def _draw_layer_noise(self, latent):
+        """Every NoiseInjection's own N(0, 1) map (the reference draws one per layer and stream when no noise is passed,
+        multi_stylegan_generator.py:288-292) out of ONE normal draw per forward instead of ~27 launches of a few microseconds'
+        work each: -> (start 1, start 2, [stream-1 layers], [stream-2 layers]) as views of one buffer, or None off the GPU."""
+        if not latent.is_cuda or not BATCH_NOISE_DRAWS:
+            return None
+        b = latent.shape[0]
+        res0 = tuple(self.constant_input_1.input.shape[2:])
+        shapes = [res0, res0]
+        h, w = res0
+        for i in range(len(self.main_convolutions_1)):
+            if i % 2 == 0:
+                h, w = 2 * h, 2 * w
+            shapes += [(h, w), (h, w)]                                    # (stream 1, stream 2)
+        sizes = [b * hh * ww for hh, ww in shapes]
+        flat = torch.randn(sum(sizes), device=latent.device, dtype=torch.float32)
+        maps = [t.view(b, 1, hh, ww) for t, (hh, ww) in zip(flat.split(sizes), shapes)]
+        return maps[0], maps[1], maps[2::2], maps[3::2]
+
     def _forward(self, input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent,
                  return_path_length_grads, path_length_noise):
         latent = self._latent(input, inject_index, input_is_latent)
         n_main = len(self.main_convolutions_1)
+        layer_noise_2 = None
         if noise is None:
             if randomize_noise:
                 noise_start, layer_noise = None, [None] * n_main
+                drawn = self._draw_layer_noise(latent)
+                if drawn is not None:
+                    noise_start, noise_start_2, layer_noise, layer_noise_2 = drawn
             else:
                 noise_start = self.noises.noise_start
                 layer_noise = [getattr(self.noises, f"noise_{i}") for i in range(n_main)]
@@ -374,7 +398,7 @@ class Generator(nn.Module):
         out1 = conv_ops.to_compute_layout(self.constant_input_1(latent), dt)
         out2 = conv_ops.to_compute_layout(self.constant_input_2(latent), dt)
         out1, style = self.starting_convolution_1(out1, w_of(0, 0), noise=noise_start)
-        out2 = self.starting_convolution_2(out2, style, noise=noise_start)
+        out2 = self.starting_convolution_2(out2, style, noise=noise_start if layer_noise_2 is None else noise_start_2)
         skip1, style = self.starting_output_block_1(out1, w_of(1, 1))
         skip2 = self.starting_output_block_2(out2, style)
         run_stream2 = not self.elide_dead_branch
@@ -384,11 +408,11 @@ class Generator(nn.Module):
             out1, style = self.main_convolutions_1[2 * i](out1, w_of(2 + 3 * i, 2 * i + 1),
                                                            noise=layer_noise[2 * i])
             if run_stream2:
-                out2 = self.main_convolutions_2[2 * i](out2, style, noise=layer_noise[2 * i])
+                out2 = self.main_convolutions_2[2 * i](out2, style, noise=(layer_noise_2 or layer_noise)[2 * i])
             out1, style = self.main_convolutions_1[2 * i + 1](out1, w_of(3 + 3 * i, 2 * i + 2),
                                                                noise=layer_noise[2 * i + 1])
             if run_stream2:
-                out2 = self.main_convolutions_2[2 * i + 1](out2, style, noise=layer_noise[2 * i + 1])
+                out2 = self.main_convolutions_2[2 * i + 1](out2, style, noise=(layer_noise_2 or layer_noise)[2 * i + 1])
             if paired:
                 skip, style = self._paired_heads(self.output_blocks_1[i], self.output_blocks_2[i], out1,
                                                  w_of(4 + 3 * i, 2 * i + 3), skip)

@@ -794,3 +794,20 @@ def test_small_map_modulated_conv_matches_per_sample_form(case, dtype, monkeypat
         assert err(other.double(), ref) < tol, ("per-sample " + name, err(other.double(), ref))
     a2, b2 = run(4096, second=True)[0], run(0, second=True)[0]
     assert err(a2.double(), b2.double()) < (1e-3 if dtype == torch.float32 else 6e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(32, 128, 127, 127), (3, 24, 5, 7), (2, 768, 15, 15)])
+def test_channel_sums(shape, dtype):
+    """msg_channel_sums -- the bias gradient of a conv with no activation behind it -- against the library reduction in fp64,
+    bit-identical over repeated launches; layouts it does not take go to the library."""
+    from multi_stylegan_amd import conv_ops
+    torch.manual_seed(shape[1])
+    if shape[0] * shape[1] * shape[2] * shape[3] > 4e7:
+        shape = (8,) + shape[1:]
+    g = torch.randn(*shape, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    a, b = conv_ops._channel_sums(g), conv_ops._channel_sums(g)
+    assert a.dtype == torch.float32 and torch.equal(a, b)
+    want = g.double().sum(dim=(0, 2, 3))
+    assert rel_err(a.double(), want) < 1e-5
+    assert rel_err(conv_ops._channel_sums(g.contiguous()).double(), want) < 1e-5          # (NCHW: library path)

@@ -22,6 +22,7 @@ SEEN = collections.defaultdict(lambda: [0, 0])
 WATCH = ("copy_", "clone", "_to_copy", "cat", "contiguous", "add", "add_", "mul", "mul_", "sum", "fill_", "zero_", "zeros",
          "zeros_like", "sub", "div", "rsqrt", "pow", "neg", "where", "flip", "permute_copy", "bmm", "mm", "addmm")
 REGULARISED = bool(int(os.environ.get("MSG_BIG_COPIES_REG", "0")))    # 1: survey a regularised iteration (R1 + path length)
+MIN_ELEMS = int(os.environ.get("MSG_BIG_COPIES_MIN", str(1 << 20)))   # 0: every call, ranked by COUNT (the tiny-launch survey)
 
 
 class Spy(TorchDispatchMode):
@@ -30,7 +31,7 @@ class Spy(TorchDispatchMode):
         name = func.__name__.split(".")[0]
         if name in WATCH:
             t = out if isinstance(out, torch.Tensor) else (args[0] if args and isinstance(args[0], torch.Tensor) else None)
-            if t is not None and t.is_cuda and t.numel() >= (1 << 20):
+            if t is not None and t.is_cuda and t.numel() >= MIN_ELEMS:
                 frames = [f for f in traceback.extract_stack() if "multi_stylegan_amd" in f.filename and "tools" not in f.filename]
                 site = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in frames[-3:][::-1]) or "(outside the package)"
                 key = (name, tuple(t.shape), str(t.dtype)[6:], site)
@@ -71,5 +72,5 @@ with Spy():
 torch.cuda.synchronize()
 tot = sum(v[1] for v in SEEN.values())
 print(f"{len(SEEN)} sites, {tot / 1e9:.2f} GB of outputs >= 1 Mi elements")
-for (name, shape, dt, site), (n, b) in sorted(SEEN.items(), key=lambda kv: -kv[1][1])[:60]:
+for (name, shape, dt, site), (n, b) in sorted(SEEN.items(), key=lambda kv: -(kv[1][0] if MIN_ELEMS == 0 else kv[1][1]))[:60]:
     print(f"{b / 1e6:9.1f} MB {n:4d}x {name:10s} {str(shape):26s} {dt:9s} {site}")

@@ -94,7 +94,7 @@ static int pool_check(const void* a, const void* b, int dtype, int B, int H, int
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int vec = dtype == MSG_BF16 ? 8 : 4;
     if (H % 2 || W % 2 || C % vec || (((uintptr_t)a | (uintptr_t)b) & 15u)) return MSG_EUNSUPPORTED;
-    return -1;                                                        // go on
+    return 1;                                                         // go on (status codes are <= 0)
 }
 
 // x [B, H, W, C] channels-last with pixel pitch ldx (>= C) -> y [B, H/2, W/2, C] dense; idx (may be NULL: no backward will follow)
@@ -102,7 +102,7 @@ static int pool_check(const void* a, const void* b, int dtype, int B, int H, int
 extern "C" int msg_maxpool2x2_fwd(const void* x, void* y, unsigned short* idx, int dtype, int B, int H, int W, int C,
                                   long long ldx, void* stream) {
     const int rc = pool_check(x, y, dtype, B, H, W, C);
-    if (rc >= 0) return rc;
+    if (rc <= 0) return rc;
     const int vec = dtype == MSG_BF16 ? 8 : 4;
     if (ldx < C || ldx % vec) return MSG_EINVAL;
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / vec);
@@ -119,7 +119,7 @@ extern "C" int msg_maxpool2x2_fwd(const void* x, void* y, unsigned short* idx, i
 extern "C" int msg_maxpool2x2_bwd(const void* gy, const unsigned short* idx, void* gx, int dtype, int B, int H, int W, int C,
                                   void* stream) {
     const int rc = pool_check(gy, gx, dtype, B, H, W, C);
-    if (rc >= 0) return rc;
+    if (rc <= 0) return rc;
     if (!idx) return MSG_EINVAL;
     const int vec = dtype == MSG_BF16 ? 8 : 4;
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / vec);

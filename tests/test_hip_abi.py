@@ -139,3 +139,53 @@ def test_softmax_and_grouped_linear_entries(lib):
     assert lib.msg_linear_grouped_wgrad(y.data_ptr(), x.data_ptr(), slot.data_ptr(), None, None, 3, 2, 8, 8, 2, 1.0, 1.0,
                                         s) == EINVAL
     torch.cuda.synchronize()
+
+
+def test_round3_entries(lib):
+    """The entries added in round 3 reject what they cannot take instead of launching."""
+    s = torch.cuda.current_stream().cuda_stream
+    x, y, fir = _buf(), _buf(), _buf(16)
+    # output pitch below the channel count
+    assert lib.msg_upfirdn2d_pitched2(x.data_ptr(), fir.data_ptr(), y.data_ptr(), F32, 1, 8, 8, 4, 4, 2, 4, 4, 1, 1, 1, 1,
+                                      2, 1, 2, 1, s) == EINVAL
+    assert lib.msg_upfirdn2d_pitched2(x.data_ptr(), fir.data_ptr(), y.data_ptr(), F32, 1, 8, 8, 4, 4, 8, 4, 4, 1, 1, 1, 1,
+                                      2, 1, 2, 1, s) == OK
+    # channel sums: size not a multiple of C / missing workspace / ragged channel vectors
+    ws = _buf(1 << 16)
+    assert lib.msg_channel_sums(x.data_ptr(), y.data_ptr(), F32, 4096, 8, ws.data_ptr(), ws.numel(), s) == OK
+    assert lib.msg_channel_sums(x.data_ptr(), y.data_ptr(), F32, 4095, 8, ws.data_ptr(), ws.numel(), s) == EINVAL
+    assert lib.msg_channel_sums(x.data_ptr(), y.data_ptr(), F32, 4096, 8, None, 0, s) == EINVAL
+    assert lib.msg_channel_sums(x.data_ptr(), y.data_ptr(), F32, 4092, 3, ws.data_ptr(), ws.numel(), s) == EUNSUPPORTED
+    # max-pooling: odd maps, missing index map in backward
+    idx = torch.zeros(4096, device=DEV, dtype=torch.int16)
+    assert lib.msg_maxpool2x2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), F32, 1, 8, 8, 8, 8, s) == OK
+    assert lib.msg_maxpool2x2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), F32, 1, 7, 8, 8, 8, s) == EUNSUPPORTED
+    assert lib.msg_maxpool2x2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), F32, 1, 8, 8, 8, 4, s) == EINVAL      # pitch < C
+    assert lib.msg_maxpool2x2_bwd(x.data_ptr(), None, y.data_ptr(), F32, 1, 8, 8, 8, s) == EINVAL
+    assert lib.msg_maxpool2x2_fwd(x.data_ptr(), y.data_ptr(), None, F32, 0, 8, 8, 8, 8, s) == OK                     # empty batch
+    # gamma merge: null scalar, ragged length
+    g = _buf(1)
+    assert lib.msg_gamma_merge(x.data_ptr(), y.data_ptr(), g.data_ptr(), y.data_ptr(), F32, 64, 0.5, s) == OK
+    assert lib.msg_gamma_merge(x.data_ptr(), y.data_ptr(), None, y.data_ptr(), F32, 64, 0.5, s) == EINVAL
+    assert lib.msg_gamma_merge(x.data_ptr(), y.data_ptr(), g.data_ptr(), y.data_ptr(), F32, 63, 0.5, s) == EUNSUPPORTED
+    assert lib.msg_gamma_merge_backward(x.data_ptr(), y.data_ptr(), g.data_ptr(), y.data_ptr(), y.data_ptr(), g.data_ptr(), F32,
+                                        64, 0.5, None, s) == EINVAL                                                 # no workspace
+    # sign-byte activation backward: bf16 only, whole tiles
+    m = torch.zeros(4096, device=DEV, dtype=torch.uint8)
+    xb = _buf(4096, torch.bfloat16)
+    args = (xb.data_ptr(), m.data_ptr(), 1, 64, xb.data_ptr(), BF16, 4096, 64, None, None, None, 1, 64, 0.2, 1.0, None, 0, s)
+    assert lib.msg_bias_act_backward_mask(*args) == OK
+    assert lib.msg_bias_act_backward_mask(*args[:5], F32, *args[6:]) == EUNSUPPORTED
+    assert lib.msg_bias_act_backward_mask(*args[:2], 3, 64, *args[4:]) == EINVAL          # 64 pixels are not whole tiles of 3
+    assert lib.msg_bias_act_backward_mask(args[0], None, *args[2:]) == EINVAL
+    # the masked conv entry refuses problems whose kernel does not write the bytes (ask msg_conv2d_fprop_plan first)
+    w = _buf(64 * 64, torch.bfloat16)
+    assert lib.msg_conv2d_fprop_act_mask(xb.data_ptr(), w.data_ptr(), xb.data_ptr(), BF16, 1, 8, 8, 64, 64, 8, 8, 64, 64, 1, 1, 1, 0,
+                                         0, None, None, None, 1, 0.2, 1.0, m.data_ptr(), s) == EUNSUPPORTED
+    # small-map scalings: both outputs missing / reduction without the second operand
+    v = _buf(64)
+    assert lib.msg_scale_reduce_channels(x.data_ptr(), None, v.data_ptr(), y.data_ptr(), None, F32, 1, 16, 8, s) == OK
+    assert lib.msg_scale_reduce_channels(x.data_ptr(), None, v.data_ptr(), None, None, F32, 1, 16, 8, s) == EINVAL
+    assert lib.msg_scale_reduce_channels(x.data_ptr(), None, v.data_ptr(), None, v.data_ptr(), F32, 1, 16, 8, s) == EINVAL
+    assert lib.msg_scale_bias_act(x.data_ptr(), None, None, None, None, y.data_ptr(), F32, 1, 16, 6, 1, 0, 0.2, 1.0, s) == EUNSUPPORTED
+    torch.cuda.synchronize()

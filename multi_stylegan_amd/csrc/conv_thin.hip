@@ -143,6 +143,84 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const bf16_t* __restri
     }
 }
 
+// ---- K <= 8 again, with the pixel vectors fetched by SCALAR loads.  The kernel above waits for its (tiny) input loads with
+// s_waitcnt vmcnt, and vmcnt retires loads AND stores in order: every wait for the next pixels also waits for the previous
+// pixels' stores, so the store stream -- all this kernel is -- drains once per step (3.5 TB/s against a 6.9 TB/s fill).  A wave's
+// 64 / NV pixels are consecutive, i.e. one wave-uniform run of 16-byte vectors: fetched with s_load (its own counter,
+// lgkmcnt), one step ahead, they never touch vmcnt, and the stores stream.  Needs M % (64 / NV) == 0 (whole runs).
+template <int NV>
+__global__ __launch_bounds__(256) void conv_thin_k_sload_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                bf16_t* __restrict__ y, ThinParams p) {
+    constexpr int PPW = 64 / NV;                                     // pixels per wave and step
+    typedef unsigned int urun __attribute__((ext_vector_type(4 * PPW)));
+    typedef const __attribute__((address_space(4))) urun* crun_t;    // constant address space + uniform address = s_load
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int v = lane % NV, psub = lane / NV;
+    const long long s = blockIdx.y;
+    const bf16_t* xb = x + s * p.x_bstride;
+    const bf16_t* wb = w + s * p.w_bstride;
+    bf16_t* yb = y + s * p.y_bstride;
+    const bf16_t* rb = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + s * p.res_bstride : nullptr;
+    float wr[8][8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(wb + (long long)(v * 8 + j) * p.Ck);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[j][k] = bf2f((bf16_t)(raw[k >> 1] >> (16 * (k & 1))));
+        bv[j] = p.bias ? p.bias[v * 8 + j] : 0.f;
+    }
+    const long long n_groups = p.M / PPW;
+    const long long g0 = ((long long)blockIdx.x * 4 + wid) * p.groups_per_wave;
+    long long g1 = g0 + p.groups_per_wave;
+    if (g1 > n_groups) g1 = n_groups;
+    if (g0 >= g1) return;
+    auto fetch = [&](long long g) __attribute__((always_inline)) {
+        return *(crun_t)(reinterpret_cast<const char*>(xb) + g * (PPW * 16));
+    };
+    urun cur = fetch(g0);
+    urun nx1 = fetch(g0 + 1 < g1 ? g0 + 1 : g0);
+    u32x4 rcur = {0u, 0u, 0u, 0u};
+    if (rb) rcur = *reinterpret_cast<const u32x4*>(rb + (g0 * PPW + psub) * p.res_ld + v * 8);
+    for (long long g = g0; g < g1; ++g) {
+        const long long gn = g + 1 < g1 ? g + 1 : g;
+        const urun nxt = fetch(g + 2 < g1 ? g + 2 : g);               // the pixels of the step after next: lgkmcnt, not vmcnt
+        u32x4 rnxt = rcur;
+        if (rb) rnxt = *reinterpret_cast<const u32x4*>(rb + (gn * PPW + psub) * p.res_ld + v * 8);
+        // this lane's pixel out of the run
+        unsigned int xw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned int sel = cur[q];
+#pragma unroll
+            for (int pp = 1; pp < PPW; ++pp) sel = psub == pp ? cur[4 * pp + q] : sel;
+            xw[q] = sel;
+        }
+        float xv[8], acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[k] = bf2f((bf16_t)(xw[k >> 1] >> (16 * (k & 1))));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = bv[j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a = fmaf(xv[k], wr[j][k], a);
+            acc[j] = a;
+        }
+        if (rb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = (bf2f(f2bf(acc[j])) + bf2f((bf16_t)(rcur[j >> 1] >> (16 * (j & 1))))) * p.res_gain;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (unsigned)f2bf(acc[2 * j]) | ((unsigned)f2bf(acc[2 * j + 1]) << 16);
+        *reinterpret_cast<u32x4*>(yb + (g * PPW + psub) * p.ldy + v * 8) = o;
+        cur = nx1;
+        nx1 = nxt;
+        rcur = rnxt;
+    }
+}
+
 static int thin_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MSG_CONV_THIN"); v = e ? atoi(e) : 1; }
@@ -216,6 +294,17 @@ extern "C" int msg_conv2d_fprop_thin_try(const void* x, const void* w, const flo
     const long long blocks = (groups + 4ll * p.groups_per_wave - 1) / (4ll * p.groups_per_wave);
     if (blocks >= (1ll << 31) || samples > 65535) return 0;
     dim3 grid((unsigned)blocks, samples);
+    static int sload = -1;
+    if (sload < 0) { const char* e = getenv("MSG_THIN_SLOAD"); sload = e ? atoi(e) : 1; }
+    // (N = 512 only: 314 -> 238 us on 6 -> 512 @256^2, B=16; with 4 pixels per wave -- N = 128 -- it measured SLOWER, 158 -> 198 us)
+    if (sload && nv == 64 && p.M % ppw == 0 && (((uintptr_t)x) & 63u) == 0 && (p.x_bstride * 2) % 64 == 0) {
+        switch (nv) {
+#define THIN_KS(NV_) case NV_: hipLaunchKernelGGL((conv_thin_k_sload_kernel<NV_>), grid, dim3(256), 0, s, xp, wp, yp, p); return 1
+            THIN_KS(8); THIN_KS(16); THIN_KS(32); THIN_KS(64);
+#undef THIN_KS
+            default: return 0;
+        }
+    }
     switch (nv) {
 #define THIN_K(NV_) case NV_: hipLaunchKernelGGL((conv_thin_k_kernel<NV_, U>), grid, dim3(256), 0, s, xp, wp, yp, p); break
         THIN_K(8); THIN_K(16); THIN_K(32); THIN_K(64);

@@ -423,6 +423,7 @@ extern "C" int msg_conv2d_fprop_thin_try(const void* x, const void* w, const flo
 extern "C" int msg_conv2d_fprop_thin_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                                               int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,
                                               int act_mode);
+
 // Which kernel msg_conv2d_fprop would launch for this problem: 5 = the streaming kernels of conv_thin.hip (1x1, <= 8 channels on
 // one side; assuming no fused activation), 3 / 4 = conv_fprop_row3_kernel<4,4> / <2,2> (3x3 'same' convs
 // on wide maps, activation tile shared by the horizontal taps; 256x256 / 128x128 tile), 2 = conv_fprop_pp_kernel (256x256 ping-pong),

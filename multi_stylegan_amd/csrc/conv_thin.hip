@@ -313,3 +313,4 @@ extern "C" int msg_conv2d_fprop_thin_try(const void* x, const void* w, const flo
     }
     return 1;
 }
+

@@ -811,3 +811,4 @@ def test_channel_sums(shape, dtype):
     want = g.double().sum(dim=(0, 2, 3))
     assert rel_err(a.double(), want) < 1e-5
     assert rel_err(conv_ops._channel_sums(g.contiguous()).double(), want) < 1e-5          # (NCHW: library path)
+

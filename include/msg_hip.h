@@ -343,9 +343,12 @@ int msg_nonlocal_attention_bwd(const void* q, const void* qt, const void* k, con
  * N M^-1 N^-1 (N: pixel [0, size-1] -> [-1, 1]) -> pixel (grid_sample, align_corners), bilinear, padding 0 = zeros /
  * 2 = reflection.  (kaf.apply_affine passes -angle: the caller negates.)
  * backward != 0: x is the gradient of y, y receives the gradient of x (overwritten) -- the transpose of the bilinear
- * gather, a scatter, accumulated in 64-bit FIXED POINT (2^-38 resolution) in `workspace` (B*C*H*W 8-byte words, contents
- * irrelevant) and converted by a second launch: integer addition is associative, so the result does not depend on the
- * order in which the atomics arrive (deterministic).  workspace may be NULL for the forward.
+ * gather, a scatter, accumulated in 64-bit FIXED POINT (2^-38 resolution) in `workspace` (B*C*H*W + 1 8-byte words,
+ * contents irrelevant) and converted by a second launch: integer addition is associative, so the result does not depend on
+ * the order in which the atomics arrive (deterministic).  A contribution that is not finite or is >= 2^17 in magnitude
+ * has no fixed-point image: it raises the last workspace word and the gradient of every transformed image comes out NaN
+ * (a diverged gradient stays visible downstream instead of wrapping into finite values).  workspace may be NULL for
+ * the forward.
  * Parity unpinned, see oracle/ada.py. */
 int msg_affine_warp(const float* x, float* y, const float* angle_deg, float angle_const, const float* scale_xy,
                     const float* select_u, const float* p, int rot_prob, float cx, float cy, int padding,

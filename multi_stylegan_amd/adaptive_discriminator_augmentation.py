@@ -35,7 +35,8 @@ def _warp_launch(x, angle, angle_const, scale, u, p, rot_prob, center, padding, 
     b, c, h, w = x.shape
     y = torch.empty_like(x)
     # backward: the scatter accumulates in 64-bit fixed point (deterministic whatever the order of the atomics)
-    ws = torch.empty(x.numel(), dtype=torch.int64, device=dev) if backward else None
+    # (+ one word that a non-finite / out-of-range contribution raises: the gradient then comes out NaN, not wrapped)
+    ws = torch.empty(x.numel() + 1, dtype=torch.int64, device=dev) if backward else None
     with _lib.on_device(dev), _lib.kernel_clock.span("affine_warp/f32", 2 * x.numel() * 4):
         code = _lib.lib().msg_affine_warp(x.data_ptr(), y.data_ptr(), _lib.ptr(angle), float(angle_const), _lib.ptr(scale),
                                           u.data_ptr(), p.data_ptr(), int(rot_prob), float(center[0]), float(center[1]),

@@ -67,8 +67,11 @@ __device__ __forceinline__ bool source_position(const WarpParams& p, const float
 }
 
 // gradient contributions are accumulated as round(v * 2^38): resolution 3.6e-12 (image gradients of the mean-reduced losses
-// are 1e-8 .. 1e-2), range +-3.3e7 per pixel
+// are 1e-8 .. 1e-2), range +-3.3e7 per pixel.  RANGE ASSUMPTION, enforced: a single contribution must be finite and below
+// FIX_LIMIT = 2^17 in magnitude (2^55 in fixed point: 256 such contributions to one pixel still cannot wrap the 64-bit sum);
+// anything else raises the poison word behind the accumulators and the whole gradient comes out NaN.
 constexpr double FIX_SCALE = 274877906944.0, FIX_INV = 1.0 / 274877906944.0;
+constexpr float FIX_LIMIT = 131072.f;
 
 template <bool BACKWARD>
 __global__ __launch_bounds__(256) void affine_warp_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -106,7 +109,12 @@ __global__ __launch_bounds__(256) void affine_warp_kernel(const float* __restric
         } else {          // in = gy; acc = fixed-point gradient of x (zeroed): the transpose of the gather above
             const float g = ib[c * hw + rem];
             unsigned long long* s = acc + ((long long)b * p.C + c) * hw;
+            unsigned long long* poison = acc + (long long)p.B * p.C * hw;
             auto add = [&](long long idx, float v) __attribute__((always_inline)) {
+                // a non-finite or out-of-range contribution has no fixed-point image (the conversion is unspecified, the
+                // sum would wrap into finite garbage): raise the poison word instead -- the finish kernel then writes NaN,
+                // so a diverged gradient is still seen by the finite checks and the norm clipping downstream
+                if (!(fabsf(v) < FIX_LIMIT)) { atomicOr(poison, 1ull); return; }
                 atomicAdd(s + idx, (unsigned long long)__double2ll_rn((double)v * FIX_SCALE));   // two's complement wraps correctly
             };
             if (vy0 && vx0) add((long long)y0 * p.W + x0, g * w00);
@@ -128,7 +136,8 @@ __global__ __launch_bounds__(256) void affine_warp_finish_kernel(const float* __
     const int b = (int)(i / chw);
     const float pr = prob[0];
     const float thr = p.rot_prob ? 1.f - sqrtf(1.f - pr) : pr;
-    gx[i] = (u[b] <= thr) ? (float)((double)(long long)acc[i] * FIX_INV) : gy[i];
+    const bool poisoned = acc[(long long)p.B * chw] != 0;
+    gx[i] = (u[b] <= thr) ? (poisoned ? __builtin_nanf("") : (float)((double)(long long)acc[i] * FIX_INV)) : gy[i];
 }
 
 int launch(bool backward, const float* in, float* out, unsigned long long* acc, const float* angle, const float* scale,
@@ -140,7 +149,7 @@ int launch(bool backward, const float* in, float* out, unsigned long long* acc, 
         return MSG_CHECK_LAUNCH();
     }
     const long long elems = pixels * p.C;
-    if (hipMemsetAsync(acc, 0, sizeof(unsigned long long) * elems, s) != hipSuccess) return MSG_ELAUNCH;
+    if (hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (elems + 1), s) != hipSuccess) return MSG_ELAUNCH;   // + poison word
     hipLaunchKernelGGL(affine_warp_kernel<true>, dim3(blocks), dim3(256), 0, s, in, out, acc, angle, scale, u, prob, p);
     if (MSG_CHECK_LAUNCH() != MSG_OK) return MSG_ELAUNCH;
     hipLaunchKernelGGL(affine_warp_finish_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, in, out, acc, u, prob, p);

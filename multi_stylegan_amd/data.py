@@ -83,7 +83,8 @@ class DevicePrefetcher:
     """``for batch in DevicePrefetcher(loader, device)``: device-resident batches, copied ``depth`` iterations ahead on a
     copy stream from pinned staging buffers.  A yielded batch is valid until the consumer asks for the next one (its device
     buffer is then refilled, ordered behind everything the consumer has launched so far); clone it to keep it longer.
-    Batches that already live on the device pass through."""
+    Batches that already live on the device pass through without a copy, but still at most ``depth`` ahead of the
+    consumer (a lazy or infinite device-side generator is not drained into HBM)."""
 
     def __init__(self, loader: Iterable, device: Union[str, torch.device] = "cuda", depth: int = 2,
                  transfer_dtype: Optional[torch.dtype] = None):
@@ -108,9 +109,22 @@ class DevicePrefetcher:
         free = queue.Queue()
         for s in slots:
             free.put(s)
-        ready: "queue.Queue" = queue.Queue()
+        # Bounded: batches that need no copy take no slot, so the slot hand-shake alone would let a loader that yields
+        # device tensors lazily (or forever) be drained as fast as this thread runs -- an epoch resident in HBM.  At most
+        # `depth` batches wait here, whatever they are.
+        ready: "queue.Queue" = queue.Queue(maxsize=self.depth)
         stop = threading.Event()
         _END, _ERR = object(), object()
+
+        def put(item) -> bool:
+            """Blocking put that gives up when the consumer has gone away."""
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def worker():
             try:
@@ -118,7 +132,8 @@ class DevicePrefetcher:
                 for batch in self.loader:
                     tensors = _tensors(batch)
                     if not tensors or all(t.is_cuda for t in tensors):
-                        ready.put((None, batch))                          # nothing to copy
+                        if not put((None, batch)):                        # nothing to copy
+                            return
                         continue
                     slot = None
                     while slot is None:                                   # a free slot (the consumer returns them)
@@ -157,10 +172,11 @@ class DevicePrefetcher:
                         slot.ready.record(self.copy_stream)
                     it = iter(slot.out)
                     slot.batch = _map(lambda _t: next(it), batch)
-                    ready.put((slot, slot.batch))
-                ready.put((_END, None))
+                    if not put((slot, slot.batch)):
+                        return
+                put((_END, None))
             except BaseException as exc:                                  # surfaces in the consumer
-                ready.put((_ERR, exc))
+                put((_ERR, exc))
 
         thread = threading.Thread(target=worker, name="msg-prefetch", daemon=True)
         thread.start()

@@ -188,6 +188,7 @@ class GradBucketReducer:
         self._cold: List[int] = []
         self._shard_sumsq: Optional[torch.Tensor] = None
         self._detached = False              # the parameters' .grad are None for the armed backward (see grad_destination)
+        self._zeroed = True                 # the store is all zeros (fresh, or zero_grad() since the last labelled backward)
         self.direct = _DIRECT_GRADS
         self._slot_of = {}
         cap = max(1, bucket_bytes // 4)
@@ -229,6 +230,7 @@ class GradBucketReducer:
         return sum(b.flat.numel() for b in self.buckets)
 
     def zero_grad(self) -> None:
+        self._zeroed = True
         for b in self.buckets:
             b.flat.zero_()
             for p in b.params:                      # re-attach if something replaced .grad (e.g. set_to_none)
@@ -265,6 +267,13 @@ class GradBucketReducer:
         if label is not None and self.direct and self.buckets and self.buckets[0].flat.is_cuda:
             # (labelled = the trainer's backwards; the store was zeroed by zero_grad(), so a parameter this backward does not
             #  reach reads as a zero gradient once finish() has re-attached the views)
+            # The direct route OVERWRITES the store's slices, so it has no accumulate semantics: a labelled backward
+            # must follow a zero_grad() (two armed backwards in a row would drop the first one's directly written gradients
+            # and keep the ones routed through AccumulateGrad).  Enforced, not assumed.
+            if not self._zeroed:
+                raise RuntimeError("GradBucketReducer.arm(label): zero_grad() must run before every labelled backward "
+                                   "(gradients are written, not accumulated, into the flat store)")
+            self._zeroed = False
             self._detached = True
             for b in self.buckets:
                 for q in b.params:
@@ -366,16 +375,23 @@ class GradBucketReducer:
         for k in self._order[self._next:] + self._cold:   # whatever is left (incomplete hot buckets, then the cold ones)
             self._launch(self.buckets[k])
         self._next = len(self._order)
-        for b in self.buckets:
-            b.work.wait()
-        if self.exchange == "reduce_scatter":
-            if self.comm_stream is not None:
-                with torch.cuda.stream(self.comm_stream):
-                    self._gather_shards()
-            else:
-                self._gather_shards()
+        # Work.wait() orders the CURRENT stream behind the collective (which runs on the backend's own stream).  The second
+        # half of the reduce_scatter exchange runs on comm_stream, so the waits must happen with comm_stream current --
+        # waiting on the main stream left the shard norms free to read shards the reduce-scatters had not written yet.
         if self.comm_stream is not None:
-            torch.cuda.current_stream(self.buckets[0].flat.device).wait_stream(self.comm_stream)
+            main = torch.cuda.current_stream(self.buckets[0].flat.device)
+            with torch.cuda.stream(self.comm_stream):
+                for b in self.buckets:
+                    b.work.wait()
+                if self.exchange == "reduce_scatter":
+                    self._gather_shards()
+                    self._shard_sumsq.record_stream(main)          # allocated on comm_stream, consumed on the main stream
+            main.wait_stream(self.comm_stream)
+        else:
+            for b in self.buckets:
+                b.work.wait()
+            if self.exchange == "reduce_scatter":
+                self._gather_shards()
         if self._fired is not None:
             self._learn()
             self._fired = None

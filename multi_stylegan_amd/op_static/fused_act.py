@@ -129,8 +129,13 @@ class FusedLeakyReLUFunctionBackward(Function):
                     g.numel(), channels,
                     _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
                     _lib.ptr(ws), need, _lib.stream_of(dev))
-            _lib.check(code, "msg_bias_act_backward_mask")
+            if code == -2:                          # MSG_EUNSUPPORTED: the backward's vector path has stricter conditions
+                mask = None                         # (pointer alignment) than the forward's decision to write the bytes --
+            else:                                   # the stored output is still here, take the slower path instead of raising
+                _lib.check(code, "msg_bias_act_backward_mask")
         else:
+            mask = None
+        if mask is None:
             with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
                 code = _lib.lib().msg_bias_act_backward(
                     g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g, True), g.numel(), step_b, channels,

@@ -195,6 +195,27 @@ def test_affine_warp_random_geometry(padding, align):
         assert rel_err(xd.grad, xr.grad) < 2e-3, (trial, rel_err(xd.grad, xr.grad))
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf"), 1e9])
+def test_affine_warp_backward_keeps_a_blow_up_visible(bad):
+    """The scatter accumulates in 64-bit fixed point; a non-finite or out-of-range cotangent has no image there and used to
+    come out as finite garbage.  It must surface as NaN in the gradient of the transformed images (so finite checks and the
+    norm clipping see it) and leave copied-through images untouched."""
+    from multi_stylegan_amd.adaptive_discriminator_augmentation import affine_warp
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 2, 12, 10, generator=gen).to(DEV).requires_grad_(True)
+    u = torch.tensor([0.1, 0.9, 0.2], device=DEV)                        # image 1 is copied through at p = 0.5
+    y = affine_warp(x, u, torch.tensor(0.5, device=DEV), angle=torch.tensor([20.0, 0.0, -35.0], device=DEV),
+                    scale=torch.ones(3, 2, device=DEV), center=(4.5, 5.5), padding=2, align_corners=True)
+    gy = torch.randn(y.shape, generator=gen).to(DEV)
+    gx_ok, = torch.autograd.grad(y, x, gy, retain_graph=True)
+    assert torch.isfinite(gx_ok).all()
+    gy_bad = gy.clone()
+    gy_bad[0, 1, 5, 5] = bad
+    gx, = torch.autograd.grad(y, x, gy_bad)
+    assert not torch.isfinite(gx[0]).all() and not torch.isfinite(gx[2]).all()
+    assert torch.equal(gx[1], gy_bad[1])                                  # the pass-through image: the cotangent itself
+
+
 def test_wrapper_pair_forward_equals_two_calls(golden):
     """forward(cat([real, fake]), minibatch_groups=2) == forward(real, is_real=True) then forward(fake): same
     predictions on the same draws, the controller fed by the fake half only, both halves rewritten in place."""

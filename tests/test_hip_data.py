@@ -52,6 +52,31 @@ def test_prefetcher_surfaces_loader_errors():
         next(it)
 
 
+def test_prefetcher_does_not_drain_a_device_side_generator():
+    """Batches that already live on the device take no staging slot; the feed must still stay a bounded number of batches
+    ahead of its consumer (an infinite generator used to be drained into HBM by the worker thread)."""
+    from multi_stylegan_amd.data import DevicePrefetcher
+    produced = []
+
+    def endless():
+        i = 0
+        while True:
+            produced.append(i)
+            yield torch.full((4,), float(i), device=DEV)
+            i += 1
+    depth = 2
+    it = iter(DevicePrefetcher(endless(), DEV, depth=depth))
+    for want in range(5):
+        assert float(next(it)[0]) == want
+        time.sleep(0.2)                                     # the worker gets every chance to run ahead
+        # consumed want+1; the queue holds at most `depth`, one more may be waiting in the worker's blocked put
+        assert len(produced) <= want + 1 + depth + 1, (want, len(produced))
+    it.close()                                              # consumer leaves: the worker must stop, not spin
+    n = len(produced)
+    time.sleep(0.3)
+    assert len(produced) == n
+
+
 def test_synthetic_batches_are_device_side_and_reproducible():
     from multi_stylegan_amd.data import SyntheticBatches, prefetch
     a = [b.clone() for b in SyntheticBatches(3, 2, 32, DEV, seed=5)]

@@ -387,8 +387,8 @@ def test_checkpoint_reload_on_device(golden, tmp_path, paths):
         t.train_iteration(real.to(DEV), draws.to(DEV))
     (steps1, ema1), (steps2, ema2) = split_trace(tr.step_trace), split_trace(tr2.step_trace)
     for label in ("d", "g"):
-        # restored optimiser moments: the second Adam step's movement depends on them (float atomics in the
-        # weight-gradient kernels make gradients differ in the last bits, hence no bitwise comparison)
+        # restored optimiser moments: the second Adam step's movement depends on them (the two trainers may run different
+        # optimiser implementations -- torch's Adam vs the flat fused one -- hence tolerances, not a bitwise comparison)
         st = check_step_trace(steps2[label], steps1[label], tol_grad=1e-4, tol_norm=1e-5, tol_delta=2e-3)
         assert st["compared"] > 0.2 * st["total"]
     # (EMA movements are ~1e-4 of the parameters: between the two EMA implementations -- one fused multiply-add per element
@@ -491,6 +491,161 @@ def test_config2_256px_batch16_matches_oracle():
         assert max(e_g.values()) < tol_grad, (dt, e_g)
         del img, s, px
         torch.cuda.empty_cache()
+
+
+def _perturb_zero_inits(modules, gen_cpu):
+    """Move zero-initialised scalars and biases off zero so that they matter in a parity check."""
+    with torch.no_grad():
+        for mod in modules:
+            for n, p in mod.named_parameters():
+                if n.endswith("noise_injection.weight") or n.endswith("gamma"):
+                    p.copy_(torch.randn(p.shape, generator=gen_cpu) * 0.3)
+                elif n.endswith(".bias") and p.ndim == 1:
+                    p.add_(torch.randn(p.shape, generator=gen_cpu) * 0.1)
+
+
+G_WATCH = ["style_mapping.layers.1.weight", "style_mapping.layers.15.weight", "constant_input_1.input",
+           "starting_convolution_1.modulated_convolution.weight",
+           "main_convolutions_1.3.modulated_convolution.weight",
+           "main_convolutions_1.3.modulated_convolution.modulation_mapping.weight",
+           "main_convolutions_1.3.modulated_convolution.modulation_mapping.bias",
+           "main_convolutions_1.10.modulated_convolution.weight",
+           "main_convolutions_1.11.modulated_convolution.weight",
+           "main_convolutions_1.11.noise_injection.weight", "main_convolutions_1.11.activation.bias",
+           "output_blocks_1.5.modulated_convolution.weight", "output_blocks_2.5.modulated_convolution.weight",
+           "output_blocks_1.3.modulated_convolution.modulation_mapping.weight"]
+
+
+def test_config2_generator_backward_matches_oracle():
+    """The generator step of BASELINE config 2's model at its own size (256x256, 7 x 512 channels) END TO END against the
+    CPU oracle: G forward -> fixed D -> non-saturating logistic loss on both discriminator outputs -> backward
+    (reference: multi_stylegan_generator.py:114-205, model_wrapper.py:377-416, loss.py:144-170).  This is the pass that runs
+    the per-sample weight gradients of the row-sharing kernels, msg_modulate_backward, the up-conv data / weight
+    gradients, the blur + activation backward from sign bytes and the grouped affine gradients into the flat store at the
+    size the benchmark runs -- each covered at kernel level elsewhere, never before as one graph at this size.  Batch 2
+    (the oracle's backward takes ~1 min per sample on the box's CPU).  fp32 storage: 1e-3 (2e-3 weight gradients) of
+    max|ref|; bf16 storage (the benchmarked path): 0.1 norm-wise.  The dead second stream's main convolutions must stay
+    without a gradient."""
+    import time
+    import torch.nn.functional as F
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    from oracle import models as om
+    torch.manual_seed(51)
+    bsz = 2
+    cfg = generator_config_for_resolution(256)
+    go, do = om.Generator(cfg), om.Discriminator(no_rfp=True)
+    gen_cpu = torch.Generator().manual_seed(52)
+    _perturb_zero_inits([go, do], gen_cpu)
+    z = [torch.randn(bsz, 512, generator=gen_cpu), torch.randn(bsz, 512, generator=gen_cpu)]
+    noise = [torch.randn(bsz, 1, 4, 4, generator=gen_cpu)] + \
+            [torch.randn(bsz, 1, 2 ** (i // 2 + 3), 2 ** (i // 2 + 3), generator=gen_cpu) for i in range(12)]
+    t0 = time.time()
+    for p in do.parameters():
+        p.requires_grad_(False)
+    want_img = go(z, noise=noise, inject_index=5)
+    ws, wp = do(want_img)
+    want_loss = F.softplus(-ws).mean() + F.softplus(-wp).mean()
+    want_loss.backward()
+    gparams = dict(go.named_parameters())
+    want_grads = {n: gparams[n].grad.clone() for n in G_WATCH}
+    want_none = sorted(n for n, p in gparams.items() if p.grad is None)
+    want_img, want_loss = want_img.detach(), want_loss.detach()
+    go.zero_grad(set_to_none=True)
+    print(f"oracle on the CPU: {time.time() - t0:.1f} s")
+    assert any(n.startswith("main_convolutions_2.") for n in want_none)
+    gd = m.MultiStyleGANGenerator(cfg)
+    gd.load_state_dict(go.state_dict())
+    dd = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    dd.load_state_dict(do.state_dict())
+    gd.to(DEV); dd.to(DEV)
+    for p in dd.parameters():
+        p.requires_grad_(False)
+    for dt, tol_out, tol_grad in ((torch.float32, 1e-3, 2e-3), (torch.bfloat16, 5e-2, 0.1)):
+        gd.compute_dtype = dd.compute_dtype = dt
+        gd.zero_grad(set_to_none=True)
+        img = gd([t.to(DEV) for t in z], noise=[t.to(DEV) for t in noise], inject_index=5)
+        s, px = dd(img)
+        loss = F.softplus(-s.float()).mean() + F.softplus(-px.float()).mean()
+        loss.backward()
+        params = dict(gd.named_parameters())
+        none_grad = sorted(n for n, p in params.items() if p.grad is None)
+        assert none_grad == want_none, (dt, set(none_grad) ^ set(want_none))
+        e_img, e_loss = rel_err(img, want_img), rel_err(loss, want_loss)
+        if dt == torch.float32:
+            e_g = {n: rel_err(params[n].grad, want_grads[n]) for n in G_WATCH}
+        else:
+            e_g = {n: ((params[n].grad.cpu().float() - want_grads[n]).norm() / want_grads[n].norm()).item()
+                   for n in G_WATCH}
+        print(f"{dt}: image {e_img:.2e}  loss {e_loss:.2e}  G grads " + " ".join(f"{v:.1e}" for v in e_g.values()))
+        assert e_img < tol_out and e_loss < tol_out, (dt, e_img, e_loss)
+        assert max(e_g.values()) < tol_grad, (dt, e_g)
+        del img, s, px, loss
+        torch.cuda.empty_cache()
+
+
+def test_path_length_double_backward_512_channels_matches_oracle():
+    """The path-length regulariser's double backward (multi_stylegan_generator.py:193-200, loss.py:353-395) through a
+    generator with the real channel count -- 64x64, 5 x 512 channels (BASELINE config 1's generator), batch 2 -- against the
+    CPU oracle: the first-order latent gradients, the regulariser's value and the second-order parameter gradients.  The
+    golden fixtures hold this pass for 16-channel models only; here the native second-order node of the modulated conv
+    (msg_scale_rows_cols2 / msg_modulate_backward2) and the contraction kernels run on 512-channel per-sample weights."""
+    import time
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    from oracle import models as om
+    torch.manual_seed(61)
+    bsz, res = 2, 64
+    cfg = generator_config_for_resolution(res)
+    go = om.Generator(cfg)
+    gen_cpu = torch.Generator().manual_seed(62)
+    _perturb_zero_inits([go], gen_cpu)
+    z = [torch.randn(bsz, 512, generator=gen_cpu), torch.randn(bsz, 512, generator=gen_cpu)]
+    n_noise = 1 + 2 * (int(math.log2(res)) - 2)
+    noise = [torch.randn(bsz, 1, 4, 4, generator=gen_cpu)] + \
+            [torch.randn(bsz, 1, 2 ** (i // 2 + 3), 2 ** (i // 2 + 3), generator=gen_cpu) for i in range(n_noise - 1)]
+    image_noise = torch.randn(bsz, 2, 3, res, res, generator=gen_cpu)
+    watch = ["style_mapping.layers.1.weight", "style_mapping.layers.15.weight",
+             "starting_convolution_1.modulated_convolution.weight",
+             "main_convolutions_1.1.modulated_convolution.weight",
+             "main_convolutions_1.1.modulated_convolution.modulation_mapping.weight",
+             "main_convolutions_1.1.modulated_convolution.modulation_mapping.bias",
+             "main_convolutions_1.6.modulated_convolution.weight", "main_convolutions_1.7.modulated_convolution.weight",
+             "main_convolutions_1.7.modulated_convolution.modulation_mapping.weight",
+             "output_blocks_1.3.modulated_convolution.weight", "output_blocks_2.3.modulated_convolution.weight",
+             "constant_input_1.input"]
+
+    def regulariser(gen, dev):
+        img, lat = gen([t.to(dev) for t in z], return_main_style_vectors=True, noise=[t.to(dev) for t in noise],
+                       inject_index=3)
+        gr, = torch.autograd.grad((img * image_noise.to(dev)).sum() / math.sqrt(3 * res * res), lat, create_graph=True)
+        pl = torch.sqrt(gr.pow(2).sum(2).mean(1) + 1e-8).mean()
+        pl.backward()
+        return gr.detach(), pl.detach()
+
+    t0 = time.time()
+    want_gr, want_pl = regulariser(go, "cpu")
+    gparams = dict(go.named_parameters())
+    want_grads = {n: gparams[n].grad.clone() for n in watch}
+    print(f"oracle on the CPU: {time.time() - t0:.1f} s")
+    gd = m.MultiStyleGANGenerator(cfg)
+    gd.load_state_dict(go.state_dict())
+    gd.to(DEV)
+    for dt, tol, tol_grad in ((torch.float32, 1e-3, 2e-3), (torch.bfloat16, 5e-2, 0.1)):
+        gd.compute_dtype = dt
+        gd.zero_grad(set_to_none=True)
+        gr, pl = regulariser(gd, DEV)
+        params = dict(gd.named_parameters())
+        if dt == torch.float32:
+            e_gr, e_g = rel_err(gr, want_gr), {n: rel_err(params[n].grad, want_grads[n]) for n in watch}
+        else:
+            e_gr = ((gr.cpu().float() - want_gr).norm() / want_gr.norm()).item()
+            e_g = {n: ((params[n].grad.cpu().float() - want_grads[n]).norm() / want_grads[n].norm()).item() for n in watch}
+        e_pl = rel_err(pl, want_pl)
+        print(f"{dt}: latent grads {e_gr:.2e}  path length {e_pl:.2e}  second-order grads " +
+              " ".join(f"{v:.1e}" for v in e_g.values()))
+        assert e_gr < (tol if dt == torch.float32 else tol_grad) and e_pl < tol, (dt, e_gr, e_pl)
+        assert max(e_g.values()) < tol_grad, (dt, e_g)
 
 
 def test_config4_512px_matches_oracle():

@@ -211,20 +211,6 @@ long long msg_conv2d_wgrad_workspace(int dtype, int B, int IH, int IW, int Cx, i
  *                          the caller sums over the first axis); d = NULL means "no demodulation".
  *                          Limits: I <= 512, taps <= 9, B <= 16 (else MSG_EUNSUPPORTED).
  * ------------------------------------------------------------------------- */
-/* The activation-scaling form of the modulated convolution on SMALL maps,
- *   conv(x, d_b * scale * W * s_b) = d_b * conv(s_b * x, scale * W),
- * keeps the weights shared (msg_conv2d_fprop / msg_conv2d_wgrad with the batch folded in) and moves the modulation onto
- * the activations (multi_stylegan_generator.py:384-411 on the 4^2 .. 32^2 layers, where the per-sample form's time is the
- * per-sample WEIGHTS).  Dense channels-last maps [B][P][C], MSG_F32 / MSG_BF16, C a whole number of 16-byte vectors:
- *   msg_scale_reduce_channels: out[b,p,c] = in[b,p,c] * v[b,c] (out may be NULL) and red[b,c] = sum_p in[b,p,c] * other[b,p,c]
- *                              (red / other may be NULL); v, red fp32 [B][C]; fixed-order sums.
- *   msg_scale_bias_act:        y = act_on ? leaky_relu(c * d[b,n] + noise_weight[0] * noise[b or 0, p] + bias[n], alpha) * scale
- *                                         : c * d[b,n];   d fp32 [B][C] or NULL (= 1). */
-int msg_scale_reduce_channels(const void* in, const void* other, const float* v, void* out, float* red, int dtype,
-                              int B, int P, int C, void* stream);
-int msg_scale_bias_act(const void* c, const float* d, const float* bias, const float* noise, const float* noise_weight,
-                       void* y, int dtype, int B, int P, int C, int noise_batch, int act_on, float alpha, float scale,
-                       void* stream);
 int msg_demod_coeff(const float* W, const float* s, float* d, int B, int O, int I, int taps,
                     float scale, float eps, void* stream);
 int msg_scale_rows_cols(const float* base, const float* rowscale, const float* colscale, void* out,

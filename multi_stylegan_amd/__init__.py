@@ -9,7 +9,8 @@ from .loss import PathLengthRegularization, TopK
 from .model_wrapper import Draws, ModelWrapper
 from .multi_stylegan_generator import Generator as MultiStyleGANGenerator
 from .u_net_2d_discriminator import Discriminator as MultiStyleGANDiscriminator
+from .validation_metrics import FID, FVD, IS
 
 __all__ = ["MultiStyleGANGenerator", "MultiStyleGANDiscriminator", "ModelWrapper", "Draws", "PathLengthRegularization",
            "TopK", "AdaptiveDiscriminatorAugmentation", "AugmentationPipeline", "GeneratorSampler", "load_generator_ema", "split_sequences", "validation_samples",
-           "DevicePrefetcher", "SyntheticBatches", "multi_style_gan_generator_config", "u_net_2d_discriminator_config", "generation_hyperparameters"]
+           "DevicePrefetcher", "SyntheticBatches", "IS", "FID", "FVD", "multi_style_gan_generator_config", "u_net_2d_discriminator_config", "generation_hyperparameters"]

@@ -71,8 +71,6 @@ _SIGNATURES = {
     "msg_conv2d_fprop_plan": (_I, [_I] * 11 + [_L]),
     "msg_conv2d_fprop_upconv_eligible": (_I, [_I] * 14 + [_L]),
     "msg_conv2d_fprop_thin_eligible": (_I, [_I] * 16),
-    "msg_scale_reduce_channels": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "msg_scale_bias_act": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "msg_maxpool2x2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _L, _P]),
     "msg_maxpool2x2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msg_linear_fprop": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),

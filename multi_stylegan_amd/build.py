@@ -23,22 +23,33 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def lib_path(variant=None):
+    return LIB if not variant else os.path.join(HERE, f"libmsg_hip_{variant}.so")
+
+
+def is_stale(variant=None):
+    lib = lib_path(variant)
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "msg_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra_flags=()):
-    if not force and not is_stale():
-        return LIB
+def build(force=False, verbose=True, extra_flags=(), variant=None):
+    """``variant``: a diagnostic / A-B build kept BESIDE the product library as libmsg_hip_<variant>.so (objects in
+    build_<variant>/), loaded by tools through MSG_LIB_VARIANT=<variant>; e.g. ``--variant tuning --flags=-DMSG_TUNING`` (the
+    kernel-selection constants of csrc/msg_common.h read MSG_* environment variables) or ``--variant stamps
+    --flags=-DMSG_ROW3_STAMPS``.  The product library (no variant) is what tests, smoke and bench.py load."""
+    lib = lib_path(variant)
+    if not force and not is_stale(variant):
+        return lib
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objdir = os.path.join(HERE, "build" if not variant else f"build_{variant}")
+    os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         deps = [src] + glob.glob(os.path.join(CSRC, "*.h"))
         objs.append(obj)
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
@@ -51,13 +62,18 @@ def build(force=False, verbose=True, extra_flags=()):
     for src, pr in procs:
         if pr.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--variant", default=None)
+    ap.add_argument("--flags", default="", help="extra hipcc flags, e.g. --flags=-DMSG_TUNING")
+    a = ap.parse_args()
+    print(build(force=a.force, extra_flags=tuple(a.flags.split()), variant=a.variant))

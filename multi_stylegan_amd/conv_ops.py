@@ -208,12 +208,9 @@ def _alloc_out(b: int, n: int, h: int, w: int, dtype, device) -> Tuple[torch.Ten
     return buf.permute(0, 3, 1, 2)[:, :n], ld
 
 
-_FUSED_RELAYOUT = bool(int(os.environ.get("MSG_FUSED_RELAYOUT", "1")))   # 0: torch transpose-copies (A/B)
-
-
 def _relayout_kernel_ok(w, dtype, taps) -> bool:
     return w.is_cuda and w.dtype == torch.float32 and dtype in (torch.bfloat16, torch.float32) and \
-        taps <= 16 and w.ndim >= 4 and _FUSED_RELAYOUT
+        taps <= 16 and w.ndim >= 4
 
 
 def _relay_fwd(w: torch.Tensor, dtype) -> Tuple[torch.Tensor, int]:
@@ -359,7 +356,7 @@ def _param_images(w, dtype, gain, kind, modulation=False):
     kernel (csrc/relayout.hip) per weight update and cached on the parameter.  `modulation`: the fp32, unpadded base
     images + wsq that the modulated conv scales per sample.  Returns None when the fast path does not apply (then the
     torch re-layout functions are used)."""
-    if not (isinstance(w, torch.nn.Parameter) and w.is_cuda and w.dtype == torch.float32 and _FUSED_RELAYOUT):
+    if not (isinstance(w, torch.nn.Parameter) and w.is_cuda and w.dtype == torch.float32):
         return None
     o, i = _oi(w)
     t = w.numel() // (o * i)
@@ -391,8 +388,6 @@ def _param_images(w, dtype, gain, kind, modulation=False):
 
 
 # --------------------------------------------------------------------------------------------------- raw launches
-FUSE_ACTIVATION = bool(int(os.environ.get("MSG_FUSE_ACT", "1")))     # 0: two-pass conv + activation (A/B; results are bit-identical)
-_S2_PARITY = bool(int(os.environ.get("MSG_S2_PARITY", "1")))          # 0: zero-insertion form of the stride-2 data gradient (A/B)
 _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
 
 
@@ -567,14 +562,11 @@ def _relay_fwd_kind(w, dtype, kind):
     return wk, ck
 
 
-_THIN_INPUT = bool(int(os.environ.get("MSG_THIN_INPUT", "1")))       # 0: no tap gathering for few-channel inputs (A/B)
-
-
 def _thin_ok(dtype, i, g: Geometry) -> bool:
     """A 'same' kh x kw conv whose (tap, channel) pairs fit ONE 128-byte K run (the discriminator's 6-channel first layer):
     it runs as a 1x1 conv over the tap-gathered input (msg_gather_taps)."""
     taps = g.kh * g.kw
-    return _THIN_INPUT and g.kind == "conv" and g.stride == 1 and not g.per_sample and taps > 1 and \
+    return g.kind == "conv" and g.stride == 1 and not g.per_sample and taps > 1 and \
         2 * g.pad + 1 == g.kh and g.kh == g.kw and i * taps <= 128 // (2 if dtype == torch.bfloat16 else 4)
 
 
@@ -641,7 +633,7 @@ def _d_raw(gy, w, g: Geometry, residual=None):
     """Data gradient; residual = (map shaped like the result, gain): (dgrad + map) * gain in the epilogue (plain
     stride-1 convs only -- the caller checks)."""
     assert residual is None or (g.kind == "conv" and g.stride == 1)
-    if g.kind == "conv" and g.stride == 2 and _S2_PARITY and _oi(w)[1] % _vec(gy.dtype) == 0:
+    if g.kind == "conv" and g.stride == 2 and _oi(w)[1] % _vec(gy.dtype) == 0:
         return _d_raw_s2(gy, w, g)          # (the pixel-shuffling epilogue needs whole 16-byte channel vectors)
     i = _oi(w)[1]
     img = _param_images(w, gy.dtype, g.wscale, g.kind) if not g.per_sample else None
@@ -1392,7 +1384,7 @@ def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, n
     return (gx, gw, gs, gwk) if keep_gwk else (gx, gw, gs)
 
 
-_NATIVE_SECOND_ORDER = bool(int(os.environ.get("MSG_MODCONV_NATIVE2", "1")))   # 0: the composite torch-op graph (A/B, tests)
+_NATIVE_SECOND_ORDER = True       # tests flip it to check the native second-order node against the composite torch-op graph
 
 
 def _modconv_second_order_composite(gy, x, weight, style, demodulate, upsample, a, cot_w, cot_s, want):
@@ -1612,184 +1604,10 @@ class _ModulatedConv(Function):
         return (gx, gw, gs) + tail
 
 
-# Maps of at most this many pixels take the ACTIVATION-SCALING form of the modulated conv (non-upsampling layers):
-# conv(x, d * scale * W * s) = d * conv(s * x, scale * W).  0 = never, the default.  Measured twice: round 2 as a composite of
-# torch ops (-2 ms of this package's kernels, +3.5 ms of launch-bound elementwise ops per iteration at 1024 pixels), round 3 as
-# _ModulatedConvSmall with the scalings and their sums in three small kernels of their own (csrc/modsmall.hip): plain
-# iteration 105.2 -> 106.0 ms.  The per-sample form moves 75 MB of weights per layer and pass but in six launches; this one
-# moves a few MB in nineteen, and on maps of 16 .. 1024 pixels every launch is a drain and a refill of the chip.  Kept as an
-# A/B switch (tools/smallmap_probe.py), tested against the per-sample form and the fp64 definition.
-_SMALL_MAP_PIXELS = int(os.environ.get("MSG_MODCONV_SMALL_MAP", "0"))
-_SECOND_ORDER_EXPECTED = [0]
-
-
-class expect_second_order:
-    """Context: the forward passes inside will be differentiated TWICE (the path-length pass).  The small-map form's
-    second-order graph is the torch composite; the per-sample form has native second-order kernels (_ModConvGrad), so
-    those passes keep it."""
-
-    def __enter__(self):
-        _SECOND_ORDER_EXPECTED[0] += 1
-
-    def __exit__(self, *exc):
-        _SECOND_ORDER_EXPECTED[0] -= 1
-        return False
-
-
-def _small_map(x, weight) -> bool:
-    # (not the 6-channel RGB heads: their weight sets are tiny)
-    return x.is_cuda and x.ndim == 4 and x.shape[2] * x.shape[3] <= _SMALL_MAP_PIXELS and weight.shape[0] == 1 and \
-        weight.shape[1] >= 64 and weight.shape[1] % 8 == 0 and weight.shape[2] % 8 == 0 and not _SECOND_ORDER_EXPECTED[0] and \
-        x.dtype in (torch.float32, torch.bfloat16)
-
-
-def _dense_cl(t):
-    """[B,C,H,W] as a dense channels-last map (pixel pitch == C)."""
-    return t if (t.stride(1) == 1 and t.stride(3) == t.shape[1] and t.is_contiguous(memory_format=torch.channels_last)) \
-        else t.contiguous(memory_format=torch.channels_last)
-
-
-def _scale_reduce(inp, other, v, want_out=True, want_red=False):
-    """(inp * v[b, c], sum_p inp * other) on dense channels-last maps -- csrc/modsmall.hip."""
-    dev = inp.device
-    b, c, h, w = inp.shape
-    out = torch.empty_like(inp) if want_out else None
-    red = torch.empty((b, c), dtype=torch.float32, device=dev) if want_red else None
-    with _lib.on_device(dev):
-        code = _lib.lib().msg_scale_reduce_channels(inp.data_ptr(), _lib.ptr(other if want_red else None), v.data_ptr(),
-                                                    _lib.ptr(out), _lib.ptr(red), _lib.dtype_code(inp), b, h * w, c,
-                                                    _lib.stream_of(dev))
-    _lib.check(code, "msg_scale_reduce_channels")
-    return out, red
-
-
-class _ModulatedConvSmall(Function):
-    """The modulated (demodulated) 3x3 / 1x1 'same' convolution of a small map in the activation-scaling form, optionally
-    with the layer's noise + bias + leaky ReLU behind it:  y = act(d * conv(s * x, scale * W) + noise_w * noise + bias).
-    Shared weights (cached kernel-side images, the batch folded into the weight gradient's contraction), three small
-    kernels for the scalings and their sums, the demodulation's own derivative in closed form.  First order only: a
-    second-order request differentiates the torch composite (see expect_second_order)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, style, demodulate, act_bias, noise, noise_w, alpha, act_scale, fuse_act):
-        dev = _lib.require_gpu(x, weight, style, act_bias, noise, noise_w)
-        b, i, h, w = x.shape
-        _, o, _, kh, kw = weight.shape
-        scale = math.sqrt(2.0) / math.sqrt(i * kh * kw)
-        s32 = style.detach().to(torch.float32).contiguous()
-        xv = _dense_cl(x.detach())
-        xs, _ = _scale_reduce(xv, None, s32)
-        g = Geometry("conv", kh, kw, 1, kh // 2, (h, w), False, scale)
-        c = _dense_cl(_f_raw(xs, weight, None, g))
-        d = None
-        if demodulate:
-            d = torch.empty((b, o), dtype=torch.float32, device=dev)
-            w3 = weight.detach()[0].contiguous()
-            with _lib.on_device(dev):
-                code = _lib.lib().msg_demod_coeff(w3.data_ptr(), s32.data_ptr(), d.data_ptr(), b, o, i, kh * kw, scale, 1e-8,
-                                                  _lib.stream_of(dev))
-            _lib.check(code, "msg_demod_coeff")
-        if d is None and not fuse_act:
-            y = c
-        else:
-            b32, nz, nw = _act_operands(act_bias, noise, noise_w, (b, o, h, w)) if fuse_act else (None, None, None)
-            y = torch.empty_like(c)
-            with _lib.on_device(dev):
-                code = _lib.lib().msg_scale_bias_act(c.data_ptr(), _lib.ptr(d), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(nw),
-                                                     y.data_ptr(), _lib.dtype_code(c), b, h * w, o,
-                                                     1 if nz is None else nz.shape[0], int(bool(fuse_act)), float(alpha),
-                                                     float(act_scale), _lib.stream_of(dev))
-            _lib.check(code, "msg_scale_bias_act")
-        ctx.save_for_backward(x, xs, weight, style, d if d is not None else torch.empty(0, device=dev), c, y,
-                              noise if fuse_act else None, noise_w if fuse_act else None)
-        ctx.cfg = (bool(demodulate), g, scale, bool(fuse_act), float(alpha), float(act_scale))
-        ctx.bias_param = act_bias if fuse_act else None
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, xs, weight, style, d, c, y, noise, noise_w = ctx.saved_tensors
-        demodulate, g, scale, fuse_act, alpha, act_scale = ctx.cfg
-        bias = ctx.bias_param
-        need = ctx.needs_input_grad
-        if torch.is_grad_enabled():
-            # second-order graph wanted after all: the composite, differentiated by autograd (the saved inputs carry their
-            # history, so the result stays on the graph)
-            with torch.enable_grad():
-                leaves = [t if (t is not None and t.requires_grad) else (None if t is None else t.detach().requires_grad_(nd))
-                          for t, nd in ((x, need[0]), (weight, need[1]), (style, need[2]), (bias, need[4]), (noise_w, need[6]))]
-                xx, ww, ss, bb, nn_ = leaves
-                out = _modulated_small_map(xx, ww, ss, demodulate, False)
-                if fuse_act:
-                    from .op_static.fused_act import fused_bias_noise_leaky_relu
-                    out = fused_bias_noise_leaky_relu(out, bb, noise, nn_, alpha, act_scale)
-                ins = [t for t in leaves if t is not None and t.requires_grad]
-                grads = list(torch.autograd.grad(out, ins, gy, create_graph=True, allow_unused=True))
-            res = [grads.pop(0) if (t is not None and t.requires_grad) else None for t in leaves]
-            return res[0], res[1], res[2], None, res[3], None, res[4], None, None, None
-        xv = _dense_cl(x.detach())
-        b, i, h, w = xv.shape
-        o = weight.shape[1]
-        gb = gnw = None
-        gpre = gy
-        if fuse_act:
-            from .op_static.fused_act import FusedLeakyReLUFunctionBackward
-            gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise, bias if bias is not None else False, alpha,
-                                                                 act_scale)
-            gb = gb if (bias is not None and need[4]) else None
-            gnw = gnw.reshape(noise_w.shape) if (noise is not None and need[6]) else None
-        gpre = _dense_cl(gpre)
-        s32 = style.detach().to(torch.float32).contiguous()
-        gd = None
-        if demodulate:
-            gc, gd = _scale_reduce(gpre, c, d, want_red=True)          # g * d,  sum_p g * conv
-        else:
-            gc = gpre
-        gx = gw = gs = None
-        if need[0] or need[2]:
-            gxs = _dense_cl(_d_raw(gc, weight, g))
-            gx, gs = _scale_reduce(gxs, xv, s32, want_out=need[0], want_red=need[2])      # gxs * s,  sum_p gxs * x
-        if need[1]:
-            gw = _g_raw(gc, xs, o, i, g).reshape(weight.shape)
-        if demodulate and (need[1] or need[2]):
-            # d = (scale^2 sum_i s_i^2 wsq[o, i] + eps)^-1/2:  dd/ds_i = -d^3 scale^2 s_i wsq[o, i],  dd/dW = -d^3 scale^2 s_i^2 W
-            coef = gd * d.pow(3) * (-(scale * scale))                   # [B, O]
-            if need[2]:
-                w3 = weight.detach()[0].reshape(o, i, -1)
-                wsq = _cached(weight, "wsq", torch.float32, 1.0, lambda: (w3.square().sum(dim=2).contiguous(), 0))[0]
-                gs = torch.addcmul(gs, s32, coef @ wsq)
-            if need[1]:
-                gw = torch.addcmul(gw, weight.detach(), (coef.t() @ s32.square()).reshape(1, o, i, 1, 1))
-        return gx, gw, (gs.to(style.dtype) if gs is not None else None), None, gb, None, gnw, None, None, None
-
-
-def _modulated_small_map(x, weight, style, demodulate, upsample):
-    """The same function as the per-sample-weight form, with the modulation moved onto the activations:
-
-        conv(x, d_b * scale * W * s_b) = d_b * conv(s_b * x, scale * W)        (s per input channel, d per output channel)
-
-    On the low-resolution layers (4^2 .. 32^2) the per-sample form spends its time on the WEIGHTS: 75 MB of per-sample
-    weights written and read per 512-channel layer and pass, a 151 MB per-sample weight gradient and its reduction
-    (msg_modulate_backward) -- for maps of 16 .. 1024 pixels.  Here the weights stay shared (cached kernel-side images,
-    batch folded into the weight gradient's K), the two scalings touch a few MB of activations, and every piece is an
-    existing differentiable op, so the second-order graph of the path-length regulariser needs no composite either."""
-    _, out_c, in_c, kh, kw = weight.shape
-    scale = math.sqrt(2.0) / math.sqrt(in_c * kh * kw)
-    xs = x * style[:, :, None, None].to(x.dtype)
-    g = Geometry("up2" if upsample else "conv", kh, kw, 1, kh // 2, x.shape[2:], False, scale)
-    y = _ConvF.apply(xs, weight, None, g)       # (the [1, O, I, kh, kw] parameter itself: its kernel-side images are cached)
-    if demodulate:
-        y = y * demod_coefficients(weight, style, scale)[:, :, None, None].to(y.dtype)
-    return y
-
-
 def modulated_conv2d_bias_act(x, weight, style, demodulate, act_bias, noise, noise_weight, negative_slope=0.2,
                               scale=1.0):
     """modulated_conv2d (no upsampling) -> noise injection -> bias -> leaky ReLU, the activation stage fused into the
     contraction's epilogue (multi_stylegan_generator.py:267-292 + 384-411 in one pass over the output map)."""
-    if _small_map(x, weight):
-        return _ModulatedConvSmall.apply(x, weight, style, bool(demodulate), act_bias, noise, noise_weight,
-                                         float(negative_slope), float(scale), True)
     return _ModulatedConv.apply(x, weight, style, bool(demodulate), False, act_bias, noise, noise_weight,
                                 float(negative_slope), float(scale), True)
 
@@ -1799,6 +1617,4 @@ def modulated_conv2d(x, weight, style, demodulate, upsample):
 
     One weight set per sample, w_b = d[b,o] * scale * W[o,i,k] * s[b,i] (multi_stylegan_generator.py:384-388), and
     one batched contraction (grid.z = sample) instead of the reference's groups=batch library conv."""
-    if not upsample and _small_map(x, weight):
-        return _ModulatedConvSmall.apply(x, weight, style, bool(demodulate), None, None, None, 0.2, 1.0, False)
     return _ModulatedConv.apply(x, weight, style, bool(demodulate), bool(upsample))

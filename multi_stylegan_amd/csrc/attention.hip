@@ -468,8 +468,7 @@ __global__ void nl_attn_reduce_kernel(const float* __restrict__ part, T* __restr
 
 // MSG_ATTN_PREFETCH (A/B switch): bit 0 forward, bit 1 dQ kernel stage through registers one block ahead.  Default 0: measured slower in every kernel (the registers it holds cost more than the latency it hides).
 int prefetch_mode() {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("MSG_ATTN_PREFETCH"); mode = e ? atoi(e) : 0; }
+    static const int mode = msg_tunable("MSG_ATTN_PREFETCH", 0);
     return mode;
 }
 
@@ -535,8 +534,7 @@ extern "C" int msg_nonlocal_attention_fwd(const void* q, const void* k, const vo
 // How many ways msg_nonlocal_attention_bwd splits the query sweep of its dK / dV kernel (1, 2, 4 or 8: enough
 // workgroups for the 256 CUs); with more than one the caller provides `workspace`, nsplit * B * Nk * (dk + dv) floats.
 extern "C" int msg_nonlocal_attention_bwd_splits(int B, int Nq, int Nk) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("MSG_ATTN_SPLITS"); forced = e ? atoi(e) : 0; }
+    static const int forced = msg_tunable("MSG_ATTN_SPLITS", 0);
     if (forced > 0 && Nq % (forced * 128) == 0) return forced;
     int nsplit = 1;
     while (nsplit < 8 && (long long)B * (Nk / 128) * nsplit < 384 && (Nq / nsplit) % 128 == 0 && Nq / nsplit >= 512)

@@ -206,11 +206,9 @@ static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x
     if (kh != 4 || kw != 4 || minor % vec || (((uintptr_t)x | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
     const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
     if (oh <= 0 || ow <= 0) return MSG_EINVAL;
-    static int xcd = -1;
-    if (xcd < 0) { const char* e = getenv("MSG_BLUR_XCD"); xcd = e ? atoi(e) : 1; }
+    static const int xcd = msg_tunable("MSG_BLUR_XCD", 1);
     BlurParams p{major, in_h, in_w, oh, ow, minor / vec, pad_x0, pad_y0, 0, act};
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("MSG_BLUR_VARIANT"); variant = e ? atoi(e) : 0; }
+    static const int variant = msg_tunable("MSG_BLUR_VARIANT", 0);
     const long long threads = (long long)((ow + 1) / 2) * p.CV;
     const long long gx = (threads + 255) / 256;
     // rows per lane: 32 amortises the 3 warm-up rows best (4.36 vs 3.48 TB/s on 512ch @256^2), as long as the grid still

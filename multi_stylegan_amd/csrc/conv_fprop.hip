@@ -440,8 +440,7 @@ extern "C" int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, i
     if (dtype == MSG_BF16 && msg_conv2d_fprop_pp_eligible(B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride)) return 2;
     const int esz = dtype == MSG_BF16 ? 2 : 4;
     const int n_iters = kh * kw * (Ck / (128 / esz));
-    const char* e = getenv("MSG_CONV_VARIANT");
-    const int variant = e ? atoi(e) : 0;
+    static const int variant = msg_tunable("MSG_CONV_VARIANT", 0);
     return (variant == 1 || (variant == 0 && n_iters >= 12)) ? 1 : 0;
 }
 
@@ -545,13 +544,11 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
     dim3 grid((unsigned)blocks, 1, p.per_sample ? B : 1);
     hipStream_t s = (hipStream_t)stream;
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("MSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+    static const int variant = msg_tunable("MSG_CONV_VARIANT", 0);
     // staging: LDS-DMA (global_load_lds) for long K sweeps, register staging (two steps in flight) for short ones;
     // MSG_CONV_VARIANT=1 / 2 forces DMA / registers (A/B measurements)
     const bool dma = variant == 1 || (variant == 0 && p.n_iters >= 12);
-    static int lean_max = -1;                       // MSG_CONV_LEAN=<n>: lean variant for n_iters <= n (0 = never)
-    if (lean_max < 0) { const char* e = getenv("MSG_CONV_LEAN"); lean_max = e ? atoi(e) : 4; }
+    static const int lean_max = msg_tunable("MSG_CONV_LEAN", 4);                       // MSG_CONV_LEAN=<n>: lean variant for n_iters <= n (0 = never)
     if (dtype == MSG_BF16) {
         if (!dma && p.n_iters <= lean_max) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
         else if (dma) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);

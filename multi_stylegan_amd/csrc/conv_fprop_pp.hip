@@ -380,8 +380,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
 // Which shapes take the large tile (shared by the launcher below and by msg_conv2d_fprop_plan).
 extern "C" int msg_conv2d_fprop_pp_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                             int kh, int kw, long long w_batch_stride) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("MSG_CONV_PP"); enabled = e ? atoi(e) : 1; }
+    static const int enabled = msg_tunable("MSG_CONV_PP", 1);
     if (!enabled) return 0;
     const bool per_sample = w_batch_stride != 0;
     const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;

@@ -505,25 +505,21 @@ static int row3_tile_columns(int N) {
 // output map equals its input map is the stride-1, pad-1, no-zero-insertion 'same' convolution.
 extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N,
                                               int kh, int kw, long long w_batch_stride) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("MSG_CONV_ROW3"); enabled = e ? atoi(e) : 1; }
+    static const int enabled = msg_tunable("MSG_CONV_ROW3", 1);
     if (!enabled || kh != 3 || kw != 3 || IH != OH || IW != OW || Ck % 64 || Cx % 64) return 0;
     const bool per_sample = w_batch_stride != 0;
     const long long mtot = per_sample ? (long long)OH * OW : (long long)B * OH * OW;
     // The 128 x 128 variant (two workgroups per CU) takes the layers with 128 / 384 output channels from the plain 128x128
     // kernel: 3x3 128->128 @256^2 516 -> 476 us, 256->128 @256^2 866 -> 819, 256->384 @128^2 650 -> 614, 384->384 @64^2
     // 235 -> 205.  MSG_CONV_ROW3_NARROW=0 switches it off (A/B).
-    static int narrow = -1;
-    if (narrow < 0) { const char* e = getenv("MSG_CONV_ROW3_NARROW"); narrow = e ? atoi(e) : 1; }
+    static const int narrow = msg_tunable("MSG_CONV_ROW3_NARROW", 1);
     // 32-wide maps: the 128 x 128 tile holds four image rows (4 x 34 = 136 buffer rows) whatever the channel count:
     // 3x3 768->768 @32^2, B=16: 229 -> 179 us, 1024->768: 318 -> 272 (they ran on the ping-pong kernel).  MSG_CONV_ROW3_W32=0: off.
-    static int w32 = -1;
-    if (w32 < 0) { const char* e = getenv("MSG_CONV_ROW3_W32"); w32 = e ? atoi(e) : 1; }
+    static const int w32 = msg_tunable("MSG_CONV_ROW3_W32", 1);
     int hn = row3_tile_columns(N);
     // short K (few channels): a 256 x 256 tile's prologue and epilogue are not amortised and nothing overlaps them with one
     // workgroup per CU; the 128 x 128 tile runs two.  MSG_CONV_ROW3_SHORTK = largest Ck that prefers the small tile.
-    static int shortk = -1;
-    if (shortk < 0) { const char* e = getenv("MSG_CONV_ROW3_SHORTK"); shortk = e ? atoi(e) : 128; }   // (3x3 128->256 @256^2, B=32: 632 -> 609 us)
+    static const int shortk = msg_tunable("MSG_CONV_ROW3_SHORTK", 128);   // (3x3 128->256 @256^2, B=32: 632 -> 609 us)
     if (hn == 256 && Ck <= shortk && N % 128 == 0) hn = 128;
     if (OW == 32 && w32 && N >= 128 && (long long)((N + 127) / 128) * 128 * 100 <= (long long)N * 115) hn = 128;
     if (!hn || (hn == 128 && !narrow) || N % hn) return 0;
@@ -568,10 +564,8 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     const long long blocks = (long long)p.m_tiles * p.n_tiles;
     dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);
     // MSG_CONV_ROW3_S16=0: the 256 x 256 tile on v_mfma_f32_32x32x16_bf16 (A/B)
-    static int s16 = -1;
-    if (s16 < 0) { const char* e = getenv("MSG_CONV_ROW3_S16"); s16 = e ? atoi(e) : 1; }
-    static int s16n = -1;
-    if (s16n < 0) { const char* e = getenv("MSG_CONV_ROW3N_S16"); s16n = e ? atoi(e) : 1; }    // (the 128 x 128 tile: +2..6 %)
+    static const int s16 = msg_tunable("MSG_CONV_ROW3_S16", 1);
+    static const int s16n = msg_tunable("MSG_CONV_ROW3N_S16", 1);    // (the 128 x 128 tile: +2..6 %)
     if (hn == 256 && s16)
         hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);

@@ -222,8 +222,7 @@ __global__ __launch_bounds__(256) void conv_thin_k_sload_kernel(const bf16_t* __
 }
 
 static int thin_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MSG_CONV_THIN"); v = e ? atoi(e) : 1; }
+    static const int v = msg_tunable("MSG_CONV_THIN", 1);
     return v;
 }
 
@@ -294,8 +293,7 @@ extern "C" int msg_conv2d_fprop_thin_try(const void* x, const void* w, const flo
     const long long blocks = (groups + 4ll * p.groups_per_wave - 1) / (4ll * p.groups_per_wave);
     if (blocks >= (1ll << 31) || samples > 65535) return 0;
     dim3 grid((unsigned)blocks, samples);
-    static int sload = -1;
-    if (sload < 0) { const char* e = getenv("MSG_THIN_SLOAD"); sload = e ? atoi(e) : 1; }
+    static const int sload = msg_tunable("MSG_THIN_SLOAD", 1);
     // (N = 512 only: 314 -> 238 us on 6 -> 512 @256^2, B=16; with 4 pixels per wave -- N = 128 -- it measured SLOWER, 158 -> 198 us)
     if (sload && nv == 64 && p.M % ppw == 0 && (((uintptr_t)x) & 63u) == 0 && (p.x_bstride * 2) % 64 == 0) {
         switch (nv) {

@@ -185,8 +185,7 @@ __global__ __launch_bounds__(64 * UC_WAVES, 1) void conv_upconv_kernel(const bf1
 
 extern "C" int msg_conv2d_fprop_upconv_eligible(int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int kh, int kw,
                                                 int stride, int pad, int in_up, int pixel_shuffle, long long w_batch_stride) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("MSG_CONV_UPCONV"); enabled = e ? atoi(e) : 1; }
+    static const int enabled = msg_tunable("MSG_CONV_UPCONV", 1);
     if (!enabled || !pixel_shuffle || w_batch_stride == 0 || kh != 1 || kw != 1 || stride != 1 || pad != 0 || in_up != 1)
         return 0;
     if (Cx != UC_K || Ck != UC_K || N % 256 || (N / 4) % 64 || IH != OH || IW != OW) return 0;
@@ -214,8 +213,7 @@ extern "C" int msg_conv2d_fprop_upconv_try(const void* x, const void* w, const f
     p.w_bstride = w_batch_stride;
     p.y_bstride = 4ll * OH * OW * ldy;
     p.m_tiles = (int)(((long long)OH * OW + UC_M - 1) / UC_M);
-    static int xcd_order = -1;                               // MSG_UPCONV_XCD=0: plain sample-major order (A/B)
-    if (xcd_order < 0) { const char* e = getenv("MSG_UPCONV_XCD"); xcd_order = e ? atoi(e) : 1; }
+    static const int xcd_order = msg_tunable("MSG_UPCONV_XCD", 1);                               // MSG_UPCONV_XCD=0: plain sample-major order (A/B)
     p.xcd_samples = xcd_order && B % 8 == 0;
     dim3 grid((unsigned)((long long)p.m_tiles * B));
     hipLaunchKernelGGL(conv_upconv_kernel, grid, dim3(64 * UC_WAVES), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,

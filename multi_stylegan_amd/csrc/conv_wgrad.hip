@@ -459,8 +459,7 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
     p.pix_per_chunk = (((npix + k_chunks - 1) / k_chunks + kp - 1) / kp) * kp;
     long long zs = (long long)B * k_chunks;
     // uniform-row addressing: K-steps map onto whole rows / whole row fragments and per-sample tensors fit 31-bit offsets
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("MSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+    static const int variant = msg_tunable("MSG_CONV_VARIANT", 0);
     const long long gy_bytes = (long long)(pixel_shuffle ? 4 : 1) * OH * OW * ldgy * esz;
     const long long x_bytes = (long long)IH * IW * Cx * esz;
     bool uni = variant != 2 && variant != 1 && (kp % OW == 0 || OW % kp == 0) && gy_bytes < (1ll << 31) &&
@@ -479,12 +478,9 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
         // a fixed prologue/epilogue cost of ~8 steps, + ~MSG_WGRAD_SLAB_COST steps when the sum is split: a workgroup's
         // 64-KiB slab tile is written once and read once by the reduce).  A fixed target count left a quarter of the chip
         // idle in the last round on some layers (768->768 @32^2: 5 chunks = 3.2 rounds, 274 us; 3 chunks = 1.9 rounds, 226 us).
-        static int target_wgs = -1;                      // MSG_WGRAD_TARGET_WGS > 0: the old fixed-target rule (A/B)
-        if (target_wgs < 0) { const char* e = getenv("MSG_WGRAD_TARGET_WGS"); target_wgs = e ? atoi(e) : 0; }
-        static int slice_tiles = -1;                     // MSG_WGRAD_SLICE_TILES: largest channel-tile count that takes the slice-per-XCD order
-        if (slice_tiles < 0) { const char* e = getenv("MSG_WGRAD_SLICE_TILES"); slice_tiles = e ? atoi(e) : 6; }
-        static int slab_cost = -1;
-        if (slab_cost < 0) { const char* e = getenv("MSG_WGRAD_SLAB_COST"); slab_cost = e ? atoi(e) : 6; }
+        static const int target_wgs = msg_tunable("MSG_WGRAD_TARGET_WGS", 0);                      // MSG_WGRAD_TARGET_WGS > 0: the old fixed-target rule (A/B)
+        static const int slice_tiles = msg_tunable("MSG_WGRAD_SLICE_TILES", 6);                     // MSG_WGRAD_SLICE_TILES: largest channel-tile count that takes the slice-per-XCD order
+        static const int slab_cost = msg_tunable("MSG_WGRAD_SLAB_COST", 6);
         const bool sliced = tiles <= (long long)kh * kw * slice_tiles;       // slices are dealt to the XCDs 8 at a time
         long long chunks = 1;
         if (target_wgs > 0) {
@@ -521,8 +517,7 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
     p.oi_major = oi_major;
     p.gain = gain;
     p.nz = (int)zs;
-    static int slice_tiles2 = -1;
-    if (slice_tiles2 < 0) { const char* e = getenv("MSG_WGRAD_SLICE_TILES"); slice_tiles2 = e ? atoi(e) : 6; }
+    static const int slice_tiles2 = msg_tunable("MSG_WGRAD_SLICE_TILES", 6);
     p.xcd_slices = (p.o_tiles * p.i_tiles <= slice_tiles2 && variant != 4 && (slice_tiles2 == 1 || zs % 8 == 0 || zs >= 64)) ||
                    (variant == 5 && zs % 8 == 0);   // 4 / 5: A/B switches
     const long long nblk = (p.xcd_slices ? ((zs + 7) / 8) * 8 : zs) * p.o_tiles * p.i_tiles * kh * kw;

@@ -571,10 +571,8 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
                                          int kh, int kw, int stride, int pad, int pixel_shuffle,
                                          int per_sample, int k_chunks, int oi_major, float gain,
                                          float* ws, long long ws_floats, int plan_only, long long* need, void* stream) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("MSG_WGRAD_ROW3"); enabled = e ? atoi(e) : 1; }
-    static int w32_on = -1;                         // MSG_WGRAD_ROW3_W32=0: 32-wide maps stay on conv_wgrad_kernel (A/B)
-    if (w32_on < 0) { const char* e = getenv("MSG_WGRAD_ROW3_W32"); w32_on = e ? atoi(e) : 1; }
+    static const int enabled = msg_tunable("MSG_WGRAD_ROW3", 1);
+    static const int w32_on = msg_tunable("MSG_WGRAD_ROW3_W32", 1);                         // MSG_WGRAD_ROW3_W32=0: 32-wide maps stay on conv_wgrad_kernel (A/B)
     const bool w32 = w32_on && OW == 32 && OH % 2 == 0;
     if (!enabled || dtype != MSG_BF16 || kw != 3 || stride != 1 || pixel_shuffle || (OW % R3_KP && !w32) || IH != OH ||
         IW != OW || pad != 1 || kh > 3)
@@ -606,8 +604,7 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
         // shared weights: the batch is folded into K; K split by the wave-quantisation cost model of conv_wgrad.hip
         // with ONE workgroup per CU (rounds of 256), ~3 steps of fixed cost per workgroup and, when the sum is split, the
         // write + read of a workgroup's three 64-KiB slab tiles (~MSG_WGRAD3_SLAB_COST steps)
-        static int slab_cost = -1;
-        if (slab_cost < 0) { const char* e = getenv("MSG_WGRAD3_SLAB_COST"); slab_cost = e ? atoi(e) : 4; }
+        static const int slab_cost = msg_tunable("MSG_WGRAD3_SLAB_COST", 4);
         const long long steps = (long long)B * steps_per_sample;
         long long chunks = 1, best = -1;
         const long long cmax = steps / 4 < 4096 ? steps / 4 : 4096;
@@ -629,8 +626,7 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     *need = p.split ? zs * p.slab : 0;
     if (plan_only) return 1;
     if (p.split && (!ws || ws_floats < *need)) return MSG_EINVAL;
-    static int s16 = -1;                            // MSG_WGRAD_ROW3_S16=0: the 32x32x16 kernel (A/B)
-    if (s16 < 0) { const char* e = getenv("MSG_WGRAD_ROW3_S16"); s16 = e ? atoi(e) : 1; }
+    static const int s16 = msg_tunable("MSG_WGRAD_ROW3_S16", 1);                            // MSG_WGRAD_ROW3_S16=0: the 32x32x16 kernel (A/B)
     // (measured, bf16, B = 16, same box: 3x3 512->512 @256^2 per-sample 4235 -> 3930 us, @128^2 1079 -> 1010, 128->128 @256^2
     //  shared 318 -> 305, 384->256 @128^2 447 -> 421; 32-wide maps: 768->768 265 -> 254, 1024->768 333 -> 317)
     if (s16 && w32)

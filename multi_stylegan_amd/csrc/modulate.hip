@@ -786,8 +786,7 @@ extern "C" int msg_modulate_backward(const float* gwk, const float* W, const flo
     if (I > 256 * MB_SLOTS || taps > MB_TAPS || B > MB_BMAX / 2) return MSG_EUNSUPPORTED;
     const int groups = (O + o_group - 1) / o_group;
     hipStream_t st = (hipStream_t)stream;
-    static int v4 = -1;
-    if (v4 < 0) { const char* e = getenv("MSG_MODBWD_V4"); v4 = e ? atoi(e) : 1; }
+    static const int v4 = msg_tunable("MSG_MODBWD_V4", 1);
     if (v4 && I % 4 == 0 && ldg % 4 == 0 && !(((uintptr_t)gwk | (uintptr_t)W | (uintptr_t)s | (uintptr_t)gW | (uintptr_t)gs_part) & 15u)) {
         const bool ok = d ? modulate_backward_v4_launch<true>(gwk, W, s, d, gW, gs_part, B, O, I, taps, ldg, o_group, scale, groups, st)
                           : modulate_backward_v4_launch<false>(gwk, W, s, d, gW, gs_part, B, O, I, taps, ldg, o_group, scale, groups, st);

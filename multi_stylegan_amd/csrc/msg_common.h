@@ -3,7 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/msg_hip.h"
+
+// Kernel-selection and cost-model constants.  In the library that ships (and that bench.py measures) every one of them IS
+// its default: `msg_tunable` is a constant expression there, the alternatives are dead code that the compiler drops, and
+// the library reads no environment variable.  Only a -DMSG_TUNING build (the variant libraries of tools/, loaded through
+// tools' MSG_LIB_VARIANT) reads MSG_* variables, for A/B measurements of alternatives whose verdicts DESIGN.md records.
+#ifdef MSG_TUNING
+static inline int msg_tunable(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+#define msg_tunable(name, dflt) (dflt)
+#endif
 
 typedef float  f32x4 __attribute__((ext_vector_type(4)));
 typedef float  f32x16 __attribute__((ext_vector_type(16)));

@@ -200,8 +200,7 @@ extern "C" int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, 
     const long long total = (long long)B * H * W * (Ko / vec);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipStream_t s = (hipStream_t)stream;
-    static int lds_path = -1;
-    if (lds_path < 0) { const char* e = getenv("MSG_GATHER_LDS"); lds_path = e ? atoi(e) : 1; }
+    static const int lds_path = msg_tunable("MSG_GATHER_LDS", 1);
     if (lds_path && dtype == MSG_BF16 && kh == 3 && kw == 3 && pad == 1 && Cx == 8 && Ko == 64 && W % 32 == 0) {
         const long long n_seg = (long long)B * H * (W / 32);
         const unsigned nb = (unsigned)(n_seg < 16384 ? n_seg : 16384);

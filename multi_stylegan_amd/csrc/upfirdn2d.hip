@@ -204,8 +204,7 @@ __global__ __launch_bounds__(256, (PIPE ? 3 : 2)) void upfirdn2d_vec_kernel(cons
 }
 
 static int fir_variant() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MSG_FIR_VARIANT"); v = e ? atoi(e) : 0; }
+    static const int v = msg_tunable("MSG_FIR_VARIANT", 0);
     return v;
 }
 

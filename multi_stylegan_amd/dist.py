@@ -113,7 +113,7 @@ class _GradSlot:
         self.reducer, self.bucket, self.offset, self.taken = reducer, bucket, offset, False
 
 
-_DIRECT_GRADS = bool(int(os.environ.get("MSG_DIRECT_GRADS", "1")))     # 0: every gradient through autograd's accumulation add (A/B)
+_DIRECT_GRADS = True     # gradients are written straight into the flat store (False: through autograd's accumulation adds)
 
 
 def grad_destination(p: torch.Tensor) -> Optional[torch.Tensor]:

@@ -37,7 +37,7 @@ class EqualizedConv2d(nn.Module):
     def forward_activated(self, input: torch.Tensor, activation, grad_slot=None, out_grad_scale=None) -> torch.Tensor:
         """``activation(self(input))`` for a following FusedLeakyReLU, its bias + leaky ReLU fused into this conv's
         epilogue (one pass over the output map instead of two; same result bit for bit)."""
-        if self.bias is not None or not input.is_cuda or not conv_ops.FUSE_ACTIVATION:
+        if self.bias is not None or not input.is_cuda:
             return activation(self(input))
         return conv_ops.conv2d_bias_act(input, self.weight, activation.bias, stride=self.stride, padding=self.padding,
                                         wscale=self.scale, negative_slope=activation.negative_slope,

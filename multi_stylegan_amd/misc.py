@@ -1,5 +1,5 @@
-"""Hot-path helpers with the reference's names: style-mixing noise and the EMA step
-(multi_stylegan/misc.py:183-199, 238-252)."""
+"""Hot-path helpers with the reference's names: style-mixing noise, the EMA step and the batch-wise range
+normalisations of the validation metrics (multi_stylegan/misc.py:183-199, 216-235, 238-252)."""
 import random
 from typing import List, Union
 
@@ -11,6 +11,20 @@ def get_noise(batch_size: int, latent_dimension, p_mixed_noise: float = 0.9, dev
     if (p_mixed_noise > 0) and (random.random() < p_mixed_noise):
         return list(torch.randn(2, batch_size, latent_dimension, dtype=torch.float32, device=device).unbind(0))
     return torch.randn(batch_size, latent_dimension, dtype=torch.float32, device=device)
+
+
+def normalize_0_1_batch(input: torch.Tensor) -> torch.Tensor:
+    """Every sample of a 5-D batch mapped to its own [0, 1] range and then clamped from BELOW at 1e-3 (reference
+    misc.py:216-225: the clamp is the reference's, values under 1e-3 are raised to it)."""
+    flat = input.reshape(input.shape[0], -1)
+    lo = flat.min(dim=1)[0][:, None, None, None, None]
+    hi = flat.max(dim=1)[0][:, None, None, None, None]
+    return ((input - lo) / (hi - lo)).clamp(min=1e-03)
+
+
+def normalize_m1_1_batch(input: torch.Tensor) -> torch.Tensor:
+    """2 * normalize_0_1_batch(x) - 1 (reference misc.py:228-235)."""
+    return 2. * normalize_0_1_batch(input) - 1.
 
 
 def random_permutation(n: int) -> torch.Tensor:

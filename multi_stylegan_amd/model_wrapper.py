@@ -15,7 +15,7 @@ import math
 import os
 import random
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional, Union
+from typing import Any, Dict, List, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -76,8 +76,10 @@ class ModelWrapper(object):
                  bucket_bytes: int = 32 << 20, overlap_communication: bool = True,
                  skip_discriminator_weight_grads_in_generator_step: bool = False,
                  fused_optimizer: Optional[bool] = None, batch_discriminator_passes: bool = True,
-                 flat_optimizer_step: bool = True) -> None:
+                 flat_optimizer_step: bool = True, validation_metrics: Tuple[Any, ...] = ()) -> None:
         self.device = torch.device(device)
+        self.validation_metrics = tuple(validation_metrics)     # reference model_wrapper.py:29,69 (validation_metrics.IS / FID / FVD)
+        self.best_fvd = float("inf")                            # reference :97
         self.generator = generator.to(self.device)
         self.discriminator = discriminator.to(self.device)
         self.hyperparameters = hyperparameters
@@ -375,13 +377,33 @@ class ModelWrapper(object):
         for real_images in msg_data.prefetch(training_dataset, self.device):
             self.train_iteration(real_images, resume_training=resume_training, top_k=top_k)
 
+    @torch.no_grad()
+    def validation(self, training_dataset) -> Dict[str, float]:
+        """The reference's ``validation`` (model_wrapper.py:197-243): every metric of ``validation_metrics`` on the EMA
+        generator and the training data, scores logged as ``<Class>_bf`` / ``_gfp`` / ``_rfp`` (returned, and kept in the
+        wrapper's log), the best bright-field FVD remembered."""
+        self.generator_ema.eval()
+        scores_out: Dict[str, float] = {}
+        for metric in self.validation_metrics:
+            scores = metric(generator=self.generator_ema, dataset=training_dataset)
+            name = metric.__class__.__name__
+            if isinstance(scores, (int, float)):
+                scores = (float(scores),)
+            for suffix, value in zip(("_bf", "_gfp", "_rfp"), scores):
+                scores_out[name + suffix] = float(value)
+            if "FVD" in name and self.best_fvd > scores[0]:
+                self.best_fvd = float(scores[0])
+        self._record(**{k: torch.tensor(v) for k, v in scores_out.items()})
+        return scores_out
+
     def train(self, training_dataset, epochs: int = 20, save_model_after_n_epochs: int = 5,
               resume_training: bool = False, top_k: bool = False, checkpoint_directory: Optional[str] = None,
-              on_epoch_end=None) -> None:
+              on_epoch_end=None, validate_after_n_epochs: int = 10) -> None:
         """The reference's ``train`` (model_wrapper.py:104-195) restricted to the hot path: top-k schedule set-up
-        (:115-125), the epoch loop, a checkpoint in the reference's layout every ``save_model_after_n_epochs`` epochs
-        (:179-192, written by rank 0).  Sample dumps, metric validation and the process-title / progress-bar plumbing
-        are outside the scope; ``on_epoch_end(wrapper, epoch)`` is the hook for them."""
+        (:115-125), the epoch loop, the metric validation every ``validate_after_n_epochs`` epochs when the wrapper was
+        given ``validation_metrics`` (:175-177), a checkpoint in the reference's layout every ``save_model_after_n_epochs``
+        epochs (:179-192, written by rank 0).  Sample dumps and the process-title / progress-bar plumbing are outside
+        the scope; ``on_epoch_end(wrapper, epoch)`` is the hook for them."""
         steps_per_epoch = len(training_dataset)
         top_k_module: Optional[nn.Module] = None
         if top_k:
@@ -397,6 +419,8 @@ class ModelWrapper(object):
             self._gan_training(training_dataset, resume_training=resume_training, top_k=top_k_module)
             if on_epoch_end is not None:
                 on_epoch_end(self, self.epoch)
+            if self.validation_metrics and (self.epoch + 1) % validate_after_n_epochs == 0:
+                self.validation(training_dataset)
             if checkpoint_directory is not None and (self.epoch + 1) % save_model_after_n_epochs == 0:
                 self.save_checkpoint(os.path.join(checkpoint_directory, f"checkpoint_{self.epoch + 1}.pt"))
 

@@ -13,7 +13,6 @@ path is laid out for MI355X:
   ``elide_dead_branch=True`` -- outputs and gradients are identical either way.
 """
 import math
-import os
 from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
@@ -23,11 +22,6 @@ import torch.nn as nn
 from . import conv_ops, equalized_layer
 from .op_static import FusedLeakyReLU, blur_bias_act, fused_bias_noise_leaky_relu, upfirdn2d
 
-# 0: the two RGB heads of a level as two modulated convs (A/B; same result up to the rounding of one bf16 add)
-PAIR_OUTPUT_HEADS = bool(int(os.environ.get("MSG_PAIR_HEADS", "1")))
-# 0: every styled layer runs its own modulation_mapping launch (A/B; identical arithmetic per layer)
-GROUP_STYLE_AFFINES = bool(int(os.environ.get("MSG_GROUP_AFFINES", "1")))
-BATCH_NOISE_DRAWS = bool(int(os.environ.get("MSG_BATCH_NOISE", "1")))     # 0: one normal draw per NoiseInjection (A/B)
 
 
 def _fir2d(taps, gain=1.0):
@@ -154,7 +148,7 @@ class StyledConv2d(nn.Module):
 
     def forward(self, input: torch.Tensor, style: torch.Tensor, noise: torch.Tensor = None):
         mc = self.modulated_convolution
-        if not mc.upsampling and conv_ops.FUSE_ACTIVATION and input.is_cuda:
+        if not mc.upsampling and input.is_cuda:
             # conv -> noise -> bias -> leaky ReLU in one launch (the upsampling layers blur in between: two passes)
             bsz = input.shape[0]
             style_out = _modulated_style(mc, style, bsz)
@@ -164,7 +158,7 @@ class StyledConv2d(nn.Module):
                 input, mc.weight, style_out.reshape(bsz, mc.in_channels), mc.demodulate, self.activation.bias, noise,
                 self.noise_injection.weight, self.activation.negative_slope, self.activation.scale)
             return (output, style_out) if self.modulation_mapping else output
-        if mc.upsampling and conv_ops.FUSE_ACTIVATION and input.is_cuda:
+        if mc.upsampling and input.is_cuda:
             # transposed conv -> [blur -> noise -> bias -> leaky ReLU] with the bracket in one launch
             result = mc(input, style, skip_blur=True)
             output, style_out = result if self.modulation_mapping else (result, None)
@@ -303,7 +297,7 @@ class Generator(nn.Module):
     def _all_styles(self, latent: torch.Tensor):
         """All style affines (multi_stylegan_generator.py:379-382, one EqualizedLinear per styled layer) in ONE grouped
         launch: they only depend on the latent.  None when the layers are not uniform (then each layer maps its own)."""
-        if not (GROUP_STYLE_AFFINES and latent.is_cuda and latent.dtype == torch.float32):
+        if not (latent.is_cuda and latent.dtype == torch.float32):
             return None
         groups = self._style_groups()
         maps = [mc.modulation_mapping for mc, _ in groups]
@@ -315,7 +309,7 @@ class Generator(nn.Module):
         return out.unbind(0)
 
     def _heads_pairable(self, features: torch.Tensor) -> bool:
-        if not (PAIR_OUTPUT_HEADS and features.is_cuda):
+        if not features.is_cuda:
             return False
         for h1, h2 in zip(self.output_blocks_1, self.output_blocks_2):
             m1, m2 = h1.modulated_convolution, h2.modulated_convolution
@@ -348,19 +342,14 @@ class Generator(nn.Module):
                 noise: Optional[List[torch.Tensor]] = None, randomize_noise: bool = True,
                 inject_index: Optional[int] = None, input_is_latent: bool = False,
                 return_path_length_grads: bool = False, path_length_noise: Optional[torch.Tensor] = None):
-        if return_path_length_grads:
-            # (this pass is differentiated twice: the layers keep the forms that have native second-order kernels)
-            with conv_ops.expect_second_order():
-                return self._forward(input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent,
-                                     True, path_length_noise)
-        return self._forward(input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent, False,
-                             path_length_noise)
+        return self._forward(input, return_main_style_vectors, noise, randomize_noise, inject_index, input_is_latent,
+                             bool(return_path_length_grads), path_length_noise)
 
     def _draw_layer_noise(self, latent):
         """Every NoiseInjection's own N(0, 1) map (the reference draws one per layer and stream when no noise is passed,
         multi_stylegan_generator.py:288-292) out of ONE normal draw per forward instead of ~27 launches of a few microseconds'
         work each: -> (start 1, start 2, [stream-1 layers], [stream-2 layers]) as views of one buffer, or None off the GPU."""
-        if not latent.is_cuda or not BATCH_NOISE_DRAWS:
+        if not latent.is_cuda:
             return None
         b = latent.shape[0]
         res0 = tuple(self.constant_input_1.input.shape[2:])

@@ -7,18 +7,14 @@ log-sum-exp, the first-order backward recomputes the probabilities tile by tile.
 block (R1 on the discriminator, every 16th iteration) is built from the composite formulation instead -- plain torch
 products and softmax, recomputed inside backward -- which is the only place the map still materialises.
 """
-import os
 
 import torch
 from torch.autograd import Function
 
 from .. import _lib
 
-FUSED_ATTENTION = bool(int(os.environ.get("MSG_FUSED_ATTENTION", "1")))      # 0: bmm -> softmax kernel -> bmm (A/B)
-
-
 def supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
-    if not (FUSED_ATTENTION and q.is_cuda and q.dtype in (torch.float32, torch.bfloat16)
+    if not (q.is_cuda and q.dtype in (torch.float32, torch.bfloat16)
             and q.dtype == k.dtype == v.dtype and q.ndim == 3):
         return False
     return bool(_lib.lib().msg_nonlocal_attention_supported(q.shape[0], q.shape[1], k.shape[1], q.shape[2], v.shape[2]))

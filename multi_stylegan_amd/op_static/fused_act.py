@@ -5,7 +5,6 @@ function default sqrt(2)).  ``fused_bias_noise_leaky_relu`` additionally folds t
 ``NoiseInjection`` (multi_stylegan_generator.py:288-292) into the same pass; its parameters stay where the
 reference keeps them (``noise_injection.weight``, ``activation.bias``).
 """
-import os
 
 import torch
 from torch import nn
@@ -68,7 +67,7 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
     return y.reshape(shape) if y.shape != shape else y
 
 
-ACT_MASK = bool(int(os.environ.get("MSG_ACT_MASK", "1")))      # 0: the activation backward always reads the stored output (A/B; bit-identical)
+ACT_MASK = True      # False: the activation backward always reads the stored output (tests compare both: bit-identical)
 
 
 def sign_mask_for(b, c, h, w, dtype, device):
@@ -224,9 +223,6 @@ class _ScaledAdd(Function):
         return g, g, None
 
 
-GAMMA_MERGE = bool(int(os.environ.get("MSG_GAMMA_MERGE", "1")))      # 0: gamma * a, then scaled_add (A/B)
-
-
 class _GammaMerge(Function):
     """y = (gamma * a + b) * gain, gamma a 0-d fp32 parameter (csrc/bias_act.hip: msg_gamma_merge), one launch forward and one
     pass backward; a second-order graph (R1) is built from the torch formulation."""
@@ -270,7 +266,7 @@ def gamma_merge(a, b, gamma, gain):
     same = a.shape == b.shape and a.dtype == b.dtype and a.stride() == b.stride() and a.is_cuda and gamma.is_cuda and \
         gamma.numel() == 1 and a.numel() % 8 == 0 and a.dtype in (torch.float32, torch.bfloat16) and \
         (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last))
-    if not (same and GAMMA_MERGE):
+    if not same:
         return scaled_add(gamma.to(a.dtype) * a, b, gain)
     return _GammaMerge.apply(a, b, gamma, gain)
 

@@ -1,15 +1,10 @@
 """2x2 / stride-2 max-pooling of channels-last maps on the gfx950 kernels (csrc/maxpool.hip) -- the pooling of the NonLocalBlock's
 key and value maps (reference u_net_2d_discriminator.py:366-370: F.max_pool2d(phi(x)), F.max_pool2d(g(x)))."""
-import os
-
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
-
-NATIVE_MAXPOOL = bool(int(os.environ.get("MSG_NATIVE_MAXPOOL", "1")))     # 0: F.max_pool2d (A/B; bit-identical)
-
 
 def _pitch(x):
     """Pixel pitch of a channels-last [B,C,H,W] map (or channel-slice of one) the kernel takes as it is, else None."""
@@ -57,7 +52,7 @@ class _MaxPool2x2(Function):
 def max_pool2x2(x: torch.Tensor) -> torch.Tensor:
     """F.max_pool2d(x, kernel_size=2, stride=2) for a channels-last map; shapes / layouts / types the kernel does not take
     go to the library."""
-    if NATIVE_MAXPOOL and x.is_cuda and x.ndim == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] % 2 == 0 and \
+    if x.is_cuda and x.ndim == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] % 2 == 0 and \
             x.shape[3] % 2 == 0 and x.shape[1] % (16 // x.element_size()) == 0 and x.shape[1] > 1 and _pitch(x) is not None:
         return _MaxPool2x2.apply(x)
     return F.max_pool2d(x, kernel_size=2, stride=2)

@@ -9,7 +9,6 @@ Memory layout: a channels-last input ([B,C,H,W] with NHWC strides) is handed to 
 ``major = B, minor = C``, anything else as NCHW planes ``major = B*C, minor = 1`` -- the two layouts the
 reference's native signature already distinguishes (upfirdn2d.cpp:12-19).
 """
-import os
 
 import torch
 from torch.autograd import Function
@@ -27,7 +26,7 @@ def _out_size(n, up, down, p0, p1, k):
 
 # 1: the bf16 blur takes the separable kernel (4.4 vs 2.8 TB/s); fp32 stays on the 2-D kernel, which is faster there
 # (4.1 vs 3.5 TB/s: half the taps per byte).  0: always the 2-D kernels, 2: separable for both types (tests, A/B).
-_SEPARABLE = int(os.environ.get("MSG_FIR_SEPARABLE", "1"))
+_SEPARABLE = 1      # which maps take the separable blur kernel: 1 = bf16 (fp32 stays on the 2-D kernel, faster there); tests set 0 / 2
 
 
 def _separable(fir: torch.Tensor):
@@ -216,7 +215,7 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0), out=None):
 
 
 def _blur_act_eligible(x, fir, pad):
-    """The fused blur + activation kernel takes bf16 (or fp32 when MSG_FIR_SEPARABLE=2) channels-last maps, whole 16-byte
+    """The fused blur + activation kernel takes bf16 (or fp32 when _SEPARABLE == 2) channels-last maps, whole 16-byte
     channel vectors and a separable 4x4 FIR."""
     if not (x.is_cuda and x.ndim == 4 and _is_channels_last(x) and tuple(fir.shape) == (4, 4)):
         return False

@@ -3,7 +3,6 @@
 state_dict keys.  Feature maps run channels-last (optionally bf16); the 6-channel input image and the two
 heads' outputs stay fp32."""
 import math
-import os
 import random
 from typing import Any, Dict, List, Optional, Tuple, Union
 
@@ -16,13 +15,9 @@ from .op_static import FusedLeakyReLU, gamma_merge, max_pool2x2, non_local_atten
 from .op_static import attention as _attention
 
 
-FUSE_RESIDUAL = bool(int(os.environ.get("MSG_FUSE_RESIDUAL", "1")))         # 0: separate merge pass (A/B; bit-identical)
-COMMUTE_UPSAMPLE = bool(int(os.environ.get("MSG_COMMUTE_UPSAMPLE", "1")))   # 0: reference order upsample -> 1x1 conv (A/B)
-IN_PLACE_CAT = bool(int(os.environ.get("MSG_IN_PLACE_CAT", "1")))           # 0: the decoder's concatenations copy their pieces (A/B; bit-identical)
-NATIVE_SOFTMAX = bool(int(os.environ.get("MSG_NATIVE_SOFTMAX", "1")))       # 0: ROCm library softmax in the non-local blocks (A/B)
-SHARE_PROJECTION_INPUT = bool(int(os.environ.get("MSG_SHARE_PROJECTION_INPUT", "1")))   # 0: four separate 1x1 convs in the non-local block (A/B)
-DEFER_MERGE_GAIN = bool(int(os.environ.get("MSG_DEFER_MERGE_GAIN", "1")))   # 0: the merge's backward rescales its gradient itself (A/B)
-FUSE_INPUT_FORK = bool(int(os.environ.get("MSG_FUSE_INPUT_FORK", "1")))     # 0: autograd adds a block input's two gradients (A/B)
+# Two formulations that tests compare in BOTH positions (bit-identical results; tests/test_hip_models.py); not configuration:
+IN_PLACE_CAT = True        # the decoder's concatenations are written in place (False: torch.cat-style copies)
+FUSE_INPUT_FORK = True     # a block input's two gradients meet in the 3x3 conv's data-gradient epilogue (False: autograd's add)
 
 
 def _fir2d(taps, gain=1.0):
@@ -115,9 +110,6 @@ class _MinibatchStdDevFused(torch.autograd.Function):
         return gx, None, None
 
 
-FUSED_MBSTD = bool(int(os.environ.get("MSG_FUSED_MBSTD", "1")))             # 0: torch-op statistic + concatenation (A/B)
-
-
 class MinibatchStdDev(nn.Module):
     """Appends one plane holding the mean (over c,h,w) of the per-position std over the batch; statistics in
     fp32.  The whole batch of ONE forward call is one group, as in the reference (:205-217); when the trainer runs the
@@ -133,7 +125,7 @@ class MinibatchStdDev(nn.Module):
         groups = self.groups
         assert input.shape[0] % groups == 0
         vec = 16 // input.element_size()
-        if FUSED_MBSTD and input.is_cuda and input.dtype in (torch.float32, torch.bfloat16) and input.shape[1] % vec == 0:
+        if input.is_cuda and input.dtype in (torch.float32, torch.bfloat16) and input.shape[1] % vec == 0:
             return _MinibatchStdDevFused.apply(input, groups, self.alpha)
         return _mbstd_composite(input, groups, self.alpha)
 
@@ -166,17 +158,16 @@ class ResNetBlock(nn.Module):
     def _merge(self, input: torch.Tensor, merge, out: Optional[torch.Tensor] = None):
         conv1, act1, conv2, act2 = self.main_mapping            # conv -> bias + leaky ReLU fused per pair
         res = self.residual_mapping
-        fuse_res = FUSE_RESIDUAL and isinstance(res, equalized_layer.EqualizedConv2d) and res.bias is None and \
-            input.is_cuda
+        fuse_res = isinstance(res, equalized_layer.EqualizedConv2d) and res.bias is None and input.is_cuda
         slot, x_main, x_res = None, self.mini_batch_std_dev(input), input
-        if fuse_res and FUSE_INPUT_FORK and conv_ops.FUSE_ACTIVATION and input.requires_grad and x_main is input \
+        if fuse_res and FUSE_INPUT_FORK and input.requires_grad and x_main is input \
                 and conv1.bias is None:
             # the input's two gradients (main 3x3 conv, 1x1 residual conv) meet in the 3x3 conv's data-gradient epilogue
             slot = conv_ops.GradSlot()
             x_main, x_res = conv_ops.fork_input(input, slot)
         # the merge's 1 / sqrt(2) on the main branch's gradient rides in act2's backward when the merge is the fused one
         # and the block output has a single consumer (conv_ops.GradScale)
-        owed = conv_ops.GradScale() if fuse_res and DEFER_MERGE_GAIN and conv_ops.FUSE_ACTIVATION and \
+        owed = conv_ops.GradScale() if fuse_res and \
             merge is not scaled_add_fork and conv2.bias is None and input.is_cuda else None
         output = conv2.forward_activated(conv1.forward_activated(x_main, act1, grad_slot=slot), act2, out_grad_scale=owed)
         if fuse_res and output.dtype == input.dtype:
@@ -206,7 +197,7 @@ class NonLocalBlock(nn.Module):
         projections = [self.theta, self.phi, self.g] + \
             ([self.residual_mapping] if isinstance(self.residual_mapping, equalized_layer.EqualizedConv2d) else [])
         residual = None
-        if SHARE_PROJECTION_INPUT and input.is_cuda and all(m.bias is None and m.stride == (1, 1) for m in projections):
+        if input.is_cuda and all(m.bias is None and m.stride == (1, 1) for m in projections):
             # the three (four) 1x1 projections of the block input as ONE autograd node: their input gradients meet in the
             # data-gradient launches instead of in three separate accumulation passes over the map
             outs = conv_ops.conv2d_shared_input(input, [(m.weight, m.scale) for m in projections])
@@ -224,7 +215,7 @@ class NonLocalBlock(nn.Module):
         else:
             # softmax accumulates in fp32 whatever the storage type: no fp32 copy of the [B, HW, HW/4] map is made
             scores = torch.bmm(query, key)
-            beta = softmax_rows(scores) if input.is_cuda and NATIVE_SOFTMAX else torch.softmax(scores, dim=-1)
+            beta = softmax_rows(scores) if input.is_cuda else torch.softmax(scores, dim=-1)
             attended = torch.bmm(beta, value)
         attended = attended.view(bsz, height, width, -1).permute(0, 3, 1, 2)
         output = self.o(conv_ops.to_compute_layout(attended))
@@ -307,7 +298,7 @@ class Discriminator(nn.Module):
     def _skip_destination(self, index: int, x: torch.Tensor, block: nn.Module):
         """(buffer, [upsampled slice, skip slice]) of the decoder level that consumes encoder block `index`'s output, or
         None when that level does not take the in-place form."""
-        if not (IN_PLACE_CAT and COMMUTE_UPSAMPLE and x.is_cuda):
+        if not (IN_PLACE_CAT and x.is_cuda):
             return None
         up = self.transposed_convolutions[len(self.transposed_convolutions) - 1 - index]
         fir, mix = up[0], up[1]
@@ -350,7 +341,7 @@ class Discriminator(nn.Module):
             # mixing the channels BEFORE upsampling runs the conv on a quarter of the pixels and the FIR on the (fewer)
             # output channels.  Same function as the reference's order (u_net_2d_discriminator.py:120-127) up to rounding.
             fir, mix = up[0], up[1]
-            commute = COMMUTE_UPSAMPLE and isinstance(mix, equalized_layer.EqualizedConv2d) and mix.bias is None and \
+            commute = isinstance(mix, equalized_layer.EqualizedConv2d) and mix.bias is None and \
                 mix.kernel_size == (1, 1) and mix.stride == (1, 1) and mix.padding == (0, 0)
             if commute and IN_PLACE_CAT and x.is_cuda and isinstance(fir, Upsample):
                 low = mix(x)

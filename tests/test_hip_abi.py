@@ -182,10 +182,4 @@ def test_round3_entries(lib):
     w = _buf(64 * 64, torch.bfloat16)
     assert lib.msg_conv2d_fprop_act_mask(xb.data_ptr(), w.data_ptr(), xb.data_ptr(), BF16, 1, 8, 8, 64, 64, 8, 8, 64, 64, 1, 1, 1, 0,
                                          0, None, None, None, 1, 0.2, 1.0, m.data_ptr(), s) == EUNSUPPORTED
-    # small-map scalings: both outputs missing / reduction without the second operand
-    v = _buf(64)
-    assert lib.msg_scale_reduce_channels(x.data_ptr(), None, v.data_ptr(), y.data_ptr(), None, F32, 1, 16, 8, s) == OK
-    assert lib.msg_scale_reduce_channels(x.data_ptr(), None, v.data_ptr(), None, None, F32, 1, 16, 8, s) == EINVAL
-    assert lib.msg_scale_reduce_channels(x.data_ptr(), None, v.data_ptr(), None, v.data_ptr(), F32, 1, 16, 8, s) == EINVAL
-    assert lib.msg_scale_bias_act(x.data_ptr(), None, None, None, None, y.data_ptr(), F32, 1, 16, 6, 1, 0, 0.2, 1.0, s) == EUNSUPPORTED
     torch.cuda.synchronize()

@@ -733,70 +733,6 @@ def test_gather_taps_kernels(shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(4, 64, 128, 8, 3, True, True), (16, 512, 512, 4, 3, True, True), (3, 128, 64, 16, 3, False, True),
-                                  (2, 64, 64, 32, 1, True, False), (5, 72, 88, 12, 3, True, True)])
-def test_small_map_modulated_conv_matches_per_sample_form(case, dtype, monkeypatch):
-    """The activation-scaling form of the modulated conv on small maps (conv_ops._ModulatedConvSmall, csrc/modsmall.hip)
-    against (a) the fp64 definition with per-sample weights (multi_stylegan_generator.py:384-411) and (b) the per-sample-weight
-    kernels it replaces there: output, gradients wrt input, weight, style, activation bias and noise weight; bit-identical
-    over repeated runs; second-order requests (composite fallback) against the per-sample form's."""
-    from multi_stylegan_amd import conv_ops
-    b, i, o, hw, k, demod, act = case
-    tol = 2e-4 if dtype == torch.float32 else (6e-2 if act else 2e-2)     # (bf16 + activation: slope flips, see below)
-    torch.manual_seed(b * 7 + hw)
-    x0 = torch.randn(b, i, hw, hw, device=DEV)
-    w0 = torch.randn(1, o, i, k, k, device=DEV)
-    s0 = 1 + 0.3 * torch.randn(b, i, device=DEV)
-    bias0 = 0.1 * torch.randn(o, device=DEV)
-    noise = torch.randn(b, 1, hw, hw, device=DEV)
-    gy0 = torch.randn(b, o, hw, hw, device=DEV)
-
-    def run(pixels, second=False):
-        monkeypatch.setattr(conv_ops, "_SMALL_MAP_PIXELS", pixels)
-        x = conv_ops.to_compute_layout(x0, dtype).requires_grad_(True)
-        w, st, bias = w0.clone().requires_grad_(True), s0.clone().requires_grad_(True), bias0.clone().requires_grad_(True)
-        nw = torch.full((1,), 0.4, device=DEV, requires_grad=True)
-        if act:
-            y = conv_ops.modulated_conv2d_bias_act(x, w, st, demod, bias, noise, nw, scale=math.sqrt(2))
-            leaves = (x, w, st, bias, nw)
-        else:
-            y = conv_ops.modulated_conv2d(x, w, st, demod, False)
-            leaves = (x, w, st)
-        gy = conv_ops.to_compute_layout(gy0, dtype)
-        if second:
-            gx, = torch.autograd.grad(y, x, gy, create_graph=True)
-            return [torch.autograd.grad(gx.float().square().sum(), st)[0]]
-        return [y.detach()] + list(torch.autograd.grad(y, leaves, gy))
-
-    small, small2, per = run(4096), run(4096), run(0)
-    for u, v in zip(small, small2):
-        assert torch.equal(u, v)
-    # fp64 definition on the operands the kernels saw
-    xd = conv_ops.to_compute_layout(x0, dtype).double().requires_grad_(True)
-    wd, sd, bd = w0.double().requires_grad_(True), s0.double().requires_grad_(True), bias0.double().requires_grad_(True)
-    nd = torch.full((1,), 0.4, device=DEV, dtype=torch.float64, requires_grad=True)
-    scale = math.sqrt(2) / math.sqrt(i * k * k)
-    wb = scale * wd * sd.view(b, 1, i, 1, 1)
-    if demod:
-        wb = wb * torch.rsqrt(wb.square().sum(dim=(2, 3, 4), keepdim=True) + 1e-8)
-    yd = torch.cat([F.conv2d(xd[j:j + 1], wb[j], padding=k // 2) for j in range(b)])
-    if act:
-        yd = F.leaky_relu(yd + nd * noise.double() + bd.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
-    leaves = (xd, wd, sd, bd, nd) if act else (xd, wd, sd)
-    want = [yd.detach()] + list(torch.autograd.grad(yd, leaves, conv_ops.to_compute_layout(gy0, dtype).double()))
-    # (bf16: a pre-activation that rounds across zero flips its slope, a handful of elements differ by a factor 5 whatever the
-    #  form -- the norm-wise error is the meaningful figure there)
-    err = rel_err if dtype == torch.float32 else (lambda u, v: float((u - v).norm() / v.norm()))
-    for name, got, ref, other in zip(("y", "gx", "gw", "gs", "gb", "gnw"), small, want, per):
-        if name == "gnw" and dtype != torch.float32:
-            continue          # (one scalar = a sum of ~1e5 terms of both signs: bf16 rounding of the terms swamps it in any form)
-        assert err(got.double(), ref) < tol, (name, err(got.double(), ref))
-        assert err(other.double(), ref) < tol, ("per-sample " + name, err(other.double(), ref))
-    a2, b2 = run(4096, second=True)[0], run(0, second=True)[0]
-    assert err(a2.double(), b2.double()) < (1e-3 if dtype == torch.float32 else 6e-2)
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(32, 128, 127, 127), (3, 24, 5, 7), (2, 768, 15, 15)])
 def test_channel_sums(shape, dtype):
     """msg_channel_sums -- the bias gradient of a conv with no activation behind it -- against the library reduction in fp64,

@@ -489,3 +489,35 @@ def test_ada_controller_on_cpu_matches_oracle():
         ref.observe(a, b, is_real=False)
         assert abs(ada.p - ref.p) < 1e-6, i
     assert len(ada.r_history) == len(ref.r_history) == 15
+
+
+def test_metric_statistics_match_the_reference_values(golden):
+    """multi_stylegan_amd.validation_metrics: the Frechet distance (streamed moments + symmetric eigendecomposition) against
+    values the reference's own FID._calc_fid / FVD._calc_fvd produced (tests/golden/metrics.npz), whole and in ragged
+    batches with a sample limit; the inception score against the oracle; the range normalisations against the reference's."""
+    import numpy as np
+    from multi_stylegan_amd import misc, validation_metrics as vm
+    from oracle import metrics as omet
+    z = golden("metrics")
+    for case in ("wide", "few_samples", "shifted"):
+        real, fake, want = z[f"frechet.{case}.real"], z[f"frechet.{case}.fake"], float(z[f"frechet.{case}.value"])
+        got = vm.frechet_distance(real, fake)
+        assert abs(got - want) <= 1e-6 * abs(want), (case, got, want)
+        # streamed: ragged batches, float32 features, a limit that cuts the last batch (the reference truncates its lists)
+        n = real.shape[0] - 5
+        mr, mf = vm.FeatureMoments(limit=n), vm.FeatureMoments(limit=n)
+        for lo in range(0, real.shape[0], 37):
+            mr.update(real[lo:lo + 37].float()); mf.update(fake[lo:lo + 37].float())
+        assert mr.n == mf.n == n and mr.full
+        want_cut = omet.frechet_distance(real[:n].float().double().numpy(), fake[:n].float().double().numpy())
+        assert abs(vm.frechet_distance_from_moments(mr, mf) - want_cut) <= 1e-6 * abs(want_cut)
+    rng = np.random.default_rng(3)
+    p = rng.dirichlet(np.ones(11), size=64)
+    assert abs(vm.inception_score(torch.from_numpy(p)) - omet.inception_score(p)) < 1e-10
+    assert torch.equal(misc.normalize_0_1_batch(z["normalize.x"]), z["normalize.y01"])
+    assert torch.equal(misc.normalize_m1_1_batch(z["normalize.x"]), z["normalize.ym11"])
+    frames = vm.select_frames(z["normalize.x"], 1, generator=torch.Generator().manual_seed(0))
+    t = int(torch.randint(0, 2, (1,), generator=torch.Generator().manual_seed(0)))
+    assert frames.shape == (3, 3, 1, 5, 4) and torch.equal(frames, omet.select_frames(z["normalize.x"], 1, t))
+    with pytest.raises(ValueError, match="feature network"):
+        vm.FID(None)

@@ -308,3 +308,33 @@ def test_top_k_schedule():
     vals, idx = tk(torch.tensor([[0.3], [-1.0], [2.0], [0.1], [0.2]]))
     assert idx.tolist() == [2, 0] and vals.tolist() == [2.0, 0.30000001192092896]
     assert ot.TopK(0, 1)(torch.tensor([[1.0]]))[1].tolist() == [0]          # k never drops below 1
+
+
+@pytest.mark.parametrize("case", ["wide", "few_samples", "shifted"])
+def test_frechet_distance(golden, case):
+    """oracle.metrics.frechet_distance against values computed by the reference's own FID._calc_fid / FVD._calc_fvd
+    (validation_metrics.py:192-220, 401-429) on stored feature matrices (scipy's sqrtm is threaded: 1e-8 run to run)."""
+    from oracle import metrics as omet
+    z = golden("metrics")
+    got = omet.frechet_distance(z[f"frechet.{case}.real"].numpy(), z[f"frechet.{case}.fake"].numpy())
+    want = float(z[f"frechet.{case}.value"])
+    assert abs(got - want) <= 1e-6 * abs(want), (got, want)
+
+
+def test_inception_score_closed_forms():
+    """The inception-score arithmetic (validation_metrics.py:126-140) has no callable in the reference besides IS.__call__
+    (which needs the Inception weights): checked against what the formula must give -- identical predictions: 1; confident,
+    balanced predictions over K classes: K; in between, the numpy statement of exp(E KL)."""
+    import numpy as np
+    from oracle import metrics as omet
+    k, n = 7, 70
+    assert abs(omet.inception_score(np.full((n, k), 1.0 / k)) - 1.0) < 1e-12
+    eps = 1e-9
+    onehot = np.full((n, k), eps / (k - 1))
+    onehot[np.arange(n), np.arange(n) % k] = 1.0 - eps
+    assert abs(omet.inception_score(onehot) - k) < 1e-5
+    rng = np.random.default_rng(0)
+    p = rng.dirichlet(np.ones(k), size=n)
+    p_y = p.mean(0)
+    want = np.exp(np.mean([(row * (np.log(row) - np.log(p_y))).sum() for row in p]))
+    assert abs(omet.inception_score(p) - want) < 1e-12 * want

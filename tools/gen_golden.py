@@ -557,6 +557,31 @@ def gen_train_step(ref, om, ot, store):
             store[pre + "D." + n] = npy(dict(dis.named_parameters())[n])
 
 
+def gen_metrics(ref, store):
+    """The statistics of multi_stylegan/validation_metrics.py that are callable without the pretrained networks: the static
+    methods FID._calc_fid (:192-220) and FVD._calc_fvd (:401-429) on stored feature matrices, and misc.normalize_0_1_batch /
+    normalize_m1_1_batch (misc.py:216-235).  The module imports torchvision and kornia at its top (for the networks and the
+    resize): empty modules stand in, nothing of them is called here.  The inception-score arithmetic exists only inline in
+    IS.__call__ (:126-140), which needs the Inception weights: not capturable, restated in oracle/metrics.py (unpinned)."""
+    from oracle import metrics as omet
+    sys.modules.setdefault("kornia", types.ModuleType("kornia"))
+    vm = importlib.import_module("multi_stylegan.validation_metrics")
+    rng = np.random.default_rng(7)
+    cases = {"wide": (400, 24, 0.3), "few_samples": (20, 24, 1.0), "shifted": (300, 8, 2.0)}   # few_samples: rank-deficient covariances
+    for name, (n, d, shift) in cases.items():
+        mix_r, mix_f = rng.normal(size=(d, d)), rng.normal(size=(d, d))
+        real = rng.normal(size=(n, d)) @ mix_r + rng.normal(size=d)
+        fake = rng.normal(size=(n + 7, d)) @ mix_f + shift * rng.normal(size=d)
+        fid, fvd = vm.FID._calc_fid(real, fake), vm.FVD._calc_fvd(real, fake)
+        assert fid == fvd
+        close(omet.frechet_distance(real, fake), fid, tol=1e-6, what=f"frechet distance {name}")   # (sqrtm: threaded Schur form, 1e-8 run to run)
+        store[f"frechet.{name}.real"], store[f"frechet.{name}.fake"] = real, fake
+        store[f"frechet.{name}.value"] = np.float64(fid)
+    x = torch.randn(3, 3, 2, 5, 4, generator=torch.Generator().manual_seed(11)) * 3 + 1
+    store["normalize.x"] = npy(x)
+    store["normalize.y01"], store["normalize.ym11"] = npy(ref["misc"].normalize_0_1_batch(x)), npy(ref["misc"].normalize_m1_1_batch(x))
+
+
 def gen_manifest(ref, om):
     G, D, C = ref["multi_stylegan_generator"], ref["u_net_2d_discriminator"], ref["config"]
     gen = G.Generator(C.multi_style_gan_generator_config)
@@ -586,7 +611,8 @@ def main():
                       ("fused_act", lambda s: gen_fused_act(ref, oracle_ops, s)),
                       ("modconv", lambda s: gen_modconv(ref, om, s)),
                       ("layers", lambda s: gen_layers(ref, om, oracle_ops, s)),
-                      ("train_step", lambda s: gen_train_step(ref, om, ot, s))):
+                      ("train_step", lambda s: gen_train_step(ref, om, ot, s)),
+                      ("metrics", lambda s: gen_metrics(ref, s))):
         store = {}
         fn(store)
         files[fname] = store

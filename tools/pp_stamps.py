@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: phase timing of the ping-pong conv kernel from in-kernel s_memtime stamps.
-Build the stamped library first:  MSG_EXTRA_HIPCC_FLAGS=-DMSG_PP_STAMPS python -m multi_stylegan_amd.build --force
+Build the stamped library first:  python -m multi_stylegan_amd.build --variant stamps --flags=-DMSG_PP_STAMPS
 (never ship or benchmark that build), then run this on the GPU box."""
 import ctypes, math, os, sys
 import numpy as np

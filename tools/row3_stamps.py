@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: where a K-step of conv_fprop_row3_kernel<4,4> spends its cycles, from in-kernel s_memtime stamps.
-Build the stamped library first:  MSG_EXTRA_HIPCC_FLAGS=-DMSG_ROW3_STAMPS python -m multi_stylegan_amd.build --force
+Build the stamped library first:  python -m multi_stylegan_amd.build --variant stamps --flags=-DMSG_ROW3_STAMPS
 (never ship or benchmark that build), then run this on the GPU box."""
 import ctypes, math, os, sys
 import numpy as np

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where a K-step of conv_wgrad_row3s_kernel spends its cycles, from in-kernel s_memtime stamps.
 Build the stamped library beside the real one:
-    MSG_EXTRA_HIPCC_FLAGS=-DMSG_WGRAD3_STAMPS python -m multi_stylegan_amd.build --force
+    python -m multi_stylegan_amd.build --variant stamps --flags=-DMSG_WGRAD3_STAMPS
     cp multi_stylegan_amd/libmsg_hip.so multi_stylegan_amd/libmsg_hip_stamps.so; python -m multi_stylegan_amd.build --force
 then run  MSG_LIB_VARIANT=stamps python tools/wgrad3_stamps.py  on the GPU box (never ship or benchmark that build)."""
 import ctypes, math, os, sys

@@ -157,8 +157,8 @@ def cpu_baseline(iters: int, same_resolution: int = 0):
 
 def fp32_leg(args, dev, batch: int = 4, steps: int = 3):
     """The same training iteration on the fp32-storage path -- exact-fp32 MFMA contractions, the path the 1e-3 parity
-    gate of tests/test_hip_models.py is held on -- at batch 4: one regularised warm-up iteration, `steps` timed plain
-    iterations and one timed regularised iteration, amortised 15:1 like `value`."""
+    gate of tests/test_hip_models.py is held on -- at the configuration's own batch: one regularised warm-up iteration, `steps`
+    timed plain iterations and one timed regularised iteration, amortised 15:1 like `value`."""
     import multi_stylegan_amd as m
     from multi_stylegan_amd.config import generator_config_for_resolution
     torch.manual_seed(1234)
@@ -223,6 +223,18 @@ def elided_leg(args, dev, dtype, steps: int = 6):
             "regularised_ms": round(reg_ms, 2), "ms_per_step": round(step_ms, 2),
             "sample": f"{steps} plain + 1 regularised iteration with --elide-dead-work (dead second-stream convolutions and the "
                       f"discriminator's weight gradients in the generator step skipped; same trajectory), amortised {lazy - 1}:1"}
+
+
+def multi_rank_fields(world, backend, rehearsal, batch, steps, per_rank_seconds, overlap_off_ms):
+    """What the JSON line says about the ranks: how many exchanged gradients and over which backend ("nccl" IS RCCL on ROCm;
+    "gloo" only in the one-GPU rehearsal), every rank's own rate over the timed region (the job's rate is the slowest
+    rank's: `value` uses the MAX of these times), and what overlapping the bucket exchange with backward buys (ms per step
+    with the exchange issued from the gradient hooks vs after backward; None on one rank)."""
+    elapsed = max(per_rank_seconds)
+    return {"rccl_ranks": world, "rehearsal_shared_gpu": bool(rehearsal), "backend": backend if world > 1 else None,
+            "per_rank_img_per_s": [round(batch * steps / t, 2) for t in per_rank_seconds],
+            "overlap": {"on_ms_per_step": round(1e3 * elapsed / steps, 2), "off_ms_per_step": round(overlap_off_ms, 2)}
+            if overlap_off_ms is not None else None}
 
 
 def self_launch(n: int) -> int:
@@ -448,12 +460,8 @@ def main():
                        "global_batch": world * args.batch,
                        "parallelism": f"dp{world}", "dead_work_elided": bool(args.elide_dead_work),
                        "ada": bool(args.ada)},
-            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
-            "rehearsal_shared_gpu": bool(args.rehearse_on_one_gpu),
-            "backend": torch.distributed.get_backend() if world > 1 else None,
-            "per_rank_img_per_s": [round(args.batch * args.steps / t, 2) for t in per_rank],
-            "overlap": {"on_ms_per_step": round(1e3 * elapsed / args.steps, 2),
-                        "off_ms_per_step": round(overlap_off_ms, 2)} if overlap_off_ms is not None else None,
+            **multi_rank_fields(world, torch.distributed.get_backend() if world > 1 else None, args.rehearse_on_one_gpu,
+                                args.batch, args.steps, per_rank, overlap_off_ms),
             "timed_region": {"iterations": [first_iteration, first_iteration + args.steps - 1],
                              "regularised_iterations": len(regd), "plain_ms": round(plain_ms, 2) if plain else None,
                              "regularised_ms": round(reg_ms, 2) if regd else None, "raw_ms_per_step": round(raw_ms, 2),
@@ -472,8 +480,8 @@ def main():
                 note("dead-work-elided leg ...")
                 out["value_dead_work_elided"] = elided_leg(args, dev, dtype)
                 torch.cuda.empty_cache()
-            note("fp32-storage leg (batch 4) ...")
-            out["value_fp32_path"] = fp32_leg(args, dev)
+            note(f"fp32-storage leg (batch {args.batch}) ...")
+            out["value_fp32_path"] = fp32_leg(args, dev, batch=args.batch)
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
             note("CPU baseline (oracle, 64x64, B=4" + ("" if args.no_cpu_same_resolution else
                                                        f"; one iteration at {args.resolution}^2, B=2") + ") ...")

@@ -259,6 +259,18 @@ int msg_scaled_add(const void* a, const void* b, void* y, int dtype, long long n
  * (multi_stylegan/u_net_2d_discriminator.py:381; gamma is a learnt parameter) -- and its backward in one pass:
  *   ga = gamma * gain * gy,  gb = gain * gy,  g_gamma[0] = gain * sum(gy * a)   (block partials in ws, added in a fixed order by a
  * second launch: deterministic).  Dense maps of n elements in one layout, MSG_F32 / MSG_BF16, n a multiple of the 16-byte vector. */
+/* The generator's RGB skip path, one launch per level (multi_stylegan_generator.py:513-523: OutputBlock.forward):
+ *   out[b,c,y,x] = float(conv[b,y,x,c]) + bias[c] + upfirdn2d(skip, fir, up = 2, pad = (2, 1))[b,c,y,x]
+ * conv [B][H][W][ld] channels-last (MSG_F32 / MSG_BF16, pixel pitch ld >= C elements: the thin 1x1 conv's output), bias fp32
+ * [C] or NULL, skip fp32 planes [B][C][H/2][W/2] or NULL (first level), fir DEVICE pointer to the 4 x 4 taps (required with
+ * skip), out fp32 planes [B][C][H][W].  C <= 8, W % 4 == 0, H even; anything else MSG_EUNSUPPORTED.
+ * msg_rgb_skip_merge_backward: g fp32 planes [B][C][H][W] -> g_conv [B][H][W][ld] (cast, padding channels zeroed; may be
+ * NULL) and g_skip fp32 [B][C][H/2][W/2] (the transposed FIR as a gather: no atomics; may be NULL).  The op is linear: its
+ * second-order pass is msg_rgb_skip_merge on the cotangents. */
+int msg_rgb_skip_merge(const void* conv, int dtype, int ld, const float* bias, const float* skip, const float* fir,
+                       float* out, int B, int C, int H, int W, void* stream);
+int msg_rgb_skip_merge_backward(const float* g, void* g_conv, int dtype, int ld, float* g_skip, const float* fir,
+                                int B, int C, int H, int W, void* stream);
 int msg_gamma_merge(const void* a, const void* b, const float* gamma, void* y, int dtype, long long n, float gain, void* stream);
 long long msg_gamma_merge_backward_workspace(void);
 int msg_gamma_merge_backward(const void* gy, const void* a, const float* gamma, void* ga, void* gb, float* g_gamma, int dtype,

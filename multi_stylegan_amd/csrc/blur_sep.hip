@@ -29,30 +29,37 @@ struct BlurParams {
     ActEpilogue act;                // optional fused (noise +) bias + leaky ReLU behind the blur (see msg_common.h)
 };
 
-// horizontal pass of input row iy -> two row sums (columns ox, ox+1), fp32
+// horizontal pass of input row iy -> two row sums (columns ox, ox+1), fp32.  The five vectors come through a buffer
+// descriptor over the sample's map: a column outside the image carries an out-of-range offset and the hardware returns
+// zeros -- no per-vector select and no zero fill in front of a conditional load (ISA of the previous form: 32 v_cndmask and
+// ~20 v_mov per row, a seventh of the kernel's vector instructions, in a kernel that is bound by them).
+constexpr int BLUR_OOB = (int)0x80000000;
 template <typename T>
-__device__ __forceinline__ void blur_hrow(const uint4* xin, int iy, int IH, long long rstride, int o0, int o1, int o2,
-                                          int o3, int o4, bool k0, bool k1, bool k2, bool k3, bool k4,
-                                          f32x4 wx, float (&h)[2][Vec16<T>::N]) {
+__device__ __forceinline__ void blur_hrow(__amdgpu_buffer_rsrc_t rs, int iy, int IH, int row_bytes, int o0, int o1, int o2,
+                                          int o3, int o4, f32x4 wx, float (&h)[2][Vec16<T>::N]) {
     constexpr int VEC = Vec16<T>::N;
-    if ((unsigned)iy < (unsigned)IH) {                               // (workgroup-uniform)
-        const uint4* row = xin + (long long)iy * rstride;
-        Vec16<T> v0, v1, v2, v3, v4;
-        v0.zero(); v1.zero(); v2.zero(); v3.zero(); v4.zero();
-        if (k0) v0.raw = row[o0];
-        if (k1) v1.raw = row[o1];
-        if (k2) v2.raw = row[o2];
-        if (k3) v3.raw = row[o3];
-        if (k4) v4.raw = row[o4];
+    // a row outside the image (top / bottom padding; workgroup-uniform) takes out-of-range offsets as well: the row sums come
+    // out as zeros without a second code path (an if / else here left part of the caller's window arrays in scratch memory)
+    const bool row_ok = (unsigned)iy < (unsigned)IH;
+    const int so = row_ok ? iy * row_bytes : 0;
+    Vec16<T> v0, v1, v2, v3, v4;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? o0 : BLUR_OOB, so, 0),
+          r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? o1 : BLUR_OOB, so, 0),
+          r2 = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? o2 : BLUR_OOB, so, 0),
+          r3 = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? o3 : BLUR_OOB, so, 0),
+          r4 = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? o4 : BLUR_OOB, so, 0);
+#else
+    u32x4 r0{}, r1{}, r2{}, r3{}, r4{};
+#endif
+    v0.raw = make_uint4(r0[0], r0[1], r0[2], r0[3]); v1.raw = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+    v2.raw = make_uint4(r2[0], r2[1], r2[2], r2[3]); v3.raw = make_uint4(r3[0], r3[1], r3[2], r3[3]);
+    v4.raw = make_uint4(r4[0], r4[1], r4[2], r4[3]);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float a0 = v0.get(e), a1 = v1.get(e), a2 = v2.get(e), a3 = v3.get(e), a4 = v4.get(e);
-            h[0][e] = fmaf(wx[3], a3, fmaf(wx[2], a2, fmaf(wx[1], a1, wx[0] * a0)));
-            h[1][e] = fmaf(wx[3], a4, fmaf(wx[2], a3, fmaf(wx[1], a2, wx[0] * a1)));
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) h[0][e] = h[1][e] = 0.f;
+    for (int e = 0; e < VEC; ++e) {
+        const float a0 = v0.get(e), a1 = v1.get(e), a2 = v2.get(e), a3 = v3.get(e), a4 = v4.get(e);
+        h[0][e] = fmaf(wx[3], a3, fmaf(wx[2], a2, fmaf(wx[1], a1, wx[0] * a0)));
+        h[1][e] = fmaf(wx[3], a4, fmaf(wx[2], a3, fmaf(wx[1], a2, wx[0] * a1)));
     }
 }
 
@@ -75,90 +82,98 @@ __global__ __launch_bounds__(256, OCC) void blur_sep_kernel(const T* __restrict_
     f32x4 wx, wy;
     wx[0] = fx[3]; wx[1] = fx[2]; wx[2] = fx[1]; wx[3] = fx[0];
     wy[0] = fy[3]; wy[1] = fy[2]; wy[2] = fy[1]; wy[3] = fy[0];
-    const uint4* xin = reinterpret_cast<const uint4*>(x) + (long long)b * p.IH * p.IW * p.CV + cv;
+    // one descriptor per sample (the host checks that a sample's map is below 2 GiB); per-lane byte offsets of the window's
+    // five columns (out of range for columns outside the image), the row as the scalar offset
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const uint4*>(x) + (long long)b * p.IH * p.IW * p.CV), 0, 0x7ffffff0, 0x00020000);
     uint4* yout = reinterpret_cast<uint4*>(y) + (long long)b * p.OH * p.OW * p.CV + cv;
-    // the five input columns of this lane's window: validity + vector offset (scalars, not arrays: no scratch)
     const int c0 = ox - p.px0;
-    const bool k0 = (unsigned)(c0 + 0) < (unsigned)p.IW, k1 = (unsigned)(c0 + 1) < (unsigned)p.IW,
-               k2 = (unsigned)(c0 + 2) < (unsigned)p.IW, k3 = (unsigned)(c0 + 3) < (unsigned)p.IW,
-               k4 = (unsigned)(c0 + 4) < (unsigned)p.IW;
-    const int o0 = (c0 + 0) * p.CV, o1 = (c0 + 1) * p.CV, o2 = (c0 + 2) * p.CV, o3 = (c0 + 3) * p.CV, o4 = (c0 + 4) * p.CV;
-    const long long rstride = (long long)p.IW * p.CV;
+    const int row_bytes = p.IW * p.CV * 16;
+    const int o0 = (unsigned)(c0 + 0) < (unsigned)p.IW ? ((c0 + 0) * p.CV + cv) * 16 : BLUR_OOB,
+              o1 = (unsigned)(c0 + 1) < (unsigned)p.IW ? ((c0 + 1) * p.CV + cv) * 16 : BLUR_OOB,
+              o2 = (unsigned)(c0 + 2) < (unsigned)p.IW ? ((c0 + 2) * p.CV + cv) * 16 : BLUR_OOB,
+              o3 = (unsigned)(c0 + 3) < (unsigned)p.IW ? ((c0 + 3) * p.CV + cv) * 16 : BLUR_OOB,
+              o4 = (unsigned)(c0 + 4) < (unsigned)p.IW ? ((c0 + 4) * p.CV + cv) * 16 : BLUR_OOB;
     const bool c1ok = ox + 1 < p.OW;
 
-    float a_bias[VEC], a_nw = 0.f;                                   // fused activation: this lane's bias vector
+    // fused activation: this lane's bias vector, as ext-vector registers (a float array that is conditionally filled ended up
+    // in scratch memory: 48 bytes per lane in the bf16 variant)
+    f32x4 a_bias_lo = {0.f, 0.f, 0.f, 0.f}, a_bias_hi = {0.f, 0.f, 0.f, 0.f};
+    float a_nw = 0.f;
     if constexpr (ACT) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) a_bias[e] = p.act.bias ? p.act.bias[cv * VEC + e] : 0.f;
+        if (p.act.bias) {
+            a_bias_lo = *reinterpret_cast<const f32x4*>(p.act.bias + cv * VEC);
+            if constexpr (VEC == 8) a_bias_hi = *reinterpret_cast<const f32x4*>(p.act.bias + cv * VEC + 4);
+        }
         a_nw = p.act.noise ? p.act.noise_w[0] : 0.f;
     }
     // noise values of the two columns, fetched ONE ROW AHEAD of their use (a dependent load in front of every row's
     // activation would stall the lane once per row)
     const float* nz_base = (ACT && p.act.noise) ? p.act.noise + (long long)(p.act.noise_batch == 1 ? 0 : b) * p.OH * p.OW + ox : nullptr;
-    float nz_cur[2] = {0.f, 0.f};
+    float nz_cur0 = 0.f, nz_cur1 = 0.f;
     if (nz_base && oy0 < p.OH) {
-        nz_cur[0] = nz_base[(long long)oy0 * p.OW];
-        nz_cur[1] = (ox + 1 < p.OW) ? nz_base[(long long)oy0 * p.OW + 1] : 0.f;
+        nz_cur0 = nz_base[(long long)oy0 * p.OW];
+        nz_cur1 = (ox + 1 < p.OW) ? nz_base[(long long)oy0 * p.OW + 1] : 0.f;
     }
     float w0[2][VEC], w1[2][VEC], w2[2][VEC];                        // the three previous row sums
-    blur_hrow<T>(xin, oy0 - p.py0 + 0, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w0);
-    blur_hrow<T>(xin, oy0 - p.py0 + 1, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w1);
-    blur_hrow<T>(xin, oy0 - p.py0 + 2, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w2);
-#pragma unroll
+    blur_hrow<T>(rs, oy0 - p.py0 + 0, p.IH, row_bytes, o0, o1, o2, o3, o4, wx, w0);
+    blur_hrow<T>(rs, oy0 - p.py0 + 1, p.IH, row_bytes, o0, o1, o2, o3, o4, wx, w1);
+    blur_hrow<T>(rs, oy0 - p.py0 + 2, p.IH, row_bytes, o0, o1, o2, o3, o4, wx, w2);
+#pragma unroll 4
     for (int r = 0; r < TH; ++r) {
         const int oy = oy0 + r;
         if (oy >= p.OH) break;                                       // (uniform)
-        float nz_next[2] = {0.f, 0.f};
+        float nz_next0 = 0.f, nz_next1 = 0.f;
         if (nz_base && oy + 1 < p.OH) {
-            nz_next[0] = nz_base[(long long)(oy + 1) * p.OW];
-            nz_next[1] = c1ok ? nz_base[(long long)(oy + 1) * p.OW + 1] : 0.f;
+            nz_next0 = nz_base[(long long)(oy + 1) * p.OW];
+            nz_next1 = c1ok ? nz_base[(long long)(oy + 1) * p.OW + 1] : 0.f;
         }
         float w3[2][VEC];
-        blur_hrow<T>(xin, oy - p.py0 + 3, p.IH, rstride, o0, o1, o2, o3, o4, k0, k1, k2, k3, k4, wx, w3);
+        blur_hrow<T>(rs, oy - p.py0 + 3, p.IH, row_bytes, o0, o1, o2, o3, o4, wx, w3);
         uint4* dst = yout + ((long long)oy * p.OW + ox) * p.CV;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c == 1 && !c1ok) break;
-            V o;
             float f[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 f[e] = fmaf(wy[3], w3[c][e], fmaf(wy[2], w2[c][e], fmaf(wy[1], w1[c][e], wy[0] * w0[c][e])));
             if constexpr (ACT) {
                 // activation of the StyledConv2d that owns this blur (see BLUR_ACT_ROUND above)
-                const float nv = a_nw * nz_cur[c];
+                const float nv = a_nw * (c == 0 ? nz_cur0 : nz_cur1);
                 const float pos = p.act.scale, neg = p.act.alpha * p.act.scale;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float r;
                     if constexpr (VEC == 4 || !BLUR_ACT_ROUND) r = f[e];
                     else r = bf2f(f2bf(f[e]));
-                    const float val = r + (nv + a_bias[e]);
+                    const float val = r + (nv + (e < 4 ? a_bias_lo[e & 3] : a_bias_hi[e & 3]));
                     f[e] = BLUR_ACT_ROUND ? ((val > 0.f) ? val : val * p.act.alpha) * p.act.scale : val * ((val > 0.f) ? pos : neg);
                 }
             }
+            // (packed into four scalars, not through Vec16's element pointer: indexing `(&raw.x)[e]` in this loop made the
+            //  compiler build the vector in SCRATCH memory and read it back -- 36 bytes of private segment per lane and
+            //  six scratch round trips per output vector in every variant of the kernel)
+            u32x4 pk;
             if constexpr (VEC == 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+                for (int e = 0; e < 4; ++e) pk[e] = __float_as_uint(f[e]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+                for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f2bf(f[2 * e]) | ((uint32_t)f2bf(f[2 * e + 1]) << 16);
             }
-            dst[c * p.CV] = o.raw;
+            *reinterpret_cast<u32x4*>(dst + c * p.CV) = pk;
             if constexpr (ACT && VEC == 8) {
-                if (p.act.mask) {
-                    u32x4 pk;
-                    pk[0] = o.raw.x; pk[1] = o.raw.y; pk[2] = o.raw.z; pk[3] = o.raw.w;
+                if (p.act.mask)
                     p.act.mask[(((long long)b * p.OH + oy) * p.OW + ox + c) * p.CV + cv] = (unsigned char)act_sign_byte(pk);
-                }
             }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { w0[c][e] = w1[c][e]; w1[c][e] = w2[c][e]; w2[c][e] = w3[c][e]; }
-        nz_cur[0] = nz_next[0];
-        nz_cur[1] = nz_next[1];
+        nz_cur0 = nz_next0;
+        nz_cur1 = nz_next1;
     }
 }
 
@@ -206,6 +221,7 @@ static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x
     if (kh != 4 || kw != 4 || minor % vec || (((uintptr_t)x | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
     const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
     if (oh <= 0 || ow <= 0) return MSG_EINVAL;
+    if ((long long)in_h * in_w * minor * (dtype == MSG_BF16 ? 2 : 4) >= 0x7ffffff0ll) return MSG_EUNSUPPORTED;   // 31-bit buffer offsets per sample
     static const int xcd = msg_tunable("MSG_BLUR_XCD", 1);
     BlurParams p{major, in_h, in_w, oh, ow, minor / vec, pad_x0, pad_y0, 0, act};
     static const int variant = msg_tunable("MSG_BLUR_VARIANT", 0);
@@ -221,21 +237,24 @@ static int blur_sep_launch(const void* x, const float* fir_y, const float* fir_x
     dim3 grid((unsigned)gx, gy, major);
     p.xcd = xcd && gx >= 16 && gx % 8 == 0;      // (XCD of a workgroup = linear id % 8 = blockIdx.x % 8 only then)
     hipStream_t s = (hipStream_t)stream;
-#define BLUR_LAUNCH(TH_, ACT_)                                                                                            \
+#define BLUR_LAUNCH(TH_, ACT_, OCC_)                                                                                      \
     do {                                                                                                               \
         if (dtype == MSG_BF16)                                                                                         \
-            hipLaunchKernelGGL((blur_sep_kernel<bf16_t, TH_, 4, ACT_>), grid, dim3(256), 0, s, (const bf16_t*)x,      \
+            hipLaunchKernelGGL((blur_sep_kernel<bf16_t, TH_, OCC_, ACT_>), grid, dim3(256), 0, s, (const bf16_t*)x,   \
                                fir_y, fir_x, (bf16_t*)y, p);                                                          \
         else                                                                                                           \
             hipLaunchKernelGGL((blur_sep_kernel<float, TH_, 4, ACT_>), grid, dim3(256), 0, s, (const float*)x, fir_y, \
                                fir_x, (float*)y, p);                                                                  \
     } while (0)
+    // the bf16 kernel with the activation stage needs ~140 registers: at four waves per SIMD (128) it spills its window,
+    // at three it does not
+    static const int act_occ = msg_tunable("MSG_BLUR_ACT_OCC", 3);
     if (act.enabled) {
-        if (th == 32) BLUR_LAUNCH(32, true);
-        else BLUR_LAUNCH(16, true);
+        if (act_occ == 3) { if (th == 32) BLUR_LAUNCH(32, true, 3); else BLUR_LAUNCH(16, true, 3); }
+        else { if (th == 32) BLUR_LAUNCH(32, true, 4); else BLUR_LAUNCH(16, true, 4); }
     } else {
-        if (th == 32) BLUR_LAUNCH(32, false);
-        else BLUR_LAUNCH(16, false);
+        if (th == 32) BLUR_LAUNCH(32, false, 4);
+        else BLUR_LAUNCH(16, false, 4);
     }
 #undef BLUR_LAUNCH
     return MSG_CHECK_LAUNCH();

@@ -393,7 +393,7 @@ class ModelWrapper(object):
                 scores_out[name + suffix] = float(value)
             if "FVD" in name and self.best_fvd > scores[0]:
                 self.best_fvd = float(scores[0])
-        self._record(**{k: torch.tensor(v) for k, v in scores_out.items()})
+        self._record(**{k: torch.tensor(v, device=self.device) for k, v in scores_out.items()})
         return scores_out
 
     def train(self, training_dataset, epochs: int = 20, save_model_after_n_epochs: int = 5,

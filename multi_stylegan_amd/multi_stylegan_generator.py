@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import conv_ops, equalized_layer
-from .op_static import FusedLeakyReLU, blur_bias_act, fused_bias_noise_leaky_relu, upfirdn2d
+from .op_static import FusedLeakyReLU, blur_bias_act, fused_bias_noise_leaky_relu, rgb_skip, upfirdn2d
 
 
 
@@ -180,6 +180,20 @@ class StyledConv2d(nn.Module):
         return output
 
 
+def _merge_rgb(conv: torch.Tensor, bias: torch.Tensor, skip: Optional[torch.Tensor], upsampling: nn.Module) -> torch.Tensor:
+    """conv.float() + bias + upsampling(skip) (multi_stylegan_generator.py:519-523 of the reference) -- one launch
+    (op_static.rgb_skip) when the upsampler is the reference's x2 / 4-tap FIR, the composition of ops otherwise."""
+    fir = getattr(upsampling, "kernel", None) if skip is not None else None
+    if skip is None or isinstance(upsampling, Upsample):
+        factor, pad = (upsampling.factor, upsampling.padding) if skip is not None else (2, (2, 1))
+        if rgb_skip.supported(conv, skip, fir, factor, pad):
+            return rgb_skip.rgb_skip_merge(conv, bias.reshape(-1).float(), skip, fir)
+    output = conv.float().contiguous() + bias
+    if skip is not None:
+        output = output + upsampling(skip)
+    return output
+
+
 class OutputBlock(nn.Module):
     """1x1 modulated conv to the 3 time-step planes (no demodulation) + scalar bias + FIR-upsampled skip.
     The RGB path is small and is kept in fp32 / NCHW."""
@@ -197,9 +211,7 @@ class OutputBlock(nn.Module):
     def forward(self, input: torch.Tensor, style: torch.Tensor, skip: torch.Tensor = None):
         result = self.modulated_convolution(input, style)
         output, style_out = result if self.modulation_mapping else (result, None)
-        output = output.float().contiguous() + self.bias
-        if skip is not None:
-            output = output + self.upsampling(skip)
+        output = _merge_rgb(output, self.bias.expand(1, output.shape[1], 1, 1), skip, self.upsampling)
         if self.modulation_mapping:
             return output, style_out
         return output
@@ -333,10 +345,7 @@ class Generator(nn.Module):
         both = conv_ops.modulated_conv2d(features, torch.cat([mc1.weight, mc2.weight], dim=1),
                                          style.reshape(bsz, mc1.in_channels), demodulate=False, upsample=False)
         bias = torch.cat([head1.bias.expand(1, o1, 1, 1), head2.bias.expand(1, o2, 1, 1)], dim=1)
-        rgb = both.float().contiguous() + bias
-        if skip is not None:
-            rgb = rgb + head1.upsampling(skip)
-        return rgb, style
+        return _merge_rgb(both, bias, skip, head1.upsampling), style
 
     def forward(self, input: Union[List[torch.Tensor], torch.Tensor], return_main_style_vectors: bool = False,
                 noise: Optional[List[torch.Tensor]] = None, randomize_noise: bool = True,

@@ -377,3 +377,53 @@ def test_gamma_merge(dtype):
     ga, = torch.autograd.grad(ops.gamma_merge(a, b, gamma, gain), a, gyr, create_graph=True)
     h, = torch.autograd.grad(ga.float().square().sum(), gyr)
     assert rel_err(h.double(), 2 * (0.7 * gain) ** 2 * gy.double()) < 5 * tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 6, 8, 8), (2, 6, 64, 64), (2, 3, 16, 32), (1, 6, 4, 4)])
+@pytest.mark.parametrize("with_skip", [True, False])
+def test_rgb_skip_merge_vs_oracle(dtype, shape, with_skip):
+    """op_static.rgb_skip (csrc/rgb_skip.hip): conv.float() + bias + upfirdn2d(skip, up = 2, pad (2, 1)) -- OutputBlock.forward
+    of the reference (multi_stylegan_generator.py:519-523) -- against the CPU oracle's upfirdn2d with an ASYMMETRIC 4 x 4 FIR
+    (so that a flipped or transposed tap table fails): output, first-order gradients of all three operands, and the
+    second-order pass (gradient of a function of the first-order gradients), which the path-length regulariser runs."""
+    from multi_stylegan_amd import conv_ops
+    from multi_stylegan_amd.op_static import rgb_skip
+    from oracle import ops as oo
+    b, c, h, w = shape
+    gen = torch.Generator().manual_seed(h * 7 + c)
+    fir = torch.rand(4, 4, generator=gen) + 0.1
+    fir = fir / fir.sum()
+    conv0 = torch.randn(b, c, h, w, generator=gen).to(dtype).float()          # (values the storage type holds exactly)
+    bias0 = torch.randn(c, generator=gen)
+    skip0 = torch.randn(b, c, h // 2, w // 2, generator=gen) if with_skip else None
+    gy = torch.randn(b, c, h, w, generator=gen)
+    probe = [torch.randn(b, c, h, w, generator=gen), torch.randn(c, generator=gen),
+             torch.randn(b, c, h // 2, w // 2, generator=gen)]
+
+    def run(dev, fused):
+        conv = conv0.to(dev).requires_grad_(True)
+        bias = bias0.to(dev).requires_grad_(True)
+        skip = skip0.to(dev).requires_grad_(True) if with_skip else None
+        leaves = [conv, bias] + ([skip] if with_skip else [])
+        gyl = gy.to(dev).requires_grad_(True)
+        if fused:
+            cl = conv_ops.to_compute_layout(conv, dtype)
+            assert rgb_skip.supported(cl, skip, fir.to(dev), 2, (2, 1))
+            y = rgb_skip.rgb_skip_merge(cl, bias, skip, fir.to(dev))
+        else:
+            y = conv + bias.view(1, -1, 1, 1)
+            if with_skip:
+                y = y + oo.upfirdn2d(skip, fir.to(dev), up=2, down=1, pad=(2, 1))
+        grads = torch.autograd.grad(y, leaves, gyl, create_graph=True)
+        second = torch.autograd.grad(sum((g.float() * p.to(dev)).sum() for g, p in zip(grads, probe)), gyl)[0]
+        return [y] + list(grads) + [second]
+
+    got, want = run(DEV, True), run("cpu", False)
+    names = ["y", "g_conv", "g_bias"] + (["g_skip"] if with_skip else []) + ["second"]
+    for name, a, r in zip(names, got, want):
+        # (g_conv is stored in the conv's dtype, and the second-order result is a function of it)
+        tol = 1e-5 if (dtype == torch.float32 or name not in ("g_conv", "second")) else 1e-2
+        assert a.shape == r.shape and rel_err(a.float(), r) < tol, (name, rel_err(a.float(), r))
+    again = run(DEV, True)
+    assert all(torch.equal(a, b2) for a, b2 in zip(got, again))                         # gathers only: bit-reproducible

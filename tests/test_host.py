@@ -98,7 +98,10 @@ def _reducer_worker(rank, world, port, out):
     # gradients arriving in a different order on each rank must not reorder the collectives
     local = [t.clone() for t in torch.autograd.grad(model(x).square().sum(), params)]
     red.zero_grad(); red.arm()
-    order = list(range(len(params))) if rank == 0 else list(reversed(range(len(params))))
+    # (rank r starts its arrival order at a different parameter and odd ranks walk it backwards: four distinct orders at world 4)
+    order = [(i + rank) % len(params) for i in range(len(params))]
+    if rank % 2:
+        order.reverse()
     for i in order:
         params[i].grad.copy_(local[i])
         red._on_grad(params[i])
@@ -132,7 +135,7 @@ def _reducer_worker(rank, world, port, out):
     red2.zero_grad(); red2.arm("fwd")
     (model(x).square().sum() + (1.0 + rank) * model.unused.sum()).backward()
     red2.finish()
-    assert torch.allclose(model.unused.grad, torch.full((4,), 1.5))
+    assert torch.allclose(model.unused.grad, torch.full((4,), 1.0 + (world - 1) / 2.0))       # mean of 1 + rank
     # ... but a gradient that arrives for a bucket ALREADY on the wire is refused loudly, never silently dropped
     red4 = GradBucketReducer(params + [model.unused], bucket_bytes=64, overlap=True)
     mixed = next(b for b in red4.buckets if any(q is model.unused for q in b.params))
@@ -179,15 +182,24 @@ def _reducer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_bucket_reducer_gloo_world2():
+def _run_ranks(worker, world, port, timeout):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29000 + os.getpid() % 500
-    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    [p.join(120) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    [p.join(timeout) for p in procs]
+    hung = [p for p in procs if p.exitcode is None]
+    [p.kill() for p in hung]
+    assert not hung, "ranks deadlocked"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucket_reducer_gloo(world):
+    """world 4: four distinct gradient-arrival orders (collectives must still be issued in ONE order), means over four
+    shards, both exchanges."""
+    _run_ranks(_reducer_worker, world, 29000 + os.getpid() % 400 + 17 * world, 180)
 
 
 def _trainer_worker(rank, world, port, out):
@@ -198,6 +210,7 @@ def _trainer_worker(rank, world, port, out):
     from multi_stylegan_amd.model_wrapper import ModelWrapper
     from oracle import models as om                      # CPU stand-ins for G/D: the trainer logic is device-agnostic
     from tools.gen_golden import TINY_D, TINY_G
+    torch.set_num_threads(max(1, 8 // world))
     torch.manual_seed(10 + rank)                         # different init per rank: broadcast must fix it
     g, d = om.Generator(TINY_G), om.Discriminator(TINY_D, no_rfp=True)
     g.live_parameters = lambda: [p for n, p in g.named_parameters() if not n.startswith("main_convolutions_2.")]
@@ -211,6 +224,15 @@ def _trainer_worker(rank, world, port, out):
     probe = StepProbe(tr)
     tr.iteration = 15                                    # next iteration is 16: R1 and path length fire
     torch.manual_seed(1000 + rank)                       # different data per rank
+    # rank-distinct style-mixing graphs (what a real job has: every rank draws its own mixing coin and crossover layer):
+    # different crossover layers per rank, and the last rank of a world > 2 does not mix at all -- its generator graph has
+    # ONE mapping-network pass where the others have two, so gradients become ready in different orders on different ranks
+    import random
+    import numpy as np
+    random.seed(4321 + rank)
+    np.random.seed(99 + 7 * rank)
+    if world > 2 and rank == world - 1:
+        tr.hyperparameters = dict(tr.hyperparameters, p_mixed_noise=0.0)
     tr.train_iteration(torch.rand(2, 2, 3, 32, 32))
     logs = tr.pop_logs()
     # every step == the single-process step with the mean of the two shards' gradients
@@ -219,24 +241,21 @@ def _trainer_worker(rank, world, port, out):
     flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())])
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
-    assert torch.equal(both[0], both[1]), "replicas diverged"
+    assert all(torch.equal(both[0], other) for other in both[1:]), "replicas diverged"
     mpl = [torch.zeros(1) for _ in range(world)]
     dist.all_gather(mpl, tr.path_length_regularization.mean_path_length)
-    assert torch.equal(mpl[0], mpl[1])
+    assert all(torch.equal(mpl[0], other) for other in mpl[1:])
     if rank == 0:
         out.put("ok")
     dist.destroy_process_group()
 
 
-def test_trainer_data_parallel_gloo_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + os.getpid() % 400
-    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in procs]
-    [p.join(300) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
-    assert q.get(timeout=5) == "ok"
+@pytest.mark.parametrize("world", [2, 4])
+def test_trainer_data_parallel_gloo(world):
+    """One regularised iteration (D, R1, G, path-length steps) on `world` gloo ranks with rank-distinct data, latents and
+    style-mixing graphs: every optimiser step is the step of the MEAN of the shards' gradients (tests/ddp_probe.py), the
+    replicas and the path-length mean stay bit-identical."""
+    _run_ranks(_trainer_worker, world, 29500 + os.getpid() % 300 + 23 * world, 420)
 
 
 def _cut_mix_gate_worker(rank, world, port, out):
@@ -521,3 +540,19 @@ def test_metric_statistics_match_the_reference_values(golden):
     assert frames.shape == (3, 3, 1, 5, 4) and torch.equal(frames, omet.select_frames(z["normalize.x"], 1, t))
     with pytest.raises(ValueError, match="feature network"):
         vm.FID(None)
+
+
+def test_bench_multi_rank_fields():
+    """What bench.py's JSON line reports about the ranks (the fields the 8-GPU run is read by), on canned timings."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.multi_rank_fields(4, "nccl", False, 16, 20, [2.0, 2.5, 2.2, 2.4], 131.0)
+    assert f["rccl_ranks"] == 4 and f["backend"] == "nccl" and f["rehearsal_shared_gpu"] is False
+    assert f["per_rank_img_per_s"] == [160.0, 128.0, 145.45, 133.33]
+    assert f["overlap"] == {"on_ms_per_step": 125.0, "off_ms_per_step": 131.0}        # the slowest rank's 2.5 s / 20 steps
+    one = bench.multi_rank_fields(1, None, False, 16, 20, [2.25], None)
+    assert one["rccl_ranks"] == 1 and one["backend"] is None and one["overlap"] is None
+    reh = bench.multi_rank_fields(2, "gloo", True, 4, 3, [1.0, 1.0], 340.0)
+    assert reh["backend"] == "gloo" and reh["rehearsal_shared_gpu"] is True

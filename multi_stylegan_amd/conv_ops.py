@@ -390,6 +390,45 @@ def _param_images(w, dtype, gain, kind, modulation=False):
 # --------------------------------------------------------------------------------------------------- raw launches
 _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
 
+# How the contractions of the fp32-STORAGE path multiply (conv forward / data gradient / weight gradient; include/msg_hip.h):
+#   "exact"      -- v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (the default: what the 1e-3 parity gate was built on);
+#   "split_bf16" -- MSG_F32_SPLIT: every product as three bf16 MFMA products on (hi, lo) splits, fp32 accumulation: ~2^-17
+#                   relative error per product at ~5x the matrix rate.  Held to the same step-trace tolerances
+#                   (tests/test_hip_models.py); bench.py reports it as its own leg.
+#   "split_bf16x3" -- MSG_F32_SPLIT3: three components per operand (all 24 mantissa bits), six products: fp32-rounding-level.
+FP32_CONTRACTION = "exact"
+MSG_F32_SPLIT, MSG_F32_SPLIT3 = 4, 5
+_SPLIT_CODES = {"split_bf16": MSG_F32_SPLIT, "split_bf16x3": MSG_F32_SPLIT3}
+
+
+class fp32_contraction:
+    """``with conv_ops.fp32_contraction("split_bf16"): ...`` (or call ``.set`` for good)."""
+
+    def __init__(self, mode: str):
+        if mode not in ("exact", "split_bf16", "split_bf16x3"):
+            raise ValueError(f"fp32 contraction mode {mode!r}: 'exact', 'split_bf16' or 'split_bf16x3'")
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        global FP32_CONTRACTION
+        self.prev, FP32_CONTRACTION = FP32_CONTRACTION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global FP32_CONTRACTION
+        FP32_CONTRACTION = self.prev
+        return False
+
+    @staticmethod
+    def set(mode: str) -> None:
+        fp32_contraction(mode).__enter__()
+
+
+def _contraction_code(t: torch.Tensor) -> int:
+    """Storage code of a contraction operand: fp32 maps carry MSG_F32_SPLIT when the split-bf16 products are selected."""
+    code = _lib.dtype_code(t)
+    return _SPLIT_CODES[FP32_CONTRACTION] if (code == _lib.MSG_F32 and FP32_CONTRACTION != "exact") else code
+
 
 def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real,
                   flops=None, act=None, residual=None, out=None):
@@ -440,11 +479,11 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
             rv, res_ld = _nhwc_view(residual[0])
             assert rv.shape == (b, n, oh, ow) and rv.dtype == x.dtype
             code = _lib.lib().msg_conv2d_fprop_residual(
-                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
+                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _contraction_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
                 stride, pad, wstride, rv.data_ptr(), res_ld, float(residual[1]), _lib.stream_of(dev))
         elif act is None:
             code = _lib.lib().msg_conv2d_fprop(
-                xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh,
+                xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _contraction_code(x), b, ih, iw, cx, ck, oh,
                 ow, n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))
         else:
             assert bias is None and in_up == 1 and not pixel_shuffle
@@ -461,7 +500,7 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
                     if mask is not None:
                         act[5].append((mask, 256 if mplan == 3 else 128, 256 if mplan == 3 else 128))
             code = _lib.lib().msg_conv2d_fprop_act_mask(
-                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
+                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _contraction_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
                 stride, pad, wstride, _lib.ptr(act_bias), _lib.ptr(noise), _lib.ptr(noise_w),
                 1 if noise is None else noise.shape[0], float(alpha), float(scale), _lib.ptr(mask), _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_fprop")
@@ -497,7 +536,7 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
         k_chunks = max(1, min((oh * ow + 4 * kp - 1) // (4 * kp), (1024 + tiles - 1) // tiles))
         while b * k_chunks > 65535:
             k_chunks -= 1
-    geom = (_lib.dtype_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw, kh, kw, stride, pad, int(pixel_shuffle),
+    geom = (_contraction_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw, kh, kw, stride, pad, int(pixel_shuffle),
             int(per_sample), k_chunks)
     # K-slices that add up to one result meet in a workspace of per-slice slabs and a fixed-order sum (deterministic; no
     # float atomics, no zero fill).  That sum also transposes a SHARED gradient into the parameter's own [O, I, kh, kw]

@@ -51,13 +51,42 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((sl
 // @256^2 255 -> 237 us; whole training step -1 ms.  What these launches still pay (ablations on 1x1 128->256: full 322
 // us, no global stores 246, no epilogue 172): the accumulator -> LDS -> 16-B-store epilogue is NOT hidden by the other
 // workgroups of the CU (de-phasing them with a start-up delay changed nothing, non-temporal stores neither).
-template <typename T, bool DMA, int LEAN = 0>
+// SPLIT (T = float, MSG_F32_SPLIT): the staged fp32 operands are split into bf16 (hi, lo) pairs in registers and each product
+// is three v_mfma_f32_32x32x16_bf16 -- hi hi + hi lo + lo hi -- instead of eight exact v_mfma_f32_32x32x2_f32: ~2^-17
+// relative error per product, fp32 accumulation, 5x the matrix rate of the exact form (msg_hip.h).
+// SPLIT = 2: (hi, lo), three products, 16 mantissa bits per operand; SPLIT = 3 (MSG_F32_SPLIT3): (hi, mid, lo), the six
+// products down to 2^-16 of the leading one (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid), all 24 bits: fp32-rounding-level.
+// x[0..7] -> bf16 vectors: hi = RNE(x), mid = RNE(x - hi), lo = RNE(x - hi - mid) (lo only when asked for)
+template <bool THREE>
+__device__ __forceinline__ void split_bf16x8(const f32x4& a, const f32x4& b, bf16v8& hi, bf16v8& mid, bf16v8& lo) {
+    typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
+    u32v4 h, m, l = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? a[2 * e] : b[2 * e - 4], x1 = e < 2 ? a[2 * e + 1] : b[2 * e - 3];
+        const unsigned hp = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
+        const unsigned mp = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+        h[e] = hp;
+        m[e] = mp;
+        if constexpr (THREE) {
+            const float q0 = r0 - __uint_as_float(mp << 16), q1 = r1 - __uint_as_float(mp & 0xffff0000u);
+            l[e] = (unsigned)f2bf(q0) | ((unsigned)f2bf(q1) << 16);
+        }
+    }
+    hi = __builtin_bit_cast(bf16v8, h);
+    mid = __builtin_bit_cast(bf16v8, m);
+    lo = __builtin_bit_cast(bf16v8, l);
+}
+
+template <typename T, bool DMA, int LEAN = 0, int SPLIT = 0>
 __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                             T* __restrict__ y, const float* __restrict__ bias,
                                                             ConvParams p) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int BKE = ROWB / sizeof(T);
     static_assert(!LEAN || (!DMA && sizeof(T) == 2), "lean variant: bf16, register staging");
+    static_assert(SPLIT == 0 || sizeof(T) == 4, "split-bf16 products are a mode of the fp32-storage kernel");
     __shared__ __attribute__((aligned(16))) char smem[(LEAN ? 1 : 2) * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -222,6 +251,36 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA x4   (step 1)
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 3)
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // MFMA x8   (steps 2, 3)
+        } else if constexpr (SPLIT != 0) {
+            // two sub-steps of 16 channels: lane (lr, lh) owns the 8 floats at 16-B slots 4 s + 2 lh, + 1 of its rows (any k
+            // order is fine as long as A and B agree), splits them once, and the 2 x 2 blocks take three MFMAs each
+#pragma unroll
+            for (int sstep = 0; sstep < 2; ++sstep) {
+                bf16v8 ah[2], al[2], bh[2], bl[2], a3[2], b3[2];         // (al / bl: the second component, a3 / b3: the third)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int ra_ = wm * 64 + t * 32 + lr, rb_ = wn * 64 + t * 32 + lr;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + swz(ra_, 4 * sstep + 2 * lh)),
+                                a1 = *reinterpret_cast<const f32x4*>(sa + swz(ra_, 4 * sstep + 2 * lh + 1)),
+                                b0 = *reinterpret_cast<const f32x4*>(sb + swz(rb_, 4 * sstep + 2 * lh)),
+                                b1 = *reinterpret_cast<const f32x4*>(sb + swz(rb_, 4 * sstep + 2 * lh + 1));
+                    split_bf16x8<SPLIT == 3>(a0, a1, ah[t], al[t], a3[t]);
+                    split_bf16x8<SPLIT == 3>(b0, b1, bh[t], bl[t], b3[t]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (SPLIT == 3) {                      // the 2^-16 terms
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3[j], ah[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a3[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], al[i], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);   // (small terms first)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+            }
         } else {
             // lane half h owns k = 16h .. 16h+15 of the 32-float run (any k order is fine as long as A and B agree)
 #pragma unroll
@@ -502,6 +561,8 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     if (!x || !w || !y || B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || N <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || in_up <= 0 || Cx <= 0 || Ck <= 0 || ldy <= 0)
         return MSG_EINVAL;
+    const int split = dtype == MSG_F32_SPLIT ? 2 : (dtype == MSG_F32_SPLIT3 ? 3 : 0);   // fp32 storage, bf16 MFMA products (msg_hip.h)
+    if (split) dtype = MSG_F32;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz, bke = 128 / esz;
     if (Ck % bke || Cx % vec || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15u)) return MSG_EUNSUPPORTED;
@@ -553,6 +614,12 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
         if (!dma && p.n_iters <= lean_max) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
         else if (dma) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
         else hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
+    } else if (split == 2) {
+        if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true, 0, 2>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
+        else hipLaunchKernelGGL((conv_fprop_kernel<float, false, 0, 2>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
+    } else if (split == 3) {
+        if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true, 0, 3>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
+        else hipLaunchKernelGGL((conv_fprop_kernel<float, false, 0, 3>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
     } else {
         if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
         else hipLaunchKernelGGL((conv_fprop_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);

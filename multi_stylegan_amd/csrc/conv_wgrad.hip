@@ -62,7 +62,9 @@ template <typename T> __device__ __forceinline__ int wg_off(int r, int ch) {
 // per K-step that the generic incremental addressing costs (the kernel was VALU-bound: 12 VALU per MFMA).
 constexpr int BUF_OOB = (int)0x80000000;             // voffset >= num_records: the buffer load returns 0
 
-template <typename T, bool DMA, bool UNI>
+// SPLIT (T = float, MSG_F32_SPLIT): products as three bf16 MFMAs on (hi, lo) splits of the staged fp32 operands, see
+// conv_fprop.hip / msg_hip.h.
+template <typename T, bool DMA, bool UNI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                             float* __restrict__ gw, float* __restrict__ ws, WgradParams p) {
     constexpr int VEC = 16 / sizeof(T);
@@ -317,6 +319,58 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // step 3
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else if constexpr (SPLIT != 0) {
+                // k-steps of 16 pixels: lane (lr, lh) gathers channel lr of the 8 pixel rows 16 ks + 8 lh + e of each operand
+                // block (the tile is [pixel][channel]: a transposed read, one float per row), splits them into bf16 hi / lo
+                // and the 2 x 2 blocks take three MFMAs each
+                const int lr = lane & 31, lh = lane >> 5;
+                typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
+                auto frag = [&](const char* base, int ks, int col, bf16v8& hi, bf16v8& lo, bf16v8& lo3) __attribute__((always_inline)) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = ks * 16 + 8 * lh + e;
+                        v[e] = *reinterpret_cast<const float*>(base + r * ROW + ((col * 4 + ((r & 3) << 6)) & (ROW - 1)));
+                    }
+                    u32v4 h, l, l3 = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned hp = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+                        const float r0 = v[2 * e] - __uint_as_float(hp << 16), r1 = v[2 * e + 1] - __uint_as_float(hp & 0xffff0000u);
+                        const unsigned mp = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+                        h[e] = hp;
+                        l[e] = mp;
+                        if constexpr (SPLIT == 3) {
+                            const float q0 = r0 - __uint_as_float(mp << 16), q1 = r1 - __uint_as_float(mp & 0xffff0000u);
+                            l3[e] = (unsigned)f2bf(q0) | ((unsigned)f2bf(q1) << 16);
+                        }
+                    }
+                    hi = __builtin_bit_cast(bf16v8, h);
+                    lo = __builtin_bit_cast(bf16v8, l);
+                    lo3 = __builtin_bit_cast(bf16v8, l3);
+                };
+#pragma unroll
+                for (int ks = 0; ks < KP / 16; ++ks) {
+                    bf16v8 ah[2], al[2], bh[2], bl[2], a3[2], b3[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        frag(sa, ks, wm * 64 + t * 32 + lr, ah[t], al[t], a3[t]);
+                        frag(sb, ks, wn * 64 + t * 32 + lr, bh[t], bl[t], b3[t]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if constexpr (SPLIT == 3) {              // (hi, mid, lo): the 2^-16 terms
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i], bh[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], b3[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bl[j], acc[i][j], 0, 0, 0);
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // (small terms first)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                }
             } else {
                 const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll 4
@@ -438,6 +492,8 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
         kw <= 0 || stride <= 0 || Cx <= 0 || ldgy <= 0 || ldgw < I || ldgw % 4 || k_chunks <= 0)
         return MSG_EINVAL;
     if (!plan_only && (!gy || !x || !gw)) return MSG_EINVAL;
+    const int split = dtype == MSG_F32_SPLIT ? 2 : (dtype == MSG_F32_SPLIT3 ? 3 : 0);   // fp32 storage, bf16 MFMA products (msg_hip.h)
+    if (split) dtype = MSG_F32;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz;
     if (Cx % vec || ldgy % vec) return MSG_EUNSUPPORTED;
@@ -534,6 +590,14 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
         if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
         else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
+    } else if (split == 2) {
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false, 2>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true, 2>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false, false, 2>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+    } else if (split == 3) {
+        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false, 3>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true, 3>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false, false, 3>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
     } else {
         if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
         else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);

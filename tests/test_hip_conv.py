@@ -91,6 +91,52 @@ def test_conv_primitives(case, per_sample, dtype):
     assert rel_err(ggx.float(), ggx_r) < tol, "d(wgrad)/dx"
 
 
+@pytest.mark.parametrize("mode,tol", [("split_bf16", 1e-4), ("split_bf16x3", 2e-6)])
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_primitives_split_bf16_products(case, per_sample, mode, tol):
+    """The fp32-storage contractions with MSG_F32_SPLIT / MSG_F32_SPLIT3 (conv_ops.fp32_contraction): every product as three
+    (six) bf16 MFMA products on (hi, lo) / (hi, mid, lo) splits, fp32 accumulation.  Forward, data gradient, weight gradient and the two
+    second-order contractions on operands with FULL fp32 mantissas against the fp64 reference: within 1e-4 of max|ref| (the
+    tolerance of the exact-fp32 kernels; a plain bf16 product of these operands is off by 4e-3), and measurably not the
+    exact kernel (the mode really ran)."""
+    from multi_stylegan_amd import conv_ops
+    name, kind, b, i, o, h, w_, k, stride, pad = case
+    g = torch.Generator().manual_seed(len(name) * 11 + b)
+    x = torch.randn(b, i, h, w_, generator=g).double()
+    wshape = (b, o, i, k, k) if per_sample else (o, i, k, k)
+    w = (torch.randn(*wshape, generator=g) / math.sqrt(i * k * k)).double()
+    x, w = x.float().double(), w.float().double()                     # fp32-representable, 24-bit mantissas
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = _reference(kind, xr, wr, stride, pad, per_sample)
+    gy = torch.randn(yr.shape, generator=g).float().double()
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy, create_graph=True)
+    v = torch.randn(x.shape, generator=g).float().double()
+    u = torch.randn(w.shape, generator=g).float().double()
+    ggw_r, = torch.autograd.grad(gxr, wr, v, retain_graph=True)
+    ggx_r, = torch.autograd.grad(gwr, xr, u, retain_graph=True)
+    geo = conv_ops.Geometry(kind, k, k, stride if kind == "conv" else 1, pad, (h, w_), per_sample)
+    cl = lambda t: t.to(DEV, torch.float32).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        xd, wd = cl(x).requires_grad_(True), w.to(DEV, torch.float32).requires_grad_(True)
+        y = conv_ops._ConvF.apply(xd, wd, None, geo)
+        gx, gw = torch.autograd.grad(y, (xd, wd), cl(gy) if y.shape[1] > 1 else gy.to(DEV, torch.float32), create_graph=True)
+        ggw, = torch.autograd.grad(gx, wd, cl(v), retain_graph=True)
+        ggx, = torch.autograd.grad(gw, xd, u.to(DEV, torch.float32), retain_graph=True)
+        return y.detach(), gx.detach(), gw.detach(), ggw.detach(), ggx.detach()
+
+    exact = run()
+    with conv_ops.fp32_contraction(mode):
+        split = run()
+    assert conv_ops.FP32_CONTRACTION == "exact"
+    for nm, got, ex, ref in zip(("forward", "data gradient", "weight gradient", "d(dgrad)/dw", "d(wgrad)/dx"), split, exact,
+                                (yr, gxr, gwr, ggw_r, ggx_r)):
+        # split_bf16x3 (all 24 mantissa bits, six products) sits at the exact kernel's own error, fp32 rounding of the sums
+        assert rel_err(got.float(), ref) < max(tol, 2.0 * rel_err(ex.float(), ref)), (nm, rel_err(got.float(), ref), rel_err(ex.float(), ref))
+    assert any(not torch.equal(a, e) for a, e in zip(split, exact)), "the split products did not run"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv2d_bias_and_linear(dtype):
     from multi_stylegan_amd import conv_ops
@@ -454,6 +500,10 @@ PP_CASES = [  # shapes that take the 256x256 ping-pong kernel: name, kind, B, I,
     ("row3_256w", "conv", 1, 128, 288, 5, 256, 3, 1, 1, False),
     ("row3_64w_ps_ragged_n", "conv", 3, 136, 264, 64, 64, 3, 1, 1, True),
     ("row3_512w_ps", "conv", 8, 64, 256, 16, 512, 3, 1, 1, True),                # tiles start mid-row: live left / right neighbours
+    # exactly 256 wide, > 128 channels, N a multiple of 256: one whole image row per 256 x 256 tile (the benchmark's largest
+    # launches), both halo rows outside the image; top / bottom image rows, 3 and 4 channel chunks
+    ("row3_256w_ps_192", "conv", 2, 192, 512, 60, 256, 3, 1, 1, True),
+    ("row3_256w_shared_256", "conv", 4, 256, 256, 64, 256, 3, 1, 1, False),
     # the 128 x 128 variant (two workgroups per CU) for 128 / 384 output channels
     ("row3_narrow_128", "conv", 4, 128, 128, 64, 128, 3, 1, 1, False),
     ("row3_narrow_384", "conv", 8, 64, 384, 64, 64, 3, 1, 1, False),
@@ -518,7 +568,7 @@ def test_grouped_linear_matches_per_layer(g, b, l, n, k):
 
 
 @pytest.mark.parametrize("shape", [(4, 512, 512, 64, 64, 3, True), (2, 256, 256, 128, 128, 3, False),
-                                    (2, 128, 512, 32, 256, 3, True), (4, 256, 256, 48, 48, 1, False),
+                                    (2, 128, 512, 32, 256, 3, True), (2, 192, 512, 64, 256, 3, True), (4, 256, 256, 48, 48, 1, False),
                                     (2, 128, 128, 128, 128, 3, False), (8, 64, 256, 16, 512, 3, True),
                                     (8, 128, 128, 128, 256, 3, False), (16, 64, 384, 64, 64, 3, False),
                                     (32, 768, 768, 32, 32, 3, False)])

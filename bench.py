@@ -163,16 +163,13 @@ def fp32_leg(args, dev, batch: int = 4, steps: int = 3, split: str = ""):
     from multi_stylegan_amd import conv_ops
     from multi_stylegan_amd.config import generator_config_for_resolution
     if split:
-        # `split`: the contractions as three bf16 MFMA products on (hi, lo) splits of the fp32 operands (MSG_F32_SPLIT; held to
+        # `split`: the contractions as six bf16 MFMA products on (hi, mid, lo) splits of the fp32 operands (MSG_F32_SPLIT; held to
         # the same step-trace tolerances as the exact path: tests/test_hip_models.py::test_train_iteration_split_bf16_products)
         with conv_ops.fp32_contraction(split):
             out = fp32_leg(args, dev, batch, steps)
-        six = split == "split_bf16x3"
-        out["dtype"] = "f32 storage, bf16 MFMA products on " + ("(hi, mid, lo) splits: six products, all 24 mantissa bits" if six
-                                                               else "(hi, lo) splits: three products, 16 mantissa bits") + ", fp32 accumulate"
-        out["sample"] = out["sample"].replace("exact-fp32 MFMA", ("six" if six else "three") + " bf16 MFMA products per product")
-        out["step_parity"] = "gradients 1e-3 / norm 1e-4 / movement 2e-3, as the exact path (tests/test_hip_models.py)" if six else \
-            "gradients 2e-3 / norm 1e-4 / movement 2e-3 (two bias gradients of the regularised steps at 1.1e-3 / 1.5e-3)"
+        out["dtype"] = "f32 storage, six bf16 MFMA products per product on (hi, mid, lo) splits (all 24 mantissa bits), fp32 accumulate"
+        out["sample"] = out["sample"].replace("exact-fp32 MFMA", "six bf16 MFMA products per product")
+        out["step_parity"] = "gradients 1e-3 / norm 1e-4 / movement 2e-3, as the exact path (tests/test_hip_models.py)"
         return out
     torch.manual_seed(1234)
     gen = m.MultiStyleGANGenerator(generator_config_for_resolution(args.resolution))
@@ -498,8 +495,6 @@ def main():
             torch.cuda.empty_cache()
             note(f"fp32-storage legs with split-bf16 products (batch {args.batch}) ...")
             out["value_fp32_split_path"] = fp32_leg(args, dev, batch=args.batch, split="split_bf16x3")
-            torch.cuda.empty_cache()
-            out["value_fp32_split2_path"] = fp32_leg(args, dev, batch=args.batch, split="split_bf16")
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
             note("CPU baseline (oracle, 64x64, B=4" + ("" if args.no_cpu_same_resolution else
                                                        f"; one iteration at {args.resolution}^2, B=2") + ") ...")

@@ -29,13 +29,13 @@ extern "C" {
 #endif
 
 enum { MSG_OK = 0, MSG_EINVAL = -1, MSG_EUNSUPPORTED = -2, MSG_ELAUNCH = -3 };
-enum { MSG_F32 = 0, MSG_BF16 = 1, MSG_F16 = 2, MSG_F64 = 3, MSG_F32_SPLIT = 4, MSG_F32_SPLIT3 = 5 };
+enum { MSG_F32 = 0, MSG_BF16 = 1, MSG_F16 = 2, MSG_F64 = 3, MSG_F32_SPLIT = 4 };
 /* MSG_F32_SPLIT (msg_conv2d_fprop* / msg_conv2d_wgrad* only): fp32 STORAGE like MSG_F32, but every product of the contraction
- * is taken as three bf16 MFMA products with fp32 accumulation -- x = xh + xl, w = wh + wl (xh = bf16(x), xl = bf16(x - xh)):
- * x w ~ xh wh + xh wl + xl wh, relative error ~2^-17 per product (the dropped xl wl term) instead of the exact-fp32 MFMA of
- * MSG_F32, at a third of the bf16 matrix rate instead of a sixteenth.  MSG_F32_SPLIT3: three components per operand
- * (hi, mid, lo: all 24 mantissa bits) and the six products down to 2^-16 of the leading one -- error at fp32-rounding level,
- * a sixth of the bf16 matrix rate.  Workspaces and layouts are those of MSG_F32. */
+ * is taken as SIX bf16 MFMA products with fp32 accumulation: x = xh + xm + xl, w = wh + wm + wl (xh = bf16(x), xm = bf16(x - xh),
+ * xl = bf16(x - xh - xm): all 24 mantissa bits), x w ~ xh wh + xh wm + xm wh + xh wl + xl wh + xm wm -- everything down to
+ * 2^-16 of the leading product; the error is at fp32-rounding level (the exact-fp32 MFMA of MSG_F32 runs at a sixteenth of the
+ * bf16 matrix rate, this at a sixth).  Workspaces and layouts are those of MSG_F32.  (A three-product form on (hi, lo) splits
+ * was built too: 16 mantissa bits per operand move the training step's gradients by up to 1e-2 -- not a parity path; removed.) */
 
 /* Library/ABI version and the code-object architecture it was built for ("gfx950"). */
 int msg_abi_version(void);

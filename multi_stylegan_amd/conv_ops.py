@@ -391,22 +391,21 @@ def _param_images(w, dtype, gain, kind, modulation=False):
 _CLOCK_SHAPES = bool(int(os.environ.get("MSG_CLOCK_SHAPES", "0")))   # per-shape timing keys (tools/shape_table.py)
 
 # How the contractions of the fp32-STORAGE path multiply (conv forward / data gradient / weight gradient; include/msg_hip.h):
-#   "exact"      -- v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (the default: what the 1e-3 parity gate was built on);
-#   "split_bf16" -- MSG_F32_SPLIT: every product as three bf16 MFMA products on (hi, lo) splits, fp32 accumulation: ~2^-17
-#                   relative error per product at ~5x the matrix rate.  Held to the same step-trace tolerances
-#                   (tests/test_hip_models.py); bench.py reports it as its own leg.
-#   "split_bf16x3" -- MSG_F32_SPLIT3: three components per operand (all 24 mantissa bits), six products: fp32-rounding-level.
+#   "exact"        -- v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (the default: what the 1e-3 parity gate was built on);
+#   "split_bf16x3" -- MSG_F32_SPLIT: every product as six bf16 MFMA products on (hi, mid, lo) splits of the operands (all 24
+#                     mantissa bits), fp32 accumulation: fp32-rounding-level error, held to the SAME step-trace tolerances
+#                     (tests/test_hip_models.py); bench.py reports it as its own leg.
 FP32_CONTRACTION = "exact"
-MSG_F32_SPLIT, MSG_F32_SPLIT3 = 4, 5
-_SPLIT_CODES = {"split_bf16": MSG_F32_SPLIT, "split_bf16x3": MSG_F32_SPLIT3}
+MSG_F32_SPLIT = 4
+_SPLIT_CODES = {"split_bf16x3": MSG_F32_SPLIT}
 
 
 class fp32_contraction:
-    """``with conv_ops.fp32_contraction("split_bf16"): ...`` (or call ``.set`` for good)."""
+    """``with conv_ops.fp32_contraction("split_bf16x3"): ...`` (or call ``.set`` for good)."""
 
     def __init__(self, mode: str):
-        if mode not in ("exact", "split_bf16", "split_bf16x3"):
-            raise ValueError(f"fp32 contraction mode {mode!r}: 'exact', 'split_bf16' or 'split_bf16x3'")
+        if mode not in ("exact", "split_bf16x3"):
+            raise ValueError(f"fp32 contraction mode {mode!r}: 'exact' or 'split_bf16x3'")
         self.mode, self.prev = mode, None
 
     def __enter__(self):

@@ -51,32 +51,34 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((sl
 // @256^2 255 -> 237 us; whole training step -1 ms.  What these launches still pay (ablations on 1x1 128->256: full 322
 // us, no global stores 246, no epilogue 172): the accumulator -> LDS -> 16-B-store epilogue is NOT hidden by the other
 // workgroups of the CU (de-phasing them with a start-up delay changed nothing, non-temporal stores neither).
-// SPLIT (T = float, MSG_F32_SPLIT): the staged fp32 operands are split into bf16 (hi, lo) pairs in registers and each product
-// is three v_mfma_f32_32x32x16_bf16 -- hi hi + hi lo + lo hi -- instead of eight exact v_mfma_f32_32x32x2_f32: ~2^-17
-// relative error per product, fp32 accumulation, 5x the matrix rate of the exact form (msg_hip.h).
-// SPLIT = 2: (hi, lo), three products, 16 mantissa bits per operand; SPLIT = 3 (MSG_F32_SPLIT3): (hi, mid, lo), the six
-// products down to 2^-16 of the leading one (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid), all 24 bits: fp32-rounding-level.
-// x[0..7] -> bf16 vectors: hi = RNE(x), mid = RNE(x - hi), lo = RNE(x - hi - mid) (lo only when asked for)
-template <bool THREE>
-__device__ __forceinline__ void split_bf16x8(const f32x4& a, const f32x4& b, bf16v8& hi, bf16v8& mid, bf16v8& lo) {
-    typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
-    u32v4 h, m, l = {0u, 0u, 0u, 0u};
+// SPLIT = 3 (T = float; MSG_F32_SPLIT): fp32 storage, every product as bf16 MFMA products on splits of the
+// fp32 operands, fp32 accumulation (include/msg_hip.h).  The split happens ONCE PER ELEMENT, on the way from the staging
+// registers into LDS: a thread turns the four floats of a staged 16-byte vector into SPLIT planes of four bf16 each (hi = RNE(x),
+// mid = RNE(x - hi), lo = RNE(x - hi - mid)) and parks 8 bytes per plane; the LDS image of a K-step is then SPLIT bf16 planes of
+// 32 channels per row (row = SPLIT * 64 B + 16 B of padding: conflict-free ds_read_b128), and the MFMA loop is fragment reads
+// and v_mfma_f32_32x32x16_bf16 only -- hi hi + hi mid + mid hi + hi lo + lo hi + mid mid, everything
+// down to 2^-16 of the leading product.  (The first version split the fragments inside the MFMA loop, every wave its own copy
+// of every operand: 5.5 vector instructions per element and sub-step made the six-product kernel 1.13x the speed of the exact
+// fp32 MFMA instead of the 2.7x its matrix time allows.)  Register staging only (LDS-DMA cannot convert in flight).
+// four floats -> SPLIT x (four bf16 = 8 bytes)
+template <int SPLIT>
+__device__ __forceinline__ void split_park(const u32x4& raw, char* dst) {
+    uint2 pl[3];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x0 = e < 2 ? a[2 * e] : b[2 * e - 4], x1 = e < 2 ? a[2 * e + 1] : b[2 * e - 3];
+    for (int h = 0; h < 2; ++h) {
+        const float x0 = __uint_as_float(raw[2 * h]), x1 = __uint_as_float(raw[2 * h + 1]);
         const unsigned hp = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
         const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
         const unsigned mp = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
-        h[e] = hp;
-        m[e] = mp;
-        if constexpr (THREE) {
+        (h ? pl[0].y : pl[0].x) = hp;
+        (h ? pl[1].y : pl[1].x) = mp;
+        if constexpr (SPLIT == 3) {
             const float q0 = r0 - __uint_as_float(mp << 16), q1 = r1 - __uint_as_float(mp & 0xffff0000u);
-            l[e] = (unsigned)f2bf(q0) | ((unsigned)f2bf(q1) << 16);
+            (h ? pl[2].y : pl[2].x) = (unsigned)f2bf(q0) | ((unsigned)f2bf(q1) << 16);
         }
     }
-    hi = __builtin_bit_cast(bf16v8, h);
-    mid = __builtin_bit_cast(bf16v8, m);
-    lo = __builtin_bit_cast(bf16v8, l);
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(dst + p * 64) = pl[p];
 }
 
 template <typename T, bool DMA, int LEAN = 0, int SPLIT = 0>
@@ -87,7 +89,17 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
     constexpr int BKE = ROWB / sizeof(T);
     static_assert(!LEAN || (!DMA && sizeof(T) == 2), "lean variant: bf16, register staging");
     static_assert(SPLIT == 0 || sizeof(T) == 4, "split-bf16 products are a mode of the fp32-storage kernel");
-    __shared__ __attribute__((aligned(16))) char smem[(LEAN ? 1 : 2) * STAGE_BYTES];
+    static_assert(SPLIT == 0 || !DMA, "the split planes are written from the staging registers");
+    // (SPLIT: rows of SPLIT bf16 planes x 64 B + 16 B of padding -- 144 / 208 B: rows 0..7 of a ds_read_b128 lane group then
+    //  start 36 / 52 banks apart, all different 4-bank groups -- 72 KiB / 104 KiB for the two stages)
+    constexpr int SROW = SPLIT ? SPLIT * 64 + 16 : ROWB;
+    constexpr int STAGE = SPLIT ? (BM + BN) * SROW : STAGE_BYTES;
+    // ONE_STAGE: the three-plane image of a K-step is 52 KiB; two stages would leave room for one workgroup per CU (one wave per
+    // SIMD, nothing to overlap a barrier with: measured 673 ms per iteration against 618 for the in-loop split).  One stage
+    // and two barriers per K-step instead (the LEAN pipeline), 64 KiB with the epilogue's patches: two workgroups per CU.
+    constexpr bool ONE_STAGE = LEAN != 0 || SPLIT == 3;
+    constexpr int SMEM_BYTES = ONE_STAGE ? (STAGE > 65536 || sizeof(T) == 2 ? STAGE : 65536) : 2 * STAGE;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             if (c_bad) a_addr = zbase + zoff;
             if constexpr (DMA) {
                 // wave-uniform LDS destination: rows 32 w + 8 j .. +7 of the stage being filled, lanes in order
-                lds_t la = (lds_t)(smem + dma_stage * STAGE_BYTES + (wid_u * 32 + 8 * j) * ROWB);
+                lds_t la = (lds_t)(smem + dma_stage * STAGE + (wid_u * 32 + 8 * j) * ROWB);
                 __builtin_amdgcn_global_load_lds(a_addr, la, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(pb[j], la + BM * ROWB, 16, 0, 0);
             } else {
@@ -210,7 +222,16 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
         }
     };
     auto park = [&](int stage) __attribute__((always_inline)) {  // registers -> LDS stage
-        char* sa = smem + stage * STAGE_BYTES;
+        char* sa = smem + stage * STAGE;
+        if constexpr (SPLIT != 0) {
+            char* sb = sa + BM * SROW;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                       // floats 4 slot .. 4 slot + 3 of the row -> 8 bytes per plane
+                split_park<SPLIT>(ra[j], sa + row_of[j] * SROW + slot_phys * 8);
+                split_park<SPLIT>(rb[j], sb + row_of[j] * SROW + slot_phys * 8);
+            }
+            return;
+        }
         char* sb = sa + BM * ROWB;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -252,33 +273,28 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read x4 (step 3)
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // MFMA x8   (steps 2, 3)
         } else if constexpr (SPLIT != 0) {
-            // two sub-steps of 16 channels: lane (lr, lh) owns the 8 floats at 16-B slots 4 s + 2 lh, + 1 of its rows (any k
-            // order is fine as long as A and B agree), splits them once, and the 2 x 2 blocks take three MFMAs each
+            // two sub-steps of 16 channels; lane (lr, lh) reads, per plane, the 8 bf16 at k = 16 s + 8 lh of its rows
+            const char* sbs = sa + BM * SROW;
 #pragma unroll
             for (int sstep = 0; sstep < 2; ++sstep) {
-                bf16v8 ah[2], al[2], bh[2], bl[2], a3[2], b3[2];         // (al / bl: the second component, a3 / b3: the third)
+                bf16v8 af[SPLIT][2], bf[SPLIT][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int ra_ = wm * 64 + t * 32 + lr, rb_ = wn * 64 + t * 32 + lr;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + swz(ra_, 4 * sstep + 2 * lh)),
-                                a1 = *reinterpret_cast<const f32x4*>(sa + swz(ra_, 4 * sstep + 2 * lh + 1)),
-                                b0 = *reinterpret_cast<const f32x4*>(sb + swz(rb_, 4 * sstep + 2 * lh)),
-                                b1 = *reinterpret_cast<const f32x4*>(sb + swz(rb_, 4 * sstep + 2 * lh + 1));
-                    split_bf16x8<SPLIT == 3>(a0, a1, ah[t], al[t], a3[t]);
-                    split_bf16x8<SPLIT == 3>(b0, b1, bh[t], bl[t], b3[t]);
-                }
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int pl = 0; pl < SPLIT; ++pl) {
+                        af[pl][t] = *reinterpret_cast<const bf16v8*>(sa + (wm * 64 + t * 32 + lr) * SROW + pl * 64 + (2 * sstep + lh) * 16);
+                        bf[pl][t] = *reinterpret_cast<const bf16v8*>(sbs + (wn * 64 + t * 32 + lr) * SROW + pl * 64 + (2 * sstep + lh) * 16);
+                    }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if constexpr (SPLIT == 3) {                      // the 2^-16 terms
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3[j], ah[i], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], a3[i], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], al[i], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);   // (small terms first)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                        // small terms first: plane sums 2 (2^-16 of the leading product), then 1 (2^-8), then hi hi
+#pragma unroll
+                        for (int order = SPLIT - 1; order >= 0; --order)
+#pragma unroll
+                            for (int pa = 0; pa <= order; ++pa)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[order - pa][j], af[pa][i], acc[i][j], 0, 0, 0);
                     }
             }
         } else {
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             }
         }
     };
-    if constexpr (LEAN) {
+    if constexpr (ONE_STAGE) {
         load_next();
         for (int it = 0; it < p.n_iters; ++it) {
             if (it) __syncthreads();                    // everyone done reading the single stage
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
                 if (it + 1 < p.n_iters) park((it + 1) & 1);
                 if (it + 2 < p.n_iters) load_next();
             }
-            mma_step(smem + (it & 1) * STAGE_BYTES);
+            mma_step(smem + (it & 1) * STAGE);
         }
     }
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -561,7 +577,7 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     if (!x || !w || !y || B < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || N <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || in_up <= 0 || Cx <= 0 || Ck <= 0 || ldy <= 0)
         return MSG_EINVAL;
-    const int split = dtype == MSG_F32_SPLIT ? 2 : (dtype == MSG_F32_SPLIT3 ? 3 : 0);   // fp32 storage, bf16 MFMA products (msg_hip.h)
+    const int split = dtype == MSG_F32_SPLIT ? 3 : 0;      // fp32 storage, bf16 MFMA products (msg_hip.h)
     if (split) dtype = MSG_F32;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz, bke = 128 / esz;
@@ -614,12 +630,8 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
         if (!dma && p.n_iters <= lean_max) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
         else if (dma) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
         else hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);
-    } else if (split == 2) {
-        if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true, 0, 2>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
-        else hipLaunchKernelGGL((conv_fprop_kernel<float, false, 0, 2>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
-    } else if (split == 3) {
-        if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true, 0, 3>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
-        else hipLaunchKernelGGL((conv_fprop_kernel<float, false, 0, 3>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
+    } else if (split == 3) {       // (register staging whatever the K length: the planes are written from the staging registers)
+        hipLaunchKernelGGL((conv_fprop_kernel<float, false, 0, 3>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
     } else {
         if (dma) hipLaunchKernelGGL((conv_fprop_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);
         else hipLaunchKernelGGL((conv_fprop_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, bias, p);

@@ -62,8 +62,31 @@ template <typename T> __device__ __forceinline__ int wg_off(int r, int ch) {
 // per K-step that the generic incremental addressing costs (the kernel was VALU-bound: 12 VALU per MFMA).
 constexpr int BUF_OOB = (int)0x80000000;             // voffset >= num_records: the buffer load returns 0
 
-// SPLIT (T = float, MSG_F32_SPLIT): products as three bf16 MFMAs on (hi, lo) splits of the staged fp32 operands, see
-// conv_fprop.hip / msg_hip.h.
+// SPLIT = 3 (T = float; MSG_F32_SPLIT): products as bf16 MFMAs on splits of the fp32 operands, see
+// conv_fprop.hip / msg_hip.h.  As there, the split happens once per element on the way from the staging registers into LDS:
+// the K-step's image is SPLIT bf16 planes per operand, each laid out exactly like the bf16 kernel's [pixel][channel] tile
+// (256-byte rows, 64-byte rotation), so the fragments come from the same transposing reads.
+// four floats -> SPLIT x (four bf16 = 8 bytes), plane p at dst + p * plane_bytes
+template <int SPLIT>
+__device__ __forceinline__ void wg_split_park(const u32x4& raw, char* dst, int plane_bytes) {
+    uint2 pl[3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float x0 = __uint_as_float(raw[2 * h]), x1 = __uint_as_float(raw[2 * h + 1]);
+        const unsigned hp = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
+        const unsigned mp = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+        (h ? pl[0].y : pl[0].x) = hp;
+        (h ? pl[1].y : pl[1].x) = mp;
+        if constexpr (SPLIT == 3) {
+            const float q0 = r0 - __uint_as_float(mp << 16), q1 = r1 - __uint_as_float(mp & 0xffff0000u);
+            (h ? pl[2].y : pl[2].x) = (unsigned)f2bf(q0) | ((unsigned)f2bf(q1) << 16);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(dst + p * plane_bytes) = pl[p];
+}
+
 template <typename T, bool DMA, bool UNI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                             float* __restrict__ gw, float* __restrict__ ws, WgradParams p) {
@@ -73,7 +96,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     constexpr int CPR = ROW / 16;                    // 16-B chunks per pixel row: 16 (bf16) / 32 (f32)
     constexpr int TILE = KP * ROW;                   // 16 KiB
     constexpr int NLD = TILE / 16 / 256;             // 16-B loads per thread per operand: 4
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+    static_assert(SPLIT == 0 || (sizeof(T) == 4 && !DMA), "split planes: fp32 storage, written from the staging registers");
+    constexpr int PROW = 256, PTILE = KP * PROW;     // SPLIT: one bf16 plane of one operand (KP pixel rows x 128 channels): 8 KiB
+    constexpr int SSTAGE = SPLIT ? 2 * SPLIT * PTILE : 2 * TILE;   // bytes per stage (both operands)
+    // (SPLIT = 3: ONE stage of 48 KiB and two barriers per K-step -- two stages would leave one workgroup per CU)
+    constexpr bool ONE_STAGE = SPLIT == 3;
+    __shared__ __attribute__((aligned(16))) char smem[(ONE_STAGE ? 1 : 2) * SSTAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -244,6 +272,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
         }
     };
     auto park = [&](int stage) __attribute__((always_inline)) {
+        if constexpr (SPLIT != 0) {
+            char* st = smem + stage * SSTAGE;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int r = r0 + RSTEP * j;              // channels 4 ch .. 4 ch + 3 of pixel row r -> 8 bytes per plane
+                const int off = r * PROW + ((ch * 8 + ((r & 3) << 6)) & (PROW - 1));
+                wg_split_park<SPLIT>(ra[j], st + off, PTILE);
+                wg_split_park<SPLIT>(rb[j], st + SPLIT * PTILE + off, PTILE);
+            }
+            return;
+        }
         char* sa = smem + stage * 2 * TILE;
         char* sb = sa + TILE;
 #pragma unroll
@@ -257,6 +296,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
         if constexpr (DMA) {
             dma_stage = 0;
             load_next();
+        } else if constexpr (ONE_STAGE) {
+            load_next();
         } else {
             load_next();
             park(0);
@@ -265,15 +306,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     }
     for (int it = 0; it < n_iters; ++it) {
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA of step `it` has landed
-        __syncthreads();
-        if constexpr (DMA) {
-            if (it + 1 < n_iters) { dma_stage = (it + 1) & 1; load_next(); }
+        if constexpr (ONE_STAGE) {
+            if (it) __syncthreads();                        // everyone done reading the single stage
+            park(0);
+            if (it + 1 < n_iters) load_next();              // flies under the MFMAs below
+            __syncthreads();
         } else {
-            if (it + 1 < n_iters) park((it + 1) & 1);
-            if (it + 2 < n_iters) load_next();
+            __syncthreads();
+            if constexpr (DMA) {
+                if (it + 1 < n_iters) { dma_stage = (it + 1) & 1; load_next(); }
+            } else {
+                if (it + 1 < n_iters) park((it + 1) & 1);
+                if (it + 2 < n_iters) load_next();
+            }
         }
         {
-            const char* sa = smem + (it & 1) * 2 * TILE;
+            const char* sa = smem + (ONE_STAGE ? 0 : (it & 1) * SSTAGE);
             const char* sb = sa + TILE;
             if constexpr (sizeof(T) == 2) {
                 // transposed fragment: lane = 16 g + 4 q + pq supplies the address of pixel row (kb + q), channels
@@ -320,55 +368,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
                 __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // step 3
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             } else if constexpr (SPLIT != 0) {
-                // k-steps of 16 pixels: lane (lr, lh) gathers channel lr of the 8 pixel rows 16 ks + 8 lh + e of each operand
-                // block (the tile is [pixel][channel]: a transposed read, one float per row), splits them into bf16 hi / lo
-                // and the 2 x 2 blocks take three MFMAs each
-                const int lr = lane & 31, lh = lane >> 5;
-                typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
-                auto frag = [&](const char* base, int ks, int col, bf16v8& hi, bf16v8& lo, bf16v8& lo3) __attribute__((always_inline)) {
-                    float v[8];
+                // SPLIT bf16 planes per operand, each a [KP][128] bf16 tile: the bf16 kernel's transposing fragment reads
+                const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+                const int kb = 8 * (g >> 1), cb = 16 * (g & 1);
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                auto frag = [&](const char* base, int ks, int col0) __attribute__((always_inline)) {
+                    s16x4 part[2];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int r = ks * 16 + 8 * lh + e;
-                        v[e] = *reinterpret_cast<const float*>(base + r * ROW + ((col * 4 + ((r & 3) << 6)) & (ROW - 1)));
+                    for (int half = 0; half < 2; ++half) {
+                        const int r = ks * 16 + kb + 4 * half + q;
+                        const char* pa = base + r * PROW + (((col0 + cb + 4 * pq) * 2 + ((r & 3) << 6)) & (PROW - 1));
+                        part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
                     }
-                    u32v4 h, l, l3 = {0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned hp = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
-                        const float r0 = v[2 * e] - __uint_as_float(hp << 16), r1 = v[2 * e + 1] - __uint_as_float(hp & 0xffff0000u);
-                        const unsigned mp = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
-                        h[e] = hp;
-                        l[e] = mp;
-                        if constexpr (SPLIT == 3) {
-                            const float q0 = r0 - __uint_as_float(mp << 16), q1 = r1 - __uint_as_float(mp & 0xffff0000u);
-                            l3[e] = (unsigned)f2bf(q0) | ((unsigned)f2bf(q1) << 16);
-                        }
-                    }
-                    hi = __builtin_bit_cast(bf16v8, h);
-                    lo = __builtin_bit_cast(bf16v8, l);
-                    lo3 = __builtin_bit_cast(bf16v8, l3);
+                    return __builtin_bit_cast(bf16v8, (s16x8)__builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7));
                 };
+                const char* sbp = sa + SPLIT * PTILE;
 #pragma unroll
                 for (int ks = 0; ks < KP / 16; ++ks) {
-                    bf16v8 ah[2], al[2], bh[2], bl[2], a3[2], b3[2];
+                    bf16v8 af[SPLIT][2], bfr[SPLIT][2];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        frag(sa, ks, wm * 64 + t * 32 + lr, ah[t], al[t], a3[t]);
-                        frag(sb, ks, wn * 64 + t * 32 + lr, bh[t], bl[t], b3[t]);
-                    }
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int pl = 0; pl < SPLIT; ++pl) {
+                            af[pl][t] = frag(sa + pl * PTILE, ks, wm * 64 + t * 32);
+                            bfr[pl][t] = frag(sbp + pl * PTILE, ks, wn * 64 + t * 32);
+                        }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            if constexpr (SPLIT == 3) {              // (hi, mid, lo): the 2^-16 terms
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i], bh[j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], b3[j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bl[j], acc[i][j], 0, 0, 0);
-                            }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // (small terms first)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                            // small terms first: plane sums 2 (2^-16 of the leading product), 1 (2^-8), then hi hi
+#pragma unroll
+                            for (int order = SPLIT - 1; order >= 0; --order)
+#pragma unroll
+                                for (int pa_ = 0; pa_ <= order; ++pa_)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa_][i], bfr[order - pa_][j], acc[i][j], 0, 0, 0);
                         }
                 }
             } else {
@@ -492,7 +526,7 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
         kw <= 0 || stride <= 0 || Cx <= 0 || ldgy <= 0 || ldgw < I || ldgw % 4 || k_chunks <= 0)
         return MSG_EINVAL;
     if (!plan_only && (!gy || !x || !gw)) return MSG_EINVAL;
-    const int split = dtype == MSG_F32_SPLIT ? 2 : (dtype == MSG_F32_SPLIT3 ? 3 : 0);   // fp32 storage, bf16 MFMA products (msg_hip.h)
+    const int split = dtype == MSG_F32_SPLIT ? 3 : 0;      // fp32 storage, bf16 MFMA products (msg_hip.h)
     if (split) dtype = MSG_F32;
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     const int esz = dtype == MSG_BF16 ? 2 : 4, vec = 16 / esz;
@@ -590,13 +624,8 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
         if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
         else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false, false>), grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
-    } else if (split == 2) {
-        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false, 2>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
-        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true, 2>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<float, false, false, 2>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
     } else if (split == 3) {
-        if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false, 3>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
-        else if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true, 3>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
+        if (uni) hipLaunchKernelGGL((conv_wgrad_kernel<float, false, true, 3>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<float, false, false, 3>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);
     } else {
         if (dma) hipLaunchKernelGGL((conv_wgrad_kernel<float, true, false>), grid, dim3(256), 0, s, (const float*)gy, (const float*)x, gw, ws, p);

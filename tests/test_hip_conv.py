@@ -91,15 +91,14 @@ def test_conv_primitives(case, per_sample, dtype):
     assert rel_err(ggx.float(), ggx_r) < tol, "d(wgrad)/dx"
 
 
-@pytest.mark.parametrize("mode,tol", [("split_bf16", 1e-4), ("split_bf16x3", 2e-6)])
 @pytest.mark.parametrize("per_sample", [False, True])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_conv_primitives_split_bf16_products(case, per_sample, mode, tol):
-    """The fp32-storage contractions with MSG_F32_SPLIT / MSG_F32_SPLIT3 (conv_ops.fp32_contraction): every product as three
-    (six) bf16 MFMA products on (hi, lo) / (hi, mid, lo) splits, fp32 accumulation.  Forward, data gradient, weight gradient and the two
-    second-order contractions on operands with FULL fp32 mantissas against the fp64 reference: within 1e-4 of max|ref| (the
-    tolerance of the exact-fp32 kernels; a plain bf16 product of these operands is off by 4e-3), and measurably not the
-    exact kernel (the mode really ran)."""
+def test_conv_primitives_split_bf16_products(case, per_sample, mode="split_bf16x3", tol=2e-6):
+    """The fp32-storage contractions with MSG_F32_SPLIT (conv_ops.fp32_contraction("split_bf16x3")): every product as six bf16
+    MFMA products on (hi, mid, lo) splits, fp32 accumulation.  Forward, data gradient, weight gradient and the two
+    second-order contractions on operands with FULL fp32 mantissas against the fp64 reference: at the exact-fp32 kernel's own
+    error (2e-6 of max|ref|, or twice the exact kernel's; a plain bf16 product of these operands is off by 4e-3), and
+    measurably not the exact kernel (the mode really ran)."""
     from multi_stylegan_amd import conv_ops
     name, kind, b, i, o, h, w_, k, stride, pad = case
     g = torch.Generator().manual_seed(len(name) * 11 + b)

@@ -3,7 +3,7 @@
 
     cd /tmp && rocprofv3 --kernel-trace --stats -d <out> -- python3 $GRAFT_REPO_ROOT/tools/fp32_path_profile.py split_bf16x3
 
-argument: exact | split_bf16 | split_bf16x3 (conv_ops.fp32_contraction); 256^2, batch 16, 1 warm-up + 3 timed plain iterations."""
+argument: exact | split_bf16x3 (conv_ops.fp32_contraction); 256^2, batch 16, 1 warm-up + 3 timed plain iterations."""
 import os
 import sys
 import time

@@ -7,12 +7,15 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_stylegan_amd import _lib, conv_ops
-b, i, o, r, k = 16, 512, 512, 256, 3
+# ROW3_STAMPS_SHAPE="batch,in,out,resolution,per_sample" (default: the 512 -> 512 @256^2 per-sample launch of the 256 x 256 tile;
+# "32,128,128,256,0" is the discriminator's 128 -> 128 @256^2 layer on the 128 x 128 tile: 512 MFMA cycles per K-step there)
+b, i, o, r, ps = (int(v) for v in os.environ.get("ROW3_STAMPS_SHAPE", "16,512,512,256,1").split(","))
+k = 3
 x = torch.randn(b, i, r, r, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-w = torch.randn(b, o, i, k, k, device="cuda") / math.sqrt(i * k * k)
+w = torch.randn((b, o, i, k, k) if ps else (o, i, k, k), device="cuda") / math.sqrt(i * k * k)
 wk, ck = conv_ops._relay_fwd(w, torch.bfloat16)
 for _ in range(200):          # long enough for the clock to settle
-    y = conv_ops._launch_fprop(x, wk, ck, None, o, (r, r), k, k, 1, 1, 1, False, True, i)
+    y = conv_ops._launch_fprop(x, wk, ck, None, o, (r, r), k, k, 1, 1, 1, False, bool(ps), i)
 torch.cuda.synchronize()
 h = ctypes.CDLL(_lib.LIB_PATH)
 buf = np.zeros(256 * 4 * 3 * 8, dtype=np.uint64)

@@ -29,8 +29,8 @@ def short(name):
     return re.sub(r"\(.*", "", name)[:110]
 
 
-KEYS = [("conv_fprop_row3_kernel<4, 4", "conv_fprop_row3/bf16"), ("conv_fprop_row3_kernel<2, 2", "conv_fprop_row3n/bf16"), ("conv_fprop_pp_kernel", "conv_fprop_pp/bf16"), ("conv_fprop_kernel<unsigned short, true>", "conv_fprop_dma/bf16"),
-        ("conv_fprop_kernel<unsigned short, false>", "conv_fprop_reg/bf16"),
+KEYS = [("conv_fprop_row3_kernel<4, 4", "conv_fprop_row3/bf16"), ("conv_fprop_row3_kernel<2, 2", "conv_fprop_row3n/bf16"), ("conv_fprop_pp_kernel", "conv_fprop_pp/bf16"), ("conv_fprop_kernel<unsigned short, true", "conv_fprop_dma/bf16"),
+        ("conv_fprop_kernel<unsigned short, false", "conv_fprop_reg/bf16"),
         ("conv_wgrad_row3_kernel", "conv_wgrad_row3/bf16"),
         ("conv_wgrad_kernel<unsigned short", "conv_wgrad/bf16"),
         ("nl_attn_fwd_kernel<unsigned short", "nl_attention_fwd/bf16"),
@@ -39,8 +39,11 @@ KEYS = [("conv_fprop_row3_kernel<4, 4", "conv_fprop_row3/bf16"), ("conv_fprop_ro
         ("mbstd_fwd_kernel<unsigned short", "mbstd_fwd/bf16"),
         ("mbstd_bwd_kernel<unsigned short", "mbstd_bwd/bf16"),
         ("upfirdn2d_vec_kernel<unsigned short, 1, 1", "upfirdn2d/bf16/up1down1/vec"),
+        ("blur_sep_kernel<unsigned short, 32, 3, true>", "upfirdn2d/bf16/up1down1/sep+act"),
+        ("blur_sep_kernel<unsigned short, 16, 3, true>", "upfirdn2d/bf16/up1down1/sep+act"),
         ("blur_sep_kernel<unsigned short, 32, 4, true>", "upfirdn2d/bf16/up1down1/sep+act"),
         ("blur_sep_kernel<unsigned short, 16, 4, true>", "upfirdn2d/bf16/up1down1/sep+act"),
+        ("rgb_skip_fwd_kernel", "rgb_skip_merge/f32"), ("rgb_skip_bwd_kernel", "rgb_skip_merge_bwd/f32"),
         ("blur_sep_kernel<unsigned short", "upfirdn2d/bf16/up1down1/sep"),
         ("bias_act_vec_kernel<unsigned short", "bias_act_fwd/torch.bfloat16"),
         ("bias_act_bwd_cl_kernel<unsigned short", "bias_act_bwd/torch.bfloat16")]

@@ -71,7 +71,14 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
 #else
     constexpr bool STAGGER = true;        // (the 128 x 128 tile too: +1..2 %)
 #endif
-    __shared__ __attribute__((aligned(16))) char smem[2 * HA + 2 * HB];
+    // (+ HM noise values and HN bias values of the fused activation stage, fetched at kernel START into LDS the K loop
+    //  does not use: with one workgroup per CU nothing overlaps the epilogue, and its dependent global loads -- bias vector and
+    //  per-pixel noise, twice per tile -- sat in front of every half patch with their full latency; tools/layer_probe.py:
+    //  the fused stage cost 330 us of a 3 300 us launch)
+    constexpr int EP_OFF = 2 * HA + 2 * HB;
+    __shared__ __attribute__((aligned(16))) char smem[EP_OFF + (HM + HN) * 4];
+    float* const ep_noise = reinterpret_cast<float*>(smem + EP_OFF);
+    float* const ep_bias = ep_noise + HM;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wid_u = __builtin_amdgcn_readfirstlane(wid);
@@ -89,6 +96,19 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     const int bz = blockIdx.z;
     const int ohw = p.OH * p.OW;
     const int seg = p.seg_len;
+    if (p.act.enabled == 1) {
+        const bool want_noise = p.act.noise != nullptr;
+        const float nw = want_noise ? p.act.noise_w[0] : 0.f;
+        for (int t = tid; t < HM; t += 256) {
+            const int m = m0 + t;
+            const bool ok = want_noise && m < p.Mtot;
+            const int mm = ok ? m : 0;
+            const int b = p.per_sample ? bz : mm / ohw;
+            const int pix = p.per_sample ? mm : mm - b * ohw;
+            ep_noise[t] = ok ? nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix] : 0.f;
+        }
+        for (int t = tid; t < HN; t += 256) ep_bias[t] = (p.act.bias && n0 + t < p.N) ? p.act.bias[n0 + t] : 0.f;
+    }
 
     // ---- staging (LDS-DMA through buffer loads): one wave-instruction fills 1 KiB = 8 consecutive rows in lane order.
     // Weights: wave w moves rows 64 w + 8 j + (lane >> 3), j = 0..7, of every K-step.  Activations: the same rows of the
@@ -424,18 +444,16 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             int b = p.per_sample ? bz : m_first / ohw;
             const int pix0 = p.per_sample ? m_first : m_first - b * ohw;
             int oh = pix0 / p.OW, ow = pix0 - oh * p.OW;
-            const bool want_noise = p.act.enabled == 1 && p.act.noise;
-            const float nw = want_noise ? p.act.noise_w[0] : 0.f;
             if (p.act.enabled == 1) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) a_bias[e] = (p.act.bias && n + e < p.N) ? p.act.bias[n + e] : 0.f;
+                for (int e = 0; e < VEC; ++e) a_bias[e] = ep_bias[wn * WN + ec + e];
             }
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 const bool ok = m0 + wm * WM + half * 64 + pass * RPP + er < p.Mtot;
                 const int pix = oh * p.OW + ow;
                 gp[pass] = ok ? b * ohw + pix : -1;
-                a_noise[pass] = (want_noise && ok) ? nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix] : 0.f;
+                a_noise[pass] = p.act.enabled == 1 ? ep_noise[wm * WM + half * 64 + pass * RPP + er] : 0.f;
                 ow += RPP;
                 while (ow >= p.OW) { ow -= p.OW; ++oh; }
                 if (!p.per_sample) while (oh >= p.OH) { oh -= p.OH; ++b; }

@@ -50,3 +50,17 @@ with torch.no_grad():
         run("alternating with 3 blurs (~1.4 ms of HBM-bound work)", lambda: [upfirdn2d(xb, fir, pad=(1, 1)) for _ in range(3)])
         run("rotating over 3 inputs / weight sets (3.4 GB: nothing warm)", lambda: None, rotate=True)
         run("rotating operands + a blur in between", lambda: upfirdn2d(xb, fir, pad=(1, 1)), rotate=True)
+
+# (e) sustained: the same launch back to back for ~20 s, rate per block of 300 launches -- does the burst rate hold once the
+# chip has been at full load for as long as a benchmark run lasts?
+if os.environ.get("INSTEP_SUSTAINED", "1") != "0":
+    with torch.no_grad():
+        for block in range(20):
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(300):
+                conv(0)
+            e.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(e) * 1e-3 / 300
+            print(f"sustained block {block:2d} ({(block + 1) * 300 * t:5.1f} s in): {t * 1e6:8.1f} us  {flops / t / 1e12:7.1f} TFLOP/s", flush=True)

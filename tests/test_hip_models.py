@@ -668,6 +668,65 @@ def test_path_length_double_backward_512_channels_matches_oracle():
         assert max(e_g.values()) < tol_grad, (dt, e_g)
 
 
+def test_config2_r1_double_backward_matches_oracle():
+    """The lazy R1 step of BASELINE config 2's discriminator at its own size (256 x 256 inputs, the 4096 x 1024 non-local
+    attention, minibatch statistics) against the CPU oracle: D(real) -> gradient of both outputs' sums with respect to the
+    images (create_graph) -> 0.5 * mean |grad|^2 -> backward (reference loss.py:283-317, model_wrapper.py:307-329).  The
+    golden fixtures hold this double backward for the 8..48-channel discriminator only; here the second-order graph runs
+    through the row-sharing 3x3 kernels' data gradients, the fused attention's composite, the stride-2 parity form and the
+    in-place concatenations at the benchmark's shapes.  Batch 2; fp32 storage 1e-3 (value) / 2e-3 (gradients) of max|ref|
+    (measured 3.5e-6 / <= 4.1e-4).  bf16 storage (the benchmarked path): value 5e-2 (measured 4.3e-2), gradients 0.3 NORM-WISE
+    -- measured 6e-2 .. 2.5e-1: the gradient of |d D / d image|^2 passes twice through every layer of the U-Net, and the 8-bit
+    mantissa of every stored map is squared on the way; the fp32 path runs the same graph on the same kernels' fp32
+    instantiations, so this is rounding, not logic -- five times the path-length pass's bf16 error (1e-2 .. 5e-2)."""
+    import time
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd import loss as product_loss
+    from oracle import models as om, train as ot
+    torch.manual_seed(71)
+    bsz = 2
+    do = om.Discriminator(no_rfp=True)
+    gen_cpu = torch.Generator().manual_seed(72)
+    _perturb_zero_inits([do], gen_cpu)
+    real = torch.rand(bsz, 2, 3, 256, 256, generator=gen_cpu)
+    watch = ["encoder_blocks.0.main_mapping.0.weight", "encoder_blocks.0.residual_mapping.weight",
+             "encoder_blocks.1.main_mapping.2.weight", "encoder_blocks.2.theta.weight", "encoder_blocks.2.g.weight",
+             "encoder_blocks.2.gamma", "downscale_convolutions.1.0.weight", "encoder_blocks.4.main_mapping.0.weight",
+             "decoder_blocks.1.o.weight", "decoder_blocks.3.main_mapping.2.weight", "transposed_convolutions.3.1.weight",
+             "final_mapping.1.weight", "classification_head.2.weight"]
+    t0 = time.time()
+    x = real.clone().requires_grad_(True)
+    ws, wp = do(x)
+    want_r1 = ot.r1_penalty(ws, x, wp)
+    want_r1.backward()
+    oparams = dict(do.named_parameters())
+    want_grads = {n: oparams[n].grad.clone() for n in watch}
+    want_r1 = want_r1.detach()
+    do.zero_grad(set_to_none=True)
+    print(f"oracle on the CPU: {time.time() - t0:.1f} s")
+    dd = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    dd.load_state_dict(do.state_dict())
+    dd.to(DEV)
+    for dt, tol, tol_grad in ((torch.float32, 1e-3, 2e-3), (torch.bfloat16, 5e-2, 0.3)):
+        dd.compute_dtype = dt
+        dd.zero_grad(set_to_none=True)
+        xd = real.to(DEV).requires_grad_(True)
+        s, px = dd(xd)
+        r1 = product_loss.R1Regularization()(s, xd, px)
+        r1.backward()
+        params = dict(dd.named_parameters())
+        if dt == torch.float32:
+            e_g = {n: rel_err(params[n].grad, want_grads[n]) for n in watch}
+        else:
+            e_g = {n: ((params[n].grad.cpu().float() - want_grads[n]).norm() / want_grads[n].norm()).item() for n in watch}
+        e_r1 = rel_err(r1, want_r1)
+        print(f"{dt}: R1 {e_r1:.2e}  second-order grads " + " ".join(f"{v:.1e}" for v in e_g.values()))
+        assert e_r1 < tol, (dt, e_r1)
+        assert max(e_g.values()) < tol_grad, (dt, e_g)
+        del s, px, r1, xd
+        torch.cuda.empty_cache()
+
+
 def test_config4_512px_matches_oracle():
     """BASELINE config 4's models -- 512x512, 8 x 512 channels in G, the discriminator on 512^2 inputs with its
     16384 x 4096 non-local attention (fused kernels) -- against the CPU oracle with the same weights, z and noise:

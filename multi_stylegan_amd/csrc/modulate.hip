@@ -233,6 +233,10 @@ extern "C" int msg_scale_rows_cols2(const float* base, const float* row1, const 
 //   out[b][r][t][c] = scale * d[b][r % O] * base[r][t][c] * s[b][c]
 // Same tiling as scale_rows_cols (row r, group of BG samples); the BG coefficients of the row come from one block
 // reduction over the input channels.  Replaces msg_demod_coeff (which re-read all of W per call) + msg_scale_rows_cols.
+// A workgroup takes ALL rows that share its output channel -- r = o, o + O, ... (the four sub-pixel rows of the 2x2
+// transposed conv, R = 4 O with one tap each): one reduction for them instead of four, and 4 x BG KiB per workgroup instead
+// of BG (round 4, tools/modw_probe.py: the up-conv's weight set 29.6 us for 33.6 MB = 1.3 TB/s with one 1-KiB row per
+// workgroup and sample).
 template <typename TO>
 __global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __restrict__ base, const float* __restrict__ wsq,
                                                                const float* __restrict__ style, TO* __restrict__ out,
@@ -242,8 +246,7 @@ __global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __re
     constexpr int VEC = V::N;
     __shared__ float red[4 * 8];
     __shared__ float dsh[8];
-    const int r = blockIdx.x, b0 = blockIdx.y * BG, b1 = min(B, b0 + BG);
-    const int o = r % O;
+    const int o = blockIdx.x, b0 = blockIdx.y * BG, b1 = min(B, b0 + BG);
     // ---- demodulation coefficients of this row for the BG samples
     {
         float part[8];
@@ -266,23 +269,29 @@ __global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __re
             const float tot = red[k] + red[8 + k] + red[16 + k] + red[24 + k];
             const float dv = rsqrtf(scale * scale * tot + eps);
             dsh[k] = dv;
-            if (d_out && r < O) d_out[(size_t)(b0 + k) * O + r] = dv;
+            if (d_out) d_out[(size_t)(b0 + k) * O + o] = dv;
         }
         __syncthreads();
     }
     const int cvecs = Ck / VEC;
-    const float* src_row = base + (size_t)r * T * C;
     const int tstep = 256 / cvecs > 0 ? 256 / cvecs : 1;
     const bool al = (C % 4 == 0) && ((((uintptr_t)base | (uintptr_t)style) & 15u) == 0);   // float4-loadable runs
+    // cells of this workgroup: (row, tap) pairs q = (r - o) / O * T + t of the rows that share output channel o, times the
+    // row's 16-byte column vectors; a thread keeps one column vector (its style values are loaded once per sample) and walks
+    // the pairs -- with one tap per row (the up-conv) the four sub-pixel rows fill the 256 threads that a single row left 3/4 idle
+    const int npairs = (R / O) * T;
     for (int cv = threadIdx.x % cvecs; cv < cvecs; cv += 256) {
         const int c0 = cv * VEC;
         const int t0 = threadIdx.x / cvecs;
-        for (int tb = t0; tb < T; tb += tstep * SRC_ITEMS) {
+        for (int qb = t0; qb < npairs; qb += tstep * SRC_ITEMS) {
             float f[SRC_ITEMS][VEC];
+            size_t cell[SRC_ITEMS];                                   // (row * T + tap) of item k
 #pragma unroll
             for (int k = 0; k < SRC_ITEMS; ++k) {
-                const int t = tb + k * tstep;
-                if (t < T) load_run<VEC>(src_row + (size_t)t * C, c0, C, al, f[k]);
+                const int q = qb + k * tstep;
+                const int rk = q / T, t = q - rk * T;
+                cell[k] = (size_t)(o + rk * O) * T + t;
+                if (q < npairs) load_run<VEC>(base + cell[k] * C, c0, C, al, f[k]);
                 else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[k][e] = 0.f;
@@ -294,11 +303,10 @@ __global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __re
                 load_run<VEC>(style + (size_t)b * C, c0, C, al, sc);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) sc[e] *= rs;
-                TO* dst_row = out + ((size_t)b * R + r) * T * Ck;
+                TO* dst_b = out + (size_t)b * R * T * Ck;
 #pragma unroll
                 for (int k = 0; k < SRC_ITEMS; ++k) {
-                    const int t = tb + k * tstep;
-                    if (t >= T) break;
+                    if (qb + k * tstep >= npairs) break;
                     V ov;
                     if constexpr (VEC == 4) {
 #pragma unroll
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) void modulate_weights_kernel(const float* __re
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov.set2(e, f[k][2 * e] * sc[2 * e], f[k][2 * e + 1] * sc[2 * e + 1]);
                     }
-                    *reinterpret_cast<uint4*>(dst_row + (size_t)t * Ck + c0) = ov.raw;
+                    *reinterpret_cast<uint4*>(dst_b + cell[k] * Ck + c0) = ov.raw;
                 }
             }
         }
@@ -323,9 +331,12 @@ extern "C" int msg_modulate_weights(const float* base, const float* wsq, const f
     const int vec = dtype == MSG_BF16 ? 8 : 4;
     if (Ck % vec || ((uintptr_t)out & 15u) || B > 65535) return MSG_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    // samples per workgroup double while the grid keeps this many workgroups (round 4: 1024, not 2048 -- 25.4 -> 22.7 us on
+    // 512 x 9 x 512 at batch 16: fewer, larger workgroups amortise the reduction's two barriers better)
+    static const int min_wgs = msg_tunable("MSG_MODW_MIN_WGS", 1024);
     int bg = 1;
-    while (bg < 8 && bg * 2 <= B && (long long)R * ((B + 2 * bg - 1) / (2 * bg)) >= 2048) bg *= 2;
-    dim3 grid(R, (B + bg - 1) / bg);
+    while (bg < 8 && bg * 2 <= B && (long long)O * ((B + 2 * bg - 1) / (2 * bg)) >= min_wgs) bg *= 2;
+    dim3 grid(O, (B + bg - 1) / bg);
     if (dtype == MSG_BF16)
         hipLaunchKernelGGL((modulate_weights_kernel<bf16_t>), grid, dim3(256), 0, s, base, wsq, style, (bf16_t*)out, d_out,
                            B, bg, R, O, T, C, Ck, scale, eps);

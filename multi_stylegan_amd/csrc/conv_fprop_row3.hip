@@ -33,6 +33,8 @@ struct ConvParamsR3 {
     int per_sample, seg_len, n_seg;
     long long x_bstride, w_bstride, y_bstride;     // elements
     int Mtot, n_chunks, n_iters, m_tiles, n_tiles;
+    int seg_magic;                 // row / (seg_len + 2) == (row * seg_magic) >> 16 for every row of the activation buffer
+    int ow_shift, ohw_shift;       // log2(OW), log2(OH * OW) when both are powers of two, else -1 (generic divisions)
     ActEpilogue act;
 };
 
@@ -49,8 +51,20 @@ __device__ unsigned long long g_row3_stamps[256 * 4 * 3 * 8];
 extern "C" int msg_row3_debug_read(void* host_dst, int nbytes) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_row3_stamps), nbytes) == hipSuccess ? 0 : -1;
 }
+// in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles (s_memtime) and the 100 MHz reference counter
+// (s_memrealtime) at kernel entry (0), at the start (1) and the end (2) of the K loop and at kernel exit (3) of every wave
+__device__ unsigned long long g_row3_clock[256 * 4 * 8];
+// (the LAST 256 workgroups of the last sample: the clock the chip holds deep into the launch, not the boost of its first tiles)
+#define R3_CLOCK(k) do { if (L + 256 >= gridDim.x && blockIdx.z == gridDim.z - 1 && lane == 0) { unsigned long long tc, tr; \
+    const unsigned cl_ = L + 256 - gridDim.x; \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc), "=s"(tr) :: "memory"); \
+    g_row3_clock[(cl_ * 4 + wid_u) * 8 + 2 * (k)] = tc; g_row3_clock[(cl_ * 4 + wid_u) * 8 + 2 * (k) + 1] = tr; } } while (0)
+extern "C" int msg_row3_clock_read(void* host_dst, int nbytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_row3_clock), nbytes) == hipSuccess ? 0 : -1;
+}
 #else
 #define R3_STAMP(k) do {} while (0)
+#define R3_CLOCK(k) do {} while (0)
 #endif
 
 // MI / NCOLB = 32-row / 32-column blocks per wave (waves are 2 x 2): <4,4> the 256 x 256 tile with 128 x 128 wave tiles, one
@@ -96,6 +110,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     const int bz = blockIdx.z;
     const int ohw = p.OH * p.OW;
     const int seg = p.seg_len;
+    R3_CLOCK(0);
     if (p.act.enabled == 1) {
         const bool want_noise = p.act.noise != nullptr;
         const float nw = want_noise ? p.act.noise_w[0] : 0.f;
@@ -103,9 +118,10 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             const int m = m0 + t;
             const bool ok = want_noise && m < p.Mtot;
             const int mm = ok ? m : 0;
-            const int b = p.per_sample ? bz : mm / ohw;
-            const int pix = p.per_sample ? mm : mm - b * ohw;
-            ep_noise[t] = ok ? nw * p.act.noise[(long long)(p.act.noise_batch == 1 ? 0 : b) * ohw + pix] : 0.f;
+            // (pixel index over the whole batch, or -- one noise map for the batch -- inside its sample)
+            long long idx = p.per_sample ? (long long)(p.act.noise_batch == 1 ? 0 : bz) * ohw + mm : (long long)mm;
+            if (!p.per_sample && p.act.noise_batch == 1) idx = p.ohw_shift >= 0 ? mm & (ohw - 1) : mm % ohw;
+            ep_noise[t] = ok ? nw * p.act.noise[idx] : 0.f;
         }
         for (int t = tid; t < HN; t += 256) ep_bias[t] = (p.act.bias && n0 + t < p.N) ? p.act.bias[n0 + t] : 0.f;
     }
@@ -127,24 +143,39 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     // term that only alternates with the parity of j.  (Eligibility: Cx a multiple of 64, N a multiple of the tile width.)
     int a_b32[NAP + 1];
     unsigned a_flags = 0;             // bit j: piece j's row is a pixel of the map; 9 + j: ... of its top row; 18 + j: ... bottom row
+    // (One wave per SIMD: every instruction of this prologue is four cycles nothing else fills -- in-kernel stamps, entry
+    //  -> K loop was 14 200 cycles of a 227 000-cycle workgroup with three generic integer divisions per piece.  The
+    //  segment comes from a multiply, and maps whose sides are powers of two -- all of the reference's -- take shifts.)
+    auto piece_offsets = [&](auto pow2_tag) __attribute__((always_inline)) {
+        constexpr bool POW2 = decltype(pow2_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NAP + 1; ++j) {
-        const int row = (j < NAP ? wid * (HM / 4) + 8 * j : HM) + (lane >> 3);    // row of the activation buffer
-        const int sl = slot_phys ^ ((row >> 1) & 7);
-        const int s = row / (seg + 2), pos = row - s * (seg + 2);                 // segment, position (0 and seg+1: halo)
-        const int inner = min(max(pos - 1, 0), seg - 1);
-        const int m = m0 + s * seg + inner;                                       // the pixel (or the halo's neighbour)
-        bool ok = (s < p.n_seg) & (m < p.Mtot) & (j < NAP || wid == 0);
-        const int mm = ok ? m : 0;
-        const int b = p.per_sample ? 0 : mm / ohw;
-        const int pix = p.per_sample ? mm : mm - b * ohw;
-        const int oh = pix / p.OW, ow = pix - oh * p.OW;
-        const int iw = ow + (pos == 0 ? -1 : (pos == seg + 1 ? 1 : 0));
-        ok = ok & ((unsigned)iw < (unsigned)p.IW);
-        a_flags |= (ok ? 1u : 0u) << j | (oh == 0 ? 1u : 0u) << (9 + j) | (oh == p.IH - 1 ? 1u : 0u) << (18 + j);
-        // offset of kernel row 0 (may be "negative" for the top image row: only used when that row is in range)
-        a_b32[j] = (int)(((long long)b * p.x_bstride + sl * VEC) * ESZ) + ((oh - 1) * p.IW + iw) * p.Cx * ESZ;
-    }
+        for (int j = 0; j < NAP + 1; ++j) {
+            const int row = (j < NAP ? wid * (HM / 4) + 8 * j : HM) + (lane >> 3);    // row of the activation buffer
+            const int sl = slot_phys ^ ((row >> 1) & 7);
+            const int s = (row * p.seg_magic) >> 16, pos = row - s * (seg + 2);       // segment, position (0 and seg+1: halo)
+            const int inner = min(max(pos - 1, 0), seg - 1);
+            const int m = m0 + s * seg + inner;                                       // the pixel (or the halo's neighbour)
+            bool ok = (s < p.n_seg) & (m < p.Mtot) & (j < NAP || wid == 0);
+            const int mm = ok ? m : 0;
+            int b, pix, oh, ow;
+            if (POW2) {
+                b = p.per_sample ? 0 : mm >> p.ohw_shift;
+                pix = p.per_sample ? mm : mm & (ohw - 1);
+                oh = pix >> p.ow_shift, ow = pix & (p.OW - 1);
+            } else {
+                b = p.per_sample ? 0 : mm / ohw;
+                pix = p.per_sample ? mm : mm - b * ohw;
+                oh = pix / p.OW, ow = pix - oh * p.OW;
+            }
+            const int iw = ow + (pos == 0 ? -1 : (pos == seg + 1 ? 1 : 0));
+            ok = ok & ((unsigned)iw < (unsigned)p.IW);
+            a_flags |= (ok ? 1u : 0u) << j | (oh == 0 ? 1u : 0u) << (9 + j) | (oh == p.IH - 1 ? 1u : 0u) << (18 + j);
+            // offset of kernel row 0 (may be "negative" for the top image row: only used when that row is in range)
+            a_b32[j] = (int)(((long long)b * p.x_bstride + sl * VEC) * ESZ) + ((oh - 1) * p.IW + iw) * p.Cx * ESZ;
+        }
+    };
+    if (p.ow_shift >= 0) piece_offsets(std::true_type{});
+    else piece_offsets(std::false_type{});
     static_assert(NAP + 1 <= 9, "flag bits");
     int vb2[2];                                                                   // weight offsets of pieces 0 and 1
 #pragma unroll
@@ -379,11 +410,13 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             }
             if (KW == 2) { kh = kh_l; chunk = chunk_l; }
         };
+        R3_CLOCK(1);
         for (int it = 0; it < p.n_iters; it += 3) {                 // (n_iters = 9 * n_chunks)
             k_step(std::integral_constant<int, 0>{}, it);
             k_step(std::integral_constant<int, 1>{}, it + 1);
             k_step(std::integral_constant<int, 2>{}, it + 2);
         }
+        R3_CLOCK(2);
     };
     if (STAGGER) {
         switch (wid_u) {
@@ -415,7 +448,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             if (bias) {
                 const int nb = n0 + wn * WN + 4 * unit;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = nb + e < p.N ? bias[nb + e] : 0.f;
+                for (int e = 0; e < 4; ++e) bv[e] = bias[nb + e];              // (N % HN == 0: eligibility)
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -431,33 +464,19 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     constexpr int NP = 64 / RPP;                                // passes per half patch (64 rows): 16 / 8
     const int er = lane / LPR, u16 = lane % LPR, ec = u16 * VEC;
     const int n = n0 + wn * WN + ec;
-    const bool n_ok = n < p.N;
-    const int lim = p.N - n;
-    // half-patches of 64 rows: row coordinates stepped, all rows / residual vectors of a half requested before any is
-    // used
+    // Eligibility (msg_conv2d_fprop_row3_eligible) leaves whole tiles only -- Mtot % HM == 0, N % HN == 0 -- and the output row of
+    // pixel m is row m: no bounds predicates and no coordinates here.  (One wave per SIMD: every epilogue instruction is four
+    // cycles that nothing overlaps; the stepped (b, oh, ow) coordinates and 16 predicated stores per half were a third of them.)
+    // half-patches of 64 rows: all rows / residual vectors of a half requested before any is used
 #pragma unroll 1
     for (int half = 0; half < MI / 2; ++half) {
-        int gp[NP];
+        const int m_first = m0 + wm * WM + half * 64 + er;              // this lane's first pixel of the half (inside the sample)
         float a_bias[VEC], a_noise[NP];
-        {
-            const int m_first = min(m0 + wm * WM + half * 64 + er, p.Mtot - 1);
-            int b = p.per_sample ? bz : m_first / ohw;
-            const int pix0 = p.per_sample ? m_first : m_first - b * ohw;
-            int oh = pix0 / p.OW, ow = pix0 - oh * p.OW;
-            if (p.act.enabled == 1) {
+        if (p.act.enabled == 1) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) a_bias[e] = ep_bias[wn * WN + ec + e];
-            }
+            for (int e = 0; e < VEC; ++e) a_bias[e] = ep_bias[wn * WN + ec + e];
 #pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const bool ok = m0 + wm * WM + half * 64 + pass * RPP + er < p.Mtot;
-                const int pix = oh * p.OW + ow;
-                gp[pass] = ok ? b * ohw + pix : -1;
-                a_noise[pass] = p.act.enabled == 1 ? ep_noise[wm * WM + half * 64 + pass * RPP + er] : 0.f;
-                ow += RPP;
-                while (ow >= p.OW) { ow -= p.OW; ++oh; }
-                if (!p.per_sample) while (oh >= p.OH) { oh -= p.OH; ++b; }
-            }
+            for (int pass = 0; pass < NP; ++pass) a_noise[pass] = ep_noise[wm * WM + half * 64 + pass * RPP + er];
         }
         if (half == 0) __syncthreads();
         u32x4 v[NP];
@@ -471,44 +490,38 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             for (int pass = 0; pass < NP; ++pass) v[pass] = u32x4{v[pass][2], v[pass][3], v[pass][0], v[pass][1]};
         }
         if (p.act.enabled == 1) {
+            if (p.act.alpha >= 0.f && p.act.alpha <= 1.f) {
 #pragma unroll
-            for (int pass = 0; pass < NP; ++pass) v[pass] = act_epilogue_apply<bf16_t>(v[pass], a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+                for (int pass = 0; pass < NP; ++pass)
+                    v[pass] = act_epilogue_apply<bf16_t, true>(v[pass], a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+            } else {
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass)
+                    v[pass] = act_epilogue_apply<bf16_t>(v[pass], a_bias, a_noise[pass], p.act.alpha, p.act.scale);
+            }
         } else if (p.act.enabled == 2) {
-            const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.act.residual) + (n_ok ? n : 0);
+            const bf16_t* rrow = reinterpret_cast<const bf16_t*>(p.act.residual) + n +
+                                 ((p.per_sample ? (long long)bz * ohw : 0) + m_first) * p.act.res_ld;
             u32x4 r[NP];
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass)
-                r[pass] = *reinterpret_cast<const u32x4*>(rbase + (long long)max(gp[pass], 0) * p.act.res_ld);
+                r[pass] = *reinterpret_cast<const u32x4*>(rrow + (long long)(pass * RPP) * p.act.res_ld);
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) v[pass] = residual_epilogue_apply<bf16_t>(v[pass], r[pass], p.act.res_gain);
         }
-        bf16_t* ybase = y + (p.per_sample ? (long long)bz * p.y_bstride : 0) + n;
-        if (n_ok && lim >= VEC) {
+        bf16_t* yrow = y + (p.per_sample ? (long long)bz * p.y_bstride : 0) + n + (long long)m_first * p.ldy;
 #pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const long long g = p.per_sample ? (long long)(gp[pass] - bz * ohw) : (long long)gp[pass];
-                if (gp[pass] >= 0) *reinterpret_cast<u32x4*>(ybase + g * p.ldy) = v[pass];
-            }
-            if (p.act.enabled == 1 && p.act.mask) {
-                // sign bytes for the activation's backward, in this workgroup's own block of the map (act_mask_index with
-                // tile_m = HM, tile_n = HN; N % HN == 0 and whole tiles of pixels: eligibility)
-                const long long tile = (long long)((p.per_sample ? (long long)bz * ohw : 0) + m0) / HM * p.n_tiles + n0 / HN;
-                unsigned char* mb = p.act.mask + tile * (HM * (HN / 8)) + (wn * WN + ec) / 8;
+        for (int pass = 0; pass < NP; ++pass) *reinterpret_cast<u32x4*>(yrow + (long long)(pass * RPP) * p.ldy) = v[pass];
+        if (p.act.enabled == 1 && p.act.mask) {
+            // sign bytes for the activation's backward, in this workgroup's own block of the map (act_mask_index with
+            // tile_m = HM, tile_n = HN)
+            const long long tile = (long long)((p.per_sample ? (long long)bz * ohw : 0) + m0) / HM * p.n_tiles + n0 / HN;
+            unsigned char* mb = p.act.mask + tile * (HM * (HN / 8)) + (wn * WN + ec) / 8 + (wm * WM + half * 64 + er) * (HN / 8);
 #pragma unroll
-                for (int pass = 0; pass < NP; ++pass)
-                    if (gp[pass] >= 0)
-                        mb[(wm * WM + half * 64 + pass * RPP + er) * (HN / 8)] = (unsigned char)act_sign_byte(v[pass]);
-            }
-        } else if (n_ok) {
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                if (gp[pass] < 0) continue;
-                const long long g = p.per_sample ? (long long)(gp[pass] - bz * ohw) : (long long)gp[pass];
-                bf16_t* dst = ybase + g * p.ldy;
-                for (int e = 0; e < lim; ++e) dst[e] = (bf16_t)(v[pass][e >> 1] >> (16 * (e & 1)));
-            }
+            for (int pass = 0; pass < NP; ++pass) mb[pass * RPP * (HN / 8)] = (unsigned char)act_sign_byte(v[pass]);
         }
     }
+    R3_CLOCK(3);
 }
 
 // Tile width for N output channels: 256 columns unless that leaves a mostly empty last tile (N = 128, 384), then 128
@@ -578,6 +591,13 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     p.n_chunks = n_chunks;
     p.n_iters = 9 * n_chunks;
     p.m_tiles = (int)(mtot / hm);
+    p.seg_magic = 65536 / (p.seg_len + 2) + 1;
+    for (int row = 0; row < hm + 16; ++row)
+        if (((row * p.seg_magic) >> 16) != row / (p.seg_len + 2)) return 0;      // (cannot happen for rows < 2^8 * 2; the plain kernels take it)
+    auto log2_exact = [](long long v) { int sh = 0; while ((1ll << sh) < v) ++sh; return (1ll << sh) == v ? sh : -1; };
+    p.ow_shift = log2_exact(OW);
+    p.ohw_shift = log2_exact((long long)OH * OW);
+    if (p.ohw_shift < 0) p.ow_shift = -1;
     p.n_tiles = (N + hn - 1) / hn;
     const long long blocks = (long long)p.m_tiles * p.n_tiles;
     dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);

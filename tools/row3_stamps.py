@@ -36,3 +36,18 @@ for st, label in enumerate(("K-step 9  (kw=0: next activation tile issued)", "K-
     for w in range(4):
         print(f"      wave {w}: " + " ".join(f"{v:6.0f}" for v in np.median(d[:, w, st, :], axis=0)))
 print("three steps, start to start:", np.median(s[:, :, 2, 0] - s[:, :, 0, 0]) / 2)
+
+# in-kernel clock over the whole K loop: shader cycles per 100 MHz reference tick (MI355X_MICROARCH.md, DVFS give-back item 6)
+cbuf = np.zeros(256 * 4 * 8, dtype=np.uint64)
+if hasattr(h, "msg_row3_clock_read") and h.msg_row3_clock_read(cbuf.ctypes.data_as(ctypes.c_void_p), cbuf.nbytes) == 0:
+    # stamps of the LAST 256 workgroups of the launch: 0 kernel entry | 1 K loop start | 2 K loop end | 3 kernel exit
+    c = cbuf.reshape(256, 4, 4, 2).astype(np.int64)
+    ok = (c[:, :, 3, 1] > c[:, :, 0, 1]) & (c[:, :, 0, 1] > 0)
+    for nm, a, z in (("entry -> K loop (offsets, noise/bias staging, first loads issued)", 0, 1), ("K loop", 1, 2),
+                     ("K loop end -> exit (epilogue)", 2, 3), ("whole workgroup", 0, 3)):
+        cyc, tick = (c[:, :, z, 0] - c[:, :, a, 0])[ok], (c[:, :, z, 1] - c[:, :, a, 1])[ok]
+        print(f"   {nm:68s} median {np.median(cyc):8.0f} cycles = {np.median(tick) * 1e-2:6.1f} us")
+    cycles, ticks = (c[:, :, 2, 0] - c[:, :, 1, 0])[ok], (c[:, :, 2, 1] - c[:, :, 1, 1])[ok]
+    ghz = cycles / ticks * 0.1
+    print(f"in-kernel clock over the K loop: median {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}); "
+          f"K loop median {np.median(cycles):.0f} cycles = {np.median(ticks) * 1e-2:.1f} us")

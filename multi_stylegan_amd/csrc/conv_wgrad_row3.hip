@@ -22,6 +22,7 @@
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char* r3_lds_t;
 
 struct Row3Params {
     int B, H, W, Cx, I, ldgy, O, ldgw;
@@ -38,6 +39,27 @@ constexpr int R3_TA = R3_KP * R3_ROW;                 // 16 KiB: GY segment
 constexpr int R3_TB = (R3_KP + 4) * R3_ROW;           // 17 KiB: X segment + neighbours (66 rows used)
 constexpr int R3_STAGE = R3_TA + R3_TB;
 constexpr int R3_OOB = (int)0x80000000;
+
+
+// LDS-DMA as inline assembly.  Through the builtin the compiler knows that the instruction writes LDS and puts an
+// s_waitcnt vmcnt(0) in front of the next LDS read -- every K-step then waits for the pieces it has just issued, which is
+// the whole point of the ring undone.  Here the waits are placed by hand (counted vmcnt in front of the barrier).
+typedef int r3_desc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ r3_desc_t r3_make_desc(const char* base) {
+    const unsigned long long a = (unsigned long long)base;
+    r3_desc_t d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    d[2] = R3_OOB;
+    d[3] = 0x00020000;
+    return d;
+}
+__device__ __forceinline__ void r3_dma16(r3_desc_t desc, unsigned lds_addr, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory");      // (m0: a reserved register the compiler has no other use for in these kernels)
+#endif
+}
 
 __device__ __forceinline__ int r3_off(int r, int ch) { return r * R3_ROW + (((ch << 4) + ((r & 3) << 6)) & (R3_ROW - 1)); }
 
@@ -294,7 +316,7 @@ extern "C" int msg_wgrad3_debug_read(void* host_dst, int nbytes) {
 #endif
 
 template <bool W32>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_reg_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
                                                                   float* __restrict__ gw, float* __restrict__ ws, Row3Params p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * R3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -561,6 +583,265 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
     }
 }
 
+// The staging of conv_wgrad_row3s_kernel without registers: LDS-DMA (buffer_load ... lds, 1 KiB = four pixel rows per wave
+// instruction) into a THREE-stage ring.  In-kernel stamps of the register-staged form (profiles/r04_wgrad_row3s_stamps.txt):
+// the nine 16-B loads and the nine LDS parks a thread issues per K-step cost ~380 + ~400 cycles of the step's ~2 500 (1 536 of
+// MFMA), and their 36 registers are what kept a third LDS stage from being useful.  Here a wave issues 8 (wave 0: 9) DMA
+// pieces per K-step and nothing else; the rotation of the LDS image (64 B x (row & 3), what the transposing reads want) is
+// applied on the GLOBAL side -- lane L of a piece lands at row L >> 4, 16-B slot L & 15, and fetches the channel chunk that
+// the rotation puts there.  Behind the barrier of step t the stage of step t is free and receives step t + 3, which has
+// two periods to land; the wait in front of a barrier leaves the newest step's pieces in flight (vmcnt(8)).
+template <bool W32>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
+                                                                  float* __restrict__ gw, float* __restrict__ ws, Row3Params p) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * R3_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    const int wm = wid_u >> 1, wn = wid_u & 1;
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int G = tiles * p.kh;
+    int z = blockIdx.x / G;
+    const int rem_ = blockIdx.x - z * G;
+    int khi = rem_ / tiles;
+    int tile = rem_ - khi * tiles;
+    z = __builtin_amdgcn_readfirstlane(z);
+    khi = __builtin_amdgcn_readfirstlane(khi);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (z >= p.nz) return;
+    const int o0 = __builtin_amdgcn_readfirstlane((tile / p.i_tiles) * 128), i0 = __builtin_amdgcn_readfirstlane((tile % p.i_tiles) * 128);
+    const int segs = W32 ? 1 : p.W / R3_KP;
+    const int steps_per_sample = W32 ? p.H / 2 : p.H * segs;
+    int b = 0, s0, s1;
+    if (p.per_sample) {
+        b = z / p.chunks_per_sample;
+        const int chunk = z - b * p.chunks_per_sample;
+        s0 = chunk * p.steps_per_chunk;
+        s1 = min(steps_per_sample, s0 + p.steps_per_chunk);
+    } else {
+        s0 = z * p.steps_per_chunk;
+        s1 = min(p.B * steps_per_sample, s0 + p.steps_per_chunk);
+    }
+    b = __builtin_amdgcn_readfirstlane(b);
+    s0 = __builtin_amdgcn_readfirstlane(s0);
+    s1 = __builtin_amdgcn_readfirstlane(s1);
+    const int n_iters = s1 - s0;
+    int b_s = s0 / steps_per_sample;
+    int row_s = W32 ? (s0 - b_s * steps_per_sample) * 2 : (s0 - b_s * steps_per_sample) / segs;
+    int col_s = W32 ? 0 : (s0 - b_s * steps_per_sample - row_s * segs) * R3_KP;
+    b_s = __builtin_amdgcn_readfirstlane(b_s);
+    row_s = __builtin_amdgcn_readfirstlane(row_s);
+    col_s = __builtin_amdgcn_readfirstlane(col_s);
+
+    // ---- staging: piece j of wave w is the 1-KiB chunk c = w + 4 j of an operand's tile (rows 4 c .. 4 c + 3); the X tile
+    // has a 17th chunk (rows 64..67: the right neighbour and spare rows), piece 4 of wave 0.  X row r' holds image column
+    // col - 1 + r' (W32: image row q = r' / 34 between two zero rows, pixel 32 q + r' % 34 - 1).
+    const int lrow = lane >> 4, chl = ((lane & 15) - 4 * lrow) & 15;      // row inside the chunk (= row & 3), logical channel chunk
+    const int oc = o0 + chl * 8, ic = i0 + chl * 8;
+    const bool oc_ok = oc + 8 <= p.ldgy, ic_ok = ic + 8 <= p.Cx;
+    const int u_L = p.ldgy * 2, u_C = p.Cx * 2;
+    int voff_gy[4], voff_x[5];
+    bool x_q1[5];                                                         // W32: the lane's row belongs to the step's second image row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * (wid_u + 4 * j) + lrow;
+        voff_gy[j] = oc_ok ? r * u_L + oc * 2 : R3_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = 4 * (j < 4 ? wid_u + 4 * j : 16) + lrow;
+        if constexpr (!W32) {
+            voff_x[j] = (ic_ok && r < R3_KP + 2) ? r * u_C + ic * 2 : R3_OOB;
+            x_q1[j] = false;
+        } else {
+            const int qq = r >= 34 ? 1 : 0, pos = r - 34 * qq;
+            voff_x[j] = (ic_ok && pos >= 1 && pos <= 32) ? (32 * qq + pos - 1) * u_C + ic * 2 : R3_OOB;
+            x_q1[j] = qq != 0;
+        }
+    }
+    // (columns outside the map: X row 0 of a row's first segment -- column -1 -- and X row 65 of its last one)
+    const int voff_x0_left = (wid_u == 0 && lrow == 0) ? R3_OOB : voff_x[0];
+    const int voff_x4_right = lrow == 1 ? R3_OOB : voff_x[4];
+    const long long sample_gy = (long long)p.H * p.W * u_L, sample_x = (long long)p.H * p.W * u_C;
+    const char* gbase = (const char*)gy + (p.per_sample ? (long long)b * sample_gy : 0);
+    const char* xbase = (const char*)x + (p.per_sample ? (long long)b * sample_x : 0) +
+                        ((long long)(khi - p.pad) * p.W - (W32 ? 0 : 1)) * u_C;
+    // (descriptors as four SGPRs for the inline-assembly DMA below: base, no stride, 2^31 records, raw dword format)
+    const r3_desc_t d_gy = r3_make_desc(gbase), d_x = r3_make_desc(xbase);
+    const unsigned lds0 = (unsigned)(unsigned long long)(r3_lds_t)smem;
+
+    f32x4 acc[3][4][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[k][i][j][e] = 0.f;
+
+    int so_gy = 0, so_x = 0, col_l = 0;
+    bool row_ok = false, row_ok1 = false;
+    auto load_setup = [&]() __attribute__((always_inline)) {      // cursor -> SGPR offsets of the step being loaded
+        const unsigned pixel = ((unsigned)b_s * (unsigned)p.H + (unsigned)row_s) * (unsigned)p.W + (unsigned)col_s;
+        so_gy = (int)(pixel * (unsigned)u_L); so_x = (int)(pixel * (unsigned)u_C);
+        row_ok = (unsigned)(row_s + khi - p.pad) < (unsigned)p.H;
+        row_ok1 = (unsigned)(row_s + 1 + khi - p.pad) < (unsigned)p.H;
+        col_l = col_s;
+    };
+    auto load_advance = [&]() __attribute__((always_inline)) {
+        if constexpr (!W32) { col_s += R3_KP; if (col_s == p.W) { col_s = 0; ++row_s; } }
+        else row_s += 2;
+        if (row_s == p.H) { row_s = 0; ++b_s; }
+    };
+    // piece q (0..3: GY, 4..8: X) of the step set up by load_setup into `stage`; `live` false: zeros
+    auto dma_piece = [&](int q, int stage, bool live) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (q < 4) {
+            r3_dma16(d_gy, lds0 + stage * R3_STAGE + (wid_u + 4 * q) * 1024, live ? voff_gy[q] : R3_OOB, so_gy);
+        } else {
+            const int j = q - 4;
+            if (j == 4 && wid_u != 0) return;
+            const unsigned la = lds0 + stage * R3_STAGE + R3_TA + (j < 4 ? wid_u + 4 * j : 16) * 1024;
+            int off = voff_x[j];
+            if (!W32 && j == 0) off = col_l == 0 ? voff_x0_left : off;
+            if (!W32 && j == 4) off = col_l + R3_KP == p.W ? voff_x4_right : off;
+            const bool ok = live & (W32 ? (x_q1[j] ? row_ok1 : row_ok) : row_ok);
+            r3_dma16(d_x, la, ok ? off : R3_OOB, so_x);
+        }
+#endif
+    };
+    auto dma_all = [&](int stage, bool live) __attribute__((always_inline)) {
+        load_setup();
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dma_piece(q, stage, live);
+        load_advance();
+    };
+    // prologue: steps 0, 1, 2 into the three stages
+    dma_all(0, n_iters > 0);
+    dma_all(1, n_iters > 1);
+    dma_all(2, n_iters > 2);
+
+    // transposed fragments (see conv_wgrad_row3_kernel)
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    constexpr int NPAR = W32 ? 2 : 1;
+    int cA[4], cB[NPAR][3][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        cA[t] = (8 * g4 + q) * R3_ROW + ((((wm * 64 + t * 16 + 4 * pq) * 2) + ((q & 3) << 6)) & (R3_ROW - 1));
+#pragma unroll
+        for (int par = 0; par < NPAR; ++par)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                cB[par][k][t] = R3_TA + (8 * g4 + q) * R3_ROW +
+                                ((((wn * 64 + t * 16 + 4 * pq) * 2) + (((q + k + 2 * par) & 3) << 6)) & (R3_ROW - 1));
+    }
+    auto frag = [&](const char* stage_base, int c, int rows) __attribute__((always_inline)) {
+        s16x4 part[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(stage_base + c + (rows + 4 * half) * R3_ROW));
+        return __builtin_bit_cast(bf16v8, (s16x8)__builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    bf16v8 fa[2][4], fb[2][3][4];
+    auto read_nth = [&](int f, int s, const char* base) __attribute__((always_inline)) {
+        const int a = f == 0 ? 0 : (f >= 5 && f < 8 ? f - 4 : -1);
+        if (a >= 0) fa[s][a] = frag(base, cA[a], 32 * s);
+        else {
+            const int bidx = f < 5 ? f - 1 : f - 4;                 // 0..11
+            const int k = bidx / 4, t = bidx % 4;
+            fb[s][k][t] = frag(base, cB[W32 ? s : 0][k][t], 32 * s + k + (W32 ? 2 * s : 0));
+        }
+    };
+    auto mfma = [&](int s, int k, int i, int j) __attribute__((always_inline)) {
+        f32x4& c = acc[k][i][j];
+        const bf16v8& af = fa[s][i];
+        const bf16v8& bfr = fb[s][k][j];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(af), "v"(bfr));
+#endif
+    };
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");               // step 0 has landed (steps 1 and 2 in flight; wave 0: two of their pieces too)
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 16; ++f) read_nth(f, 0, smem);
+
+    // One K-step, its stage a compile-time constant (the loop is unrolled by three): the stage offset joins the fragment
+    // reads' immediate offsets.
+    auto k_step = [&](auto stage_tag, int it) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+        const char* sa = smem + ST * R3_STAGE;
+        const char* sn = smem + ((ST + 1) % 3) * R3_STAGE;
+        const bool live3 = it + 3 < n_iters;
+        W3_STAMP(0);
+        // sub-step 0: fragments of sub-step 1 in the first 32 gaps
+#pragma unroll
+        for (int m = 0; m < 48; ++m) {
+            mfma(0, m / 16, (m / 4) % 4, m % 4);
+            if (m < 32 && (m & 1) == 0) read_nth(m / 2, 1, sa);    // (a fragment = two transposing reads: gaps m and m + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 31) W3_STAMP(1);
+        }
+        W3_STAMP(2);
+        // own fragment reads done; own pieces of step it + 1 landed (those of step it + 2 stay in flight)
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        W3_STAMP(3);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        W3_STAMP(4);
+        // sub-step 1: first fragments of step it + 1; the pieces of step it + 3 into the stage this step just left
+#pragma unroll
+        for (int m = 0; m < 48; ++m) {
+            mfma(1, m / 16, (m / 4) % 4, m % 4);
+            if (m < 32 && (m & 1) == 0) read_nth(m / 2, 0, sn);
+            if (m == 29) load_setup();
+            if (m >= 30 && (m & 1) == 0 && m < 48) dma_piece((m - 30) / 2, ST, live3);
+            if (m == 47) load_advance();
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 29) W3_STAMP(5);
+            if (m == 38) W3_STAMP(6);
+        }
+        W3_STAMP(7);
+    };
+    int it = 0;
+    for (; it + 2 < n_iters; it += 3) {
+        k_step(std::integral_constant<int, 0>{}, it);
+        k_step(std::integral_constant<int, 1>{}, it + 1);
+        k_step(std::integral_constant<int, 2>{}, it + 2);
+    }
+    if (it < n_iters) k_step(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < n_iters) k_step(std::integral_constant<int, 1>{}, it + 1);
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // (the last inline-assembly MFMAs retire before anything reads them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the dummy pieces of the last steps write zeros into LDS: they land first)
+
+    // ---- epilogue: fp32; lanes 0..15 of a row group = 16 consecutive input channels, one pass per tap and block
+    const int l15 = lane & 15;
+    const int taps = p.kh * 3;
+    float* gz = p.split ? ws + (long long)z * p.slab : gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
+    const bool oi_major = p.oi_major && !p.split;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int tap = khi * 3 + k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int icn = i0 + wn * 64 + j * 16 + l15;
+                if (icn >= p.ldgw) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = o0 + wm * 64 + i * 16 + 4 * g4 + e;
+                    if (o >= p.O) continue;
+                    float* dst = oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
+                                          : gz + ((long long)o * taps + tap) * p.ldgw + icn;
+                    if (oi_major && icn >= p.I) continue;
+                    *dst = acc[k][i][j][e] * p.gain;
+                }
+            }
+    }
+}
+
 extern "C" int msg_wgrad_reduce_launch(const float* ws, float* gw, long long slab, int n_out, int chunks, int O, int taps,
                                        int I, int ldgw, int oi_major, void* stream);
 
@@ -629,7 +910,14 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     static const int s16 = msg_tunable("MSG_WGRAD_ROW3_S16", 1);                            // MSG_WGRAD_ROW3_S16=0: the 32x32x16 kernel (A/B)
     // (measured, bf16, B = 16, same box: 3x3 512->512 @256^2 per-sample 4235 -> 3930 us, @128^2 1079 -> 1010, 128->128 @256^2
     //  shared 318 -> 305, 384->256 @128^2 447 -> 421; 32-wide maps: 768->768 265 -> 254, 1024->768 333 -> 317)
-    if (s16 && w32)
+    static const int dma = msg_tunable("MSG_WGRAD_ROW3_DMA", 1);                            // MSG_WGRAD_ROW3_DMA=0: register-staged form (A/B)
+    if (s16 && !dma && w32)
+        hipLaunchKernelGGL(conv_wgrad_row3s_reg_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
+    else if (s16 && !dma)
+        hipLaunchKernelGGL(conv_wgrad_row3s_reg_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
+    else if (s16 && w32)
         hipLaunchKernelGGL(conv_wgrad_row3s_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     else if (s16)

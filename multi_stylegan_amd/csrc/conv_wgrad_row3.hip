@@ -290,15 +290,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* _
     }
 }
 
-// The same kernel on v_mfma_f32_16x16x32_bf16 with a hand-scheduled K loop (what conv_fprop_row3.hip does, for the same
+// The same contraction on v_mfma_f32_16x16x32_bf16 with a hand-scheduled K loop (what conv_fprop_row3.hip does, for the same
 // reasons: on real data the 16x16x32 form holds the higher clock, and at 16 cycles per MFMA only ~8 cycles of a gap are
 // free for other instructions, so they are placed one per gap by hand -- a sched_barrier per MFMA -- instead of in
 // clusters).  A K-step of 64 pixels = two sub-steps of 32; per sub-step and wave 48 MFMAs (3 taps x 4 x 4 blocks of
 // 16 x 16), 32 transposing fragment reads for the NEXT sub-step in its first 32 gaps.  The workgroup barrier of a step sits
 // between its two sub-steps: by then every wave holds the step's last fragments in registers, so behind the barrier
-//   * the stage is free: the pixels of step t + 2 (in registers since the previous period) are parked into it, and the
-//     global loads of step t + 3 follow them into the same registers -- a whole period ahead of their use;
-//   * the first fragments of step t + 1 (parked before the barrier) are read beside the second sub-step's MFMAs.
+//   * the step's LDS stage is free and receives the pixels of step t + 3 (three stages: two periods to land);
+//   * the first fragments of step t + 1 (landed: every wave waited for its own pieces before the barrier) are read beside
+//     the second sub-step's MFMAs.
 // Accumulators: 3 x 4 x 4 four-register blocks in AGPRs, tied operands of inline-assembly MFMAs (through the builtin the
 // compiler re-assigned and copied them around the loop); the compiler still places the s_waitcnt for their inputs.
 #ifdef MSG_WGRAD3_STAMPS
@@ -315,282 +315,17 @@ extern "C" int msg_wgrad3_debug_read(void* host_dst, int nbytes) {
 #define W3_STAMP(k) do {} while (0)
 #endif
 
-template <bool W32>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_reg_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
-                                                                  float* __restrict__ gw, float* __restrict__ ws, Row3Params p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * R3_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int tiles = p.o_tiles * p.i_tiles;
-    const int G = tiles * p.kh;
-    int z = blockIdx.x / G;
-    const int rem_ = blockIdx.x - z * G;
-    int khi = rem_ / tiles;
-    int tile = rem_ - khi * tiles;
-    z = __builtin_amdgcn_readfirstlane(z);
-    khi = __builtin_amdgcn_readfirstlane(khi);
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    if (z >= p.nz) return;
-    const int o0 = __builtin_amdgcn_readfirstlane((tile / p.i_tiles) * 128), i0 = __builtin_amdgcn_readfirstlane((tile % p.i_tiles) * 128);
-    const int segs = W32 ? 1 : p.W / R3_KP;
-    const int steps_per_sample = W32 ? p.H / 2 : p.H * segs;
-    int b = 0, s0, s1;
-    if (p.per_sample) {
-        b = z / p.chunks_per_sample;
-        const int chunk = z - b * p.chunks_per_sample;
-        s0 = chunk * p.steps_per_chunk;
-        s1 = min(steps_per_sample, s0 + p.steps_per_chunk);
-    } else {
-        s0 = z * p.steps_per_chunk;
-        s1 = min(p.B * steps_per_sample, s0 + p.steps_per_chunk);
-    }
-    b = __builtin_amdgcn_readfirstlane(b);
-    s0 = __builtin_amdgcn_readfirstlane(s0);
-    s1 = __builtin_amdgcn_readfirstlane(s1);
-    const int n_iters = s1 - s0;
-    int b_s = s0 / steps_per_sample;
-    int row_s = W32 ? (s0 - b_s * steps_per_sample) * 2 : (s0 - b_s * steps_per_sample) / segs;
-    int col_s = W32 ? 0 : (s0 - b_s * steps_per_sample - row_s * segs) * R3_KP;
-    b_s = __builtin_amdgcn_readfirstlane(b_s);
-    row_s = __builtin_amdgcn_readfirstlane(row_s);
-    col_s = __builtin_amdgcn_readfirstlane(col_s);
-
-    // ---- staging (as in conv_wgrad_row3_kernel): thread moves 16-B chunk `ch` of pixel rows r0 + 16 j of both operands
-    const int r0 = tid >> 4, ch = tid & 15;
-    const int oc = o0 + ch * 8, ic = i0 + ch * 8;
-    const bool oc_ok = oc + 8 <= p.ldgy, ic_ok = ic + 8 <= p.Cx;
-    const int u_L = p.ldgy * 2, u_C = p.Cx * 2;
-    int voff_gy[4], voff_x[5], xw_c[5], st_a[4], st_b[5];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = r0 + 16 * j;
-        voff_gy[j] = oc_ok ? r * u_L + oc * 2 : R3_OOB;
-        voff_x[j] = ic_ok ? r * u_C + ic * 2 : R3_OOB;
-        xw_c[j] = W32 ? 0 : r - 1;
-        st_a[j] = r3_off(r, ch);
-        st_b[j] = W32 ? r3_off((r >> 5) * 34 + (r & 31) + 1, ch) : r3_off(r, ch);
-    }
-    {
-        const int r = 64 + r0;
-        voff_x[4] = (!W32 && ic_ok && tid < 32) ? r * u_C + ic * 2 : R3_OOB;
-        xw_c[4] = r - 1;
-        st_b[4] = r3_off(r, ch);
-    }
-    const int voff_x0_left = r0 == 0 ? R3_OOB : voff_x[0];          // X row 0 = column col - 1
-    const int voff_x4_right = r0 == 1 ? R3_OOB : voff_x[4];         // X row 65 = column col + 64
-    if constexpr (W32) {
-        if (tid < 64) {
-            const int hr = (tid >> 4) == 0 ? 0 : ((tid >> 4) == 1 ? 33 : ((tid >> 4) == 2 ? 34 : 67));
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-                *reinterpret_cast<u32x4*>(smem + st * R3_STAGE + R3_TA + hr * R3_ROW + ((tid & 15) << 4)) = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    const long long sample_gy = (long long)p.H * p.W * u_L, sample_x = (long long)p.H * p.W * u_C;
-    const char* gbase = (const char*)gy + (p.per_sample ? (long long)b * sample_gy : 0);
-    const char* xbase = (const char*)x + (p.per_sample ? (long long)b * sample_x : 0) +
-                        ((long long)(khi - p.pad) * p.W - (W32 ? 0 : 1)) * u_C;
-    const __amdgpu_buffer_rsrc_t rs_gy = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, R3_OOB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, R3_OOB, 0x00020000);
-
-    f32x4 acc[3][4][4];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[k][i][j][e] = 0.f;
-
-    // The nine 16-B loads of a K-step, one at a time (piece 0..3: GY rows, 4..8: X rows); `live` false: zeros.
-    u32x4 ra[4], rb[5];
-    int so_gy = 0, so_x = 0;
-    bool row_ok = false, row_ok1 = false;
-    auto load_setup = [&]() __attribute__((always_inline)) {      // cursor -> SGPR offsets of the step being loaded, then advance
-        const unsigned pixel = ((unsigned)b_s * (unsigned)p.H + (unsigned)row_s) * (unsigned)p.W + (unsigned)col_s;
-        so_gy = (int)(pixel * (unsigned)u_L); so_x = (int)(pixel * (unsigned)u_C);
-        row_ok = (unsigned)(row_s + khi - p.pad) < (unsigned)p.H;
-        row_ok1 = (unsigned)(row_s + 1 + khi - p.pad) < (unsigned)p.H;
-    };
-    int col_l = 0;                                                // column of the step being loaded (xok tests)
-    auto load_piece = [&](int q, bool live) __attribute__((always_inline)) {
-        if (q < 4) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_gy, live ? voff_gy[q] : R3_OOB, so_gy, 0);
-        else {
-            const int j = q - 4;
-            if (W32 && j == 4) return;
-            // (columns outside the map: only X row 0 of a row's first segment -- column -1 -- and X row 65 of its last
-            //  one; which lanes those are is known up front, so the per-step test is wave-uniform)
-            const bool ok = live & (W32 ? (j < 2 ? row_ok : row_ok1) : row_ok);
-            int off = voff_x[j];
-            if (!W32 && j == 0) off = col_l == 0 ? voff_x0_left : off;
-            if (!W32 && j == 4) off = col_l + R3_KP == p.W ? voff_x4_right : off;
-            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : R3_OOB, so_x, 0);
-        }
-    };
-    auto load_advance = [&]() __attribute__((always_inline)) {
-        if constexpr (!W32) { col_s += R3_KP; if (col_s == p.W) { col_s = 0; ++row_s; } }
-        else row_s += 2;
-        if (row_s == p.H) { row_s = 0; ++b_s; }
-    };
-    auto park_piece = [&](int q, int stage) __attribute__((always_inline)) {
-        char* sa = smem + stage * R3_STAGE;
-        char* sb = sa + R3_TA;
-        if (q < 4) *reinterpret_cast<u32x4*>(sa + st_a[q]) = ra[q];
-        else if (q < 8) *reinterpret_cast<u32x4*>(sb + st_b[q - 4]) = rb[q - 4];
-        else if (!W32 && tid < 32) *reinterpret_cast<u32x4*>(sb + st_b[4]) = rb[4];
-    };
-    auto load_all = [&](bool live) __attribute__((always_inline)) {
-        col_l = col_s; load_setup();
-#pragma unroll
-        for (int q = 0; q < 9; ++q) load_piece(q, live);
-        load_advance();
-    };
-    // prologue: steps 0 and 1 into the two stages, step 2 into the registers
-    load_all(n_iters > 0);
-#pragma unroll
-    for (int q = 0; q < 9; ++q) park_piece(q, 0);
-    load_all(n_iters > 1);
-#pragma unroll
-    for (int q = 0; q < 9; ++q) park_piece(q, 1);
-    load_all(n_iters > 2);
-
-    // transposed fragments (see conv_wgrad_row3_kernel): within each group of 16 lanes, lane 4 q + pq supplies the address
-    // of pixel row (8 g + q), channels 4 pq ..+3 of a 16-channel block, and receives channel (lane % 16) of pixel rows
-    // 8 g .. 8 g + 3 (second read: + 4) -- the operand layout of the 16x16x32 MFMA (row lane % 16, k = 8 (lane / 16) ..+7).
-    const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
-    constexpr int NPAR = W32 ? 2 : 1;
-    int cA[4], cB[NPAR][3][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        cA[t] = (8 * g4 + q) * R3_ROW + ((((wm * 64 + t * 16 + 4 * pq) * 2) + ((q & 3) << 6)) & (R3_ROW - 1));
-#pragma unroll
-        for (int par = 0; par < NPAR; ++par)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                cB[par][k][t] = R3_TA + (8 * g4 + q) * R3_ROW +
-                                ((((wn * 64 + t * 16 + 4 * pq) * 2) + (((q + k + 2 * par) & 3) << 6)) & (R3_ROW - 1));
-    }
-    auto frag = [&](const char* stage_base, int c, int rows) __attribute__((always_inline)) {
-        s16x4 part[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-            part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(stage_base + c + (rows + 4 * half) * R3_ROW));
-        return __builtin_bit_cast(bf16v8, (s16x8)__builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7));
-    };
-    bf16v8 fa[2][4], fb[2][3][4];
-    // fragment f of sub-step s (0, 1) of the stage at `base`, in the order the MFMAs need them: A0, B(tap 0) x 4, A1..A3,
-    // B(tap 1) x 4, B(tap 2) x 4
-    auto read_nth = [&](int f, int s, const char* base) __attribute__((always_inline)) {
-        const int a = f == 0 ? 0 : (f >= 5 && f < 8 ? f - 4 : -1);
-        if (a >= 0) fa[s][a] = frag(base, cA[a], 32 * s);
-        else {
-            const int bidx = f < 5 ? f - 1 : f - 4;                 // 0..11
-            const int k = bidx / 4, t = bidx % 4;
-            fb[s][k][t] = frag(base, cB[W32 ? s : 0][k][t], 32 * s + k + (W32 ? 2 * s : 0));
-        }
-    };
-    auto mfma = [&](int s, int k, int i, int j) __attribute__((always_inline)) {
-        f32x4& c = acc[k][i][j];
-        const bf16v8& af = fa[s][i];
-        const bf16v8& bfr = fb[s][k][j];
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(af), "v"(bfr));
-#endif
-    };
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int f = 0; f < 16; ++f) read_nth(f, 0, smem);
-
-    // One K-step with the stage it uses a compile-time constant (the loop is unrolled by two): the stage offset joins the
-    // fragment reads' immediate offsets, which takes the address add out of every one of the 32 reads of a sub-step.
-    // (Stamps, tools/wgrad3_stamps.py: the nine parks and the nine loads of a K-step cost ~320 + ~300 cycles of its ~2450.
-    // Measured and rejected: per-wave instances of the loop that stagger them in time, one park + one load per 16 cycles
-    // on the CU, interleaved with the fragment reads -- 3800 -> 4030 us on 3x3 512->512 @256^2; parks and loads as pairs, a
-    // period minus one gap apart -- no change.  An ablation whose parks do not depend on the loads shows the same ~44 cycles
-    // per park: it is not the loads' latency but the cost of four waves issuing 1-KiB LDS writes in the same gap.)
-    auto k_step = [&](auto stage_tag, int it) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_tag)::value;
-        const char* sa = smem + ST * R3_STAGE;
-        const char* sn = smem + (ST ^ 1) * R3_STAGE;
-        const bool live3 = it + 3 < n_iters;
-        W3_STAMP(0);
-        // sub-step 0: fragments of sub-step 1 in the first 32 gaps
-#pragma unroll
-        for (int m = 0; m < 48; ++m) {
-            mfma(0, m / 16, (m / 4) % 4, m % 4);
-            if (m < 32 && (m & 1) == 0) read_nth(m / 2, 1, sa);    // (a fragment = two transposing reads: gaps m and m + 1)
-            __builtin_amdgcn_sched_barrier(0);
-            if (m == 31) W3_STAMP(1);
-        }
-        W3_STAMP(2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own fragment reads and parks done
-        __builtin_amdgcn_sched_barrier(0);
-        W3_STAMP(3);
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        W3_STAMP(4);
-        // sub-step 1: first fragments of step it + 1; then the registers (step it + 2) into the stage this step just
-        // left, and the loads of step it + 3 behind them
-#pragma unroll
-        for (int m = 0; m < 48; ++m) {
-            mfma(1, m / 16, (m / 4) % 4, m % 4);
-            if (m < 32 && (m & 1) == 0) read_nth(m / 2, 0, sn);
-            if (m >= 30 && m < 39) park_piece(m - 30, ST);
-            if (m == 38) { col_l = col_s; load_setup(); }
-            if (m >= 39) load_piece(m - 39, live3);
-            if (m == 47) load_advance();
-            __builtin_amdgcn_sched_barrier(0);
-            if (m == 29) W3_STAMP(5);
-            if (m == 38) W3_STAMP(6);
-        }
-        W3_STAMP(7);
-    };
-    int it = 0;
-    for (; it + 1 < n_iters; it += 2) {
-        k_step(std::integral_constant<int, 0>{}, it);
-        k_step(std::integral_constant<int, 1>{}, it + 1);
-    }
-    if (it < n_iters) k_step(std::integral_constant<int, 0>{}, it);
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // (the last inline-assembly MFMAs retire before anything reads them)
-
-    // ---- epilogue: fp32; lanes 0..15 of a row group = 16 consecutive input channels, one pass per tap and block
-    const int l15 = lane & 15;
-    const int taps = p.kh * 3;
-    float* gz = p.split ? ws + (long long)z * p.slab : gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
-    const bool oi_major = p.oi_major && !p.split;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int tap = khi * 3 + k;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int icn = i0 + wn * 64 + j * 16 + l15;
-                if (icn >= p.ldgw) continue;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = o0 + wm * 64 + i * 16 + 4 * g4 + e;
-                    if (o >= p.O) continue;
-                    float* dst = oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
-                                          : gz + ((long long)o * taps + tap) * p.ldgw + icn;
-                    if (oi_major && icn >= p.I) continue;
-                    *dst = acc[k][i][j][e] * p.gain;
-                }
-            }
-    }
-}
-
-// The staging of conv_wgrad_row3s_kernel without registers: LDS-DMA (buffer_load ... lds, 1 KiB = four pixel rows per wave
-// instruction) into a THREE-stage ring.  In-kernel stamps of the register-staged form (profiles/r04_wgrad_row3s_stamps.txt):
-// the nine 16-B loads and the nine LDS parks a thread issues per K-step cost ~380 + ~400 cycles of the step's ~2 500 (1 536 of
-// MFMA), and their 36 registers are what kept a third LDS stage from being useful.  Here a wave issues 8 (wave 0: 9) DMA
-// pieces per K-step and nothing else; the rotation of the LDS image (64 B x (row & 3), what the transposing reads want) is
-// applied on the GLOBAL side -- lane L of a piece lands at row L >> 4, 16-B slot L & 15, and fetches the channel chunk that
-// the rotation puts there.  Behind the barrier of step t the stage of step t is free and receives step t + 3, which has
-// two periods to land; the wait in front of a barrier leaves the newest step's pieces in flight (vmcnt(8)).
+// Staging: LDS-DMA (buffer_load ... lds, 1 KiB = four pixel rows per wave instruction) into a THREE-stage ring.  (Rounds 2-3
+// staged through registers -- nine 16-B loads and nine LDS parks per thread and K-step; in-kernel stamps,
+// profiles/r04_wgrad_row3s_stamps.txt: ~380 + ~400 cycles of a step's ~2 500, 1 536 of them MFMA -- and their 36 registers
+// were the third stage.  Same box, 3x3 512->512 @256^2, B = 16: 4 050 -> 3 470 us; profiles/r04_wgrad_row3s_dma_ab.txt.)
+// A wave issues 8 (wave 0: 9) pieces per K-step and nothing else; the rotation of the LDS image (64 B x (row & 3), what the
+// transposing reads want) is applied on the GLOBAL side -- lane L of a piece lands at row L >> 4, 16-B slot L & 15, and
+// fetches the channel chunk that the rotation puts there.  Behind the barrier of step t the stage of step t receives step
+// t + 3; the wait in front of a barrier leaves the newest step's pieces in flight (vmcnt(8)).  Where the pieces sit in the
+// period does not matter (measured: every second gap of the read-free tail of sub-step 1 -- kept; split over the tails of
+// two sub-steps -- same; per-wave instances that stagger the waves over 72 gaps -- 2 % slower, the pieces then collide with
+// the fragment reads): a piece costs its wave ~45 cycles of MFMA issue wherever it is.
 template <bool W32>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
                                                                   float* __restrict__ gw, float* __restrict__ ws, Row3Params p) {
@@ -910,14 +645,7 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     static const int s16 = msg_tunable("MSG_WGRAD_ROW3_S16", 1);                            // MSG_WGRAD_ROW3_S16=0: the 32x32x16 kernel (A/B)
     // (measured, bf16, B = 16, same box: 3x3 512->512 @256^2 per-sample 4235 -> 3930 us, @128^2 1079 -> 1010, 128->128 @256^2
     //  shared 318 -> 305, 384->256 @128^2 447 -> 421; 32-wide maps: 768->768 265 -> 254, 1024->768 333 -> 317)
-    static const int dma = msg_tunable("MSG_WGRAD_ROW3_DMA", 1);                            // MSG_WGRAD_ROW3_DMA=0: register-staged form (A/B)
-    if (s16 && !dma && w32)
-        hipLaunchKernelGGL(conv_wgrad_row3s_reg_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
-    else if (s16 && !dma)
-        hipLaunchKernelGGL(conv_wgrad_row3s_reg_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
-    else if (s16 && w32)
+    if (s16 && w32)
         hipLaunchKernelGGL(conv_wgrad_row3s_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     else if (s16)

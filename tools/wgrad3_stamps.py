@@ -20,7 +20,7 @@ buf = np.zeros(256 * 4 * 2 * 8, dtype=np.uint64)
 assert h.msg_wgrad3_debug_read(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes) == 0
 s = buf.reshape(256, 4, 2, 8).astype(np.int64)
 names = ["sub-step 0, MFMAs 0..31 (32 fragment reads)", "sub-step 0, MFMAs 32..47", "lgkmcnt wait", "barrier",
-         "sub-step 1, MFMAs 0..29 (30 reads)", "sub-step 1, MFMAs 30..38 (2 reads, 9 parks)", "sub-step 1, MFMAs 39..47 (9 loads)"]
+         "sub-step 1, MFMAs 0..29 (30 reads)", "sub-step 1, MFMAs 30..38 (2 reads, 5 DMA pieces)", "sub-step 1, MFMAs 39..47 (4 DMA pieces)"]
 d = np.diff(s, axis=3)
 for st in range(2):
     print(f"K-step {8 + st}")

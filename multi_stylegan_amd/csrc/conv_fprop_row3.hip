@@ -43,11 +43,12 @@ constexpr int H_OOB = (int)0x80000000;
 
 #ifdef MSG_ROW3_STAMPS
 // diagnostic build only (tools/row3_stamps.py; never ship or benchmark it): cycle stamps of K-steps 9..11 of every wave
-// of the first 256 workgroups of sample 0
+// of the LAST 256 workgroups of the launch (the first 256 start in lock-step at the boost clock and fight over the same weight
+// rows: their waits are not the steady state's)
 __device__ unsigned long long g_row3_stamps[256 * 4 * 3 * 8];
-#define R3_STAMP(k) do { if (it >= 9 && it < 12 && L < 256 && blockIdx.z == 0 && lane == 0) { unsigned long long tt; \
+#define R3_STAMP(k) do { if (it >= 9 && it < 12 && L + 256 >= gridDim.x && blockIdx.z == gridDim.z - 1 && lane == 0) { unsigned long long tt; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); \
-    g_row3_stamps[((L * 4 + wid_u) * 3 + (it - 9)) * 8 + (k)] = tt; } } while (0)
+    g_row3_stamps[(((L + 256 - gridDim.x) * 4 + wid_u) * 3 + (it - 9)) * 8 + (k)] = tt; } } while (0)
 extern "C" int msg_row3_debug_read(void* host_dst, int nbytes) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_row3_stamps), nbytes) == hipSuccess ? 0 : -1;
 }

@@ -54,12 +54,17 @@ __device__ __forceinline__ r3_desc_t r3_make_desc(const char* base) {
     d[3] = 0x00020000;
     return d;
 }
+// (m0 is named as clobbered so that the compiler never keeps a value of its own in it across a piece; clang warns that it
+//  is a reserved register -- it has no other use for it in these kernels)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void r3_dma16(r3_desc_t desc, unsigned lds_addr, int voff, int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory");      // (m0: a reserved register the compiler has no other use for in these kernels)
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
 #endif
 }
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ int r3_off(int r, int ch) { return r * R3_ROW + (((ch << 4) + ((r & 3) << 6)) & (R3_ROW - 1)); }
 

@@ -200,38 +200,56 @@ __global__ __launch_bounds__(256) void bias_act_bwd_cl_kernel(const T* __restric
     float sb[VEC], sn = 0.f;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) sb[e] = 0.f;
-    for (long long q = p0 + pl; q < p1; q += npl) {
+    // Two pixels per trip, both requested before either is used: with one 16-byte load in flight per thread the kernel sat at
+    // 4.7 TB/s (32 KiB in flight per CU; Little's law wants ~48 KiB at this latency).  The sums still add pixel q before pixel
+    // q + npl: the association -- and with it every bit of the bias / noise gradients -- is the one-pixel loop's.
+    for (long long q = p0 + pl; q < p1; q += 2 * npl) {
         // (no fused multiply-adds here: f[e] is stored AND summed; a product folded into the running sum in one instantiation
         //  and not in the other would make the masked and the unmasked kernel differ in the sums' last bit)
 #pragma clang fp contract(off)
-        const long long i = q * p.size_b + (long long)cv * VEC;
-        V g, o, r;
-        g.raw = *reinterpret_cast<const uint4*>(gy + i);
-        unsigned int mbits = 0;
-        if constexpr (SUMS_ONLY) {
+        const long long qq[2] = {q, q + npl};
+        const bool live1 = qq[1] < p1;
+        V g[2], o[2];
+        unsigned int mbits[2] = {0u, 0u};
+        float nz[2] = {0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) sb[e] += g.get(e);
-            continue;
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !live1) break;
+            const long long i = qq[u] * p.size_b + (long long)cv * VEC;
+            g[u].raw = *reinterpret_cast<const uint4*>(gy + i);
+            if constexpr (!SUMS_ONLY) {
+                if constexpr (MASK) mbits[u] = reinterpret_cast<const unsigned char*>(out)[act_mask_index(qq[u], cv, p.size_b, tile_m, tile_n)];
+                else o[u].raw = *reinterpret_cast<const uint4*>(out + i);
+                if (HAS_NOISE) nz[u] = noise[p.noise_batch == 1 ? qq[u] % p.pix : qq[u]];
+            }
         }
-        if constexpr (MASK) mbits = reinterpret_cast<const unsigned char*>(out)[act_mask_index(q, cv, p.size_b, tile_m, tile_n)];
-        else o.raw = *reinterpret_cast<const uint4*>(out + i);
-        float f[VEC], rowsum = 0.f;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const bool pos = MASK ? ((mbits >> e) & 1u) != 0 : o.get(e) > 0.f;
-            f[e] = g.get(e) * p.scale * ((pos || p.act != 3) ? 1.f : p.alpha);
-            sb[e] += f[e];
-            rowsum += f[e];
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !live1) break;
+            if constexpr (SUMS_ONLY) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sb[e] += g[u].get(e);
+                continue;
+            }
+            V r;
+            float f[VEC], rowsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const bool pos = MASK ? ((mbits[u] >> e) & 1u) != 0 : o[u].get(e) > 0.f;
+                f[e] = g[u].get(e) * p.scale * ((pos || p.act != 3) ? 1.f : p.alpha);
+                sb[e] += f[e];
+                rowsum += f[e];
+            }
+            if (HAS_NOISE) sn = fmaf(rowsum, nz[u], sn);
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r.set(e, f[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r.set2(e, f[2 * e], f[2 * e + 1]);
+            }
+            *reinterpret_cast<uint4*>(gx + qq[u] * p.size_b + (long long)cv * VEC) = r.raw;
         }
-        if (HAS_NOISE) sn = fmaf(rowsum, noise[p.noise_batch == 1 ? q % p.pix : q], sn);
-        if constexpr (VEC == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r.set(e, f[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r.set2(e, f[2 * e], f[2 * e + 1]);
-        }
-        *reinterpret_cast<uint4*>(gx + i) = r.raw;
     }
     if (part_b) {
 #pragma unroll

@@ -40,7 +40,6 @@ constexpr int R3_TB = (R3_KP + 4) * R3_ROW;           // 17 KiB: X segment + nei
 constexpr int R3_STAGE = R3_TA + R3_TB;
 constexpr int R3_OOB = (int)0x80000000;
 
-
 // LDS-DMA as inline assembly.  Through the builtin the compiler knows that the instruction writes LDS and puts an
 // s_waitcnt vmcnt(0) in front of the next LDS read -- every K-step then waits for the pieces it has just issued, which is
 // the whole point of the ring undone.  Here the waits are placed by hand (counted vmcnt in front of the barrier).
@@ -60,242 +59,17 @@ __device__ __forceinline__ r3_desc_t r3_make_desc(const char* base) {
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void r3_dma16(r3_desc_t desc, unsigned lds_addr, int voff, int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"   // (s_nop: one wait state between the scalar write of m0 and the DMA that reads it)
                  :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
 #endif
 }
 #pragma clang diagnostic pop
 
-__device__ __forceinline__ int r3_off(int r, int ch) { return r * R3_ROW + (((ch << 4) + ((r & 3) << 6)) & (R3_ROW - 1)); }
 
 // W32: the map is exactly 32 pixels wide -- a K-step is TWO whole image rows; each occupies 34 rows of the X tile (its 32
-// pixels between two zero rows, written once), tap kw of pixel p of image row q reads X row 34 q + p + kw.
-template <bool W32>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_row3_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
-                                                                 float* __restrict__ gw, float* __restrict__ ws, Row3Params p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * R3_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int tiles = p.o_tiles * p.i_tiles;
-    const int G = tiles * p.kh;
-    // tile index fastest, then kernel row, then K-slice (8 | tiles: an XCD keeps its channel tiles for every slice)
-    int z = blockIdx.x / G;
-    const int rem_ = blockIdx.x - z * G;
-    int khi = rem_ / tiles;
-    int tile = rem_ - khi * tiles;
-    z = __builtin_amdgcn_readfirstlane(z);
-    khi = __builtin_amdgcn_readfirstlane(khi);
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    if (z >= p.nz) return;
-    const int o0 = __builtin_amdgcn_readfirstlane((tile / p.i_tiles) * 128), i0 = __builtin_amdgcn_readfirstlane((tile % p.i_tiles) * 128);
-    const int segs = W32 ? 1 : p.W / R3_KP;
-    const int steps_per_sample = W32 ? p.H / 2 : p.H * segs;
-    int b = 0, s0, s1;
-    if (p.per_sample) {
-        b = z / p.chunks_per_sample;
-        const int chunk = z - b * p.chunks_per_sample;
-        s0 = chunk * p.steps_per_chunk;
-        s1 = min(steps_per_sample, s0 + p.steps_per_chunk);
-    } else {
-        s0 = z * p.steps_per_chunk;
-        s1 = min(p.B * steps_per_sample, s0 + p.steps_per_chunk);
-    }
-    // (integer divisions run on the vector ALU: pin the wave-uniform results back into SGPRs, otherwise the buffer
-    //  descriptors derived from them count as divergent and every load becomes a waterfall loop)
-    b = __builtin_amdgcn_readfirstlane(b);
-    s0 = __builtin_amdgcn_readfirstlane(s0);
-    s1 = __builtin_amdgcn_readfirstlane(s1);
-    const int n_iters = s1 - s0;
-    // cursor of the next K-step to load: (sample, row, column) -- wave-uniform
-    int b_s = s0 / steps_per_sample;
-    int row_s = W32 ? (s0 - b_s * steps_per_sample) * 2 : (s0 - b_s * steps_per_sample) / segs;
-    int col_s = W32 ? 0 : (s0 - b_s * steps_per_sample - row_s * segs) * R3_KP;
-    b_s = __builtin_amdgcn_readfirstlane(b_s);
-    row_s = __builtin_amdgcn_readfirstlane(row_s);
-    col_s = __builtin_amdgcn_readfirstlane(col_s);
-
-    // ---- staging: thread moves 16-B chunk `ch` of pixel rows r0 + 16 j (j = 0..3) of both operands; threads 0..31 also
-    // move X rows 64, 65 (the right neighbour and one spare).  X row r' holds image column col - 1 + r'.
-    const int r0 = tid >> 4, ch = tid & 15;
-    const int oc = o0 + ch * 8, ic = i0 + ch * 8;
-    const bool oc_ok = oc + 8 <= p.ldgy, ic_ok = ic + 8 <= p.Cx;
-    const int u_L = p.ldgy * 2, u_C = p.Cx * 2;
-    int voff_gy[4], voff_x[5], xw_c[5], st_a[4], st_b[5];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = r0 + 16 * j;
-        voff_gy[j] = oc_ok ? r * u_L + oc * 2 : R3_OOB;
-        voff_x[j] = ic_ok ? r * u_C + ic * 2 : R3_OOB;
-        xw_c[j] = W32 ? 0 : r - 1;                     // (W32: every staged column exists; the halo rows are never loaded)
-        st_a[j] = r3_off(r, ch);
-        st_b[j] = W32 ? r3_off((r >> 5) * 34 + (r & 31) + 1, ch) : r3_off(r, ch);
-    }
-    {
-        const int r = 64 + r0;                        // (tid < 32: r0 is 0 or 1)
-        voff_x[4] = (!W32 && ic_ok && tid < 32) ? r * u_C + ic * 2 : R3_OOB;
-        xw_c[4] = r - 1;
-        st_b[4] = r3_off(r, ch);
-    }
-    if constexpr (W32) {                               // the four halo rows of both stages: zeros, once
-        if (tid < 64) {
-            const int hr = (tid >> 4) == 0 ? 0 : ((tid >> 4) == 1 ? 33 : ((tid >> 4) == 2 ? 34 : 67));
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-                *reinterpret_cast<u32x4*>(smem + st * R3_STAGE + R3_TA + hr * R3_ROW + ((tid & 15) << 4)) = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    const long long sample_gy = (long long)p.H * p.W * u_L, sample_x = (long long)p.H * p.W * u_C;
-    const char* gbase = (const char*)gy + (p.per_sample ? (long long)b * sample_gy : 0);
-    const char* xbase = (const char*)x + (p.per_sample ? (long long)b * sample_x : 0) +
-                        ((long long)(khi - p.pad) * p.W - (W32 ? 0 : 1)) * u_C;   // tap (khi, 0) of pixel (0, 0): may precede the tensor
-    const __amdgpu_buffer_rsrc_t rs_gy = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, R3_OOB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, R3_OOB, 0x00020000);
-
-    f32x16 acc[3][2][2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[k][i][j][e] = 0.f;
-
-    u32x4 ra[4], rb[5];
-    auto load_next = [&]() __attribute__((always_inline)) {
-        const unsigned pixel = ((unsigned)b_s * (unsigned)p.H + (unsigned)row_s) * (unsigned)p.W + (unsigned)col_s;
-        const int so_gy = (int)(pixel * (unsigned)u_L), so_x = (int)(pixel * (unsigned)u_C);
-        const bool row_ok = (unsigned)(row_s + khi - p.pad) < (unsigned)p.H;
-        const bool row_ok1 = (unsigned)(row_s + 1 + khi - p.pad) < (unsigned)p.H;      // (W32: the step's second image row)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool xok = W32 ? (j < 2 ? row_ok : row_ok1) : (row_ok & ((unsigned)(col_s + xw_c[j]) < (unsigned)p.W));
-            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gy, voff_gy[j], so_gy, 0);
-            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[j] : R3_OOB, so_x, 0);
-        }
-        if constexpr (!W32) {
-            const bool xok = row_ok & ((unsigned)(col_s + xw_c[4]) < (unsigned)p.W);
-            rb[4] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xok ? voff_x[4] : R3_OOB, so_x, 0);
-            col_s += R3_KP;
-            if (col_s == p.W) { col_s = 0; ++row_s; }
-        } else {
-            row_s += 2;
-        }
-        if (row_s == p.H) { row_s = 0; ++b_s; }
-    };
-    auto park = [&](int stage) __attribute__((always_inline)) {
-        char* sa = smem + stage * R3_STAGE;
-        char* sb = sa + R3_TA;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<u32x4*>(sa + st_a[j]) = ra[j];
-            *reinterpret_cast<u32x4*>(sb + st_b[j]) = rb[j];
-        }
-        if (!W32 && tid < 32) *reinterpret_cast<u32x4*>(sb + st_b[4]) = rb[4];
-    };
-    if (n_iters > 0) {
-        load_next();
-        park(0);
-        if (n_iters > 1) load_next();
-    }
-    // transposed fragment: lane = 16 g + 4 q + pq supplies the address of pixel row (kb + q), channels cb + 4 pq ..+3;
-    // it receives channel (cb + lane % 16) of pixel rows kb .. kb + 3 (see conv_wgrad.hip).  The row a lane addresses is
-    // (multiple of 4) + q + tap shift, so the 64-B rotation of its row only depends on (q + shift) & 3: every address is
-    // a per-lane constant (one per operand / tap / 32-channel block) plus a compile-time row offset.
-    const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
-    const int kb = 8 * (g4 >> 1), cb = 16 * (g4 & 1);
-    // (W32: pixels 32..63 of the K-step sit two rows further down the X tile, which also shifts their rotation: a second
-    //  set of constants for the k-steps 2 and 3)
-    constexpr int NPAR = W32 ? 2 : 1;
-    int cA[2], cB[NPAR][3][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        cA[t] = (kb + q) * R3_ROW + ((((wm * 64 + t * 32 + cb + 4 * pq) * 2) + ((q & 3) << 6)) & (R3_ROW - 1));
-#pragma unroll
-        for (int par = 0; par < NPAR; ++par)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                cB[par][k][t] = R3_TA + (kb + q) * R3_ROW +
-                                ((((wn * 64 + t * 32 + cb + 4 * pq) * 2) + (((q + k + 2 * par) & 3) << 6)) & (R3_ROW - 1));
-    }
-    auto b_row = [](int ks, int k) { return ks * 16 + k + (W32 ? 2 * (ks >> 1) : 0); };     // first X-tile row of (k-step, tap)
-    auto frag = [&](const char* stage_base, int c, int rows) __attribute__((always_inline)) {
-        s16x4 part[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-            part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(stage_base + c + (rows + 4 * half) * R3_ROW));
-        return __builtin_bit_cast(bf16v8, (s16x8)__builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7));
-    };
-    for (int it = 0; it < n_iters; ++it) {
-        __syncthreads();
-        if (it + 1 < n_iters) park((it + 1) & 1);
-        if (it + 2 < n_iters) load_next();
-        const char* sa = smem + (it & 1) * R3_STAGE;
-        bf16v8 fa[2][2], fb[2][3][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            fa[0][t] = frag(sa, cA[t], 0);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) fb[0][k][t] = frag(sa, cB[0][k][t], b_row(0, k));
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                          // k-steps of 16 pixels, fragments one step ahead
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    fa[(ks + 1) & 1][t] = frag(sa, cA[t], (ks + 1) * 16);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        fb[(ks + 1) & 1][k][t] = frag(sa, cB[W32 ? ((ks + 1) >> 1) : 0][k][t], b_row(ks + 1, k));
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[k][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][k][j], acc[k][i][j], 0, 0, 0);
-        }
-        // order: the 16 fragment reads of k-step 0, then per k-step [3 MFMAs, 4 reads of the next k-step] x 4
-        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-    }
-
-    // ---- epilogue: fp32, lanes 0..31 = 32 consecutive input channels (128-B runs), one pass per horizontal tap
-    const int lr = lane & 31, lh = lane >> 5;
-    const int taps = p.kh * 3;
-    float* gz = p.split ? ws + (long long)z * p.slab : gw + (p.per_sample ? (long long)b * p.gw_zstride : 0);
-    const bool oi_major = p.oi_major && !p.split;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int tap = khi * 3 + k;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int icn = i0 + wn * 64 + j * 32 + lr;
-                if (icn >= p.ldgw) continue;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int o = o0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (o >= p.O) continue;
-                    float* dst = oi_major ? gz + ((long long)o * p.I + icn) * taps + tap
-                                          : gz + ((long long)o * taps + tap) * p.ldgw + icn;
-                    if (oi_major && icn >= p.I) continue;
-                    *dst = acc[k][i][j][e] * p.gain;
-                }
-            }
-    }
-}
-
-// The same contraction on v_mfma_f32_16x16x32_bf16 with a hand-scheduled K loop (what conv_fprop_row3.hip does, for the same
+// pixels between two zero rows: lanes whose source is out of range), tap kw of pixel p of image row q reads X row 34 q + p + kw.
+// (Round 1's kernel of this file ran v_mfma_f32_32x32x16_bf16 in compiler-scheduled clusters; `git log` has it.)
+// The contraction runs on v_mfma_f32_16x16x32_bf16 with a hand-scheduled K loop (what conv_fprop_row3.hip does, for the same
 // reasons: on real data the 16x16x32 form holds the higher clock, and at 16 cycles per MFMA only ~8 cycles of a gap are
 // free for other instructions, so they are placed one per gap by hand -- a sched_barrier per MFMA -- instead of in
 // clusters).  A K-step of 64 pixels = two sub-steps of 32; per sub-step and wave 48 MFMAs (3 taps x 4 x 4 blocks of
@@ -461,7 +235,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
     dma_all(1, n_iters > 1);
     dma_all(2, n_iters > 2);
 
-    // transposed fragments (see conv_wgrad_row3_kernel)
+    // transposed fragments (ds_read_b64_tr_b16, see conv_wgrad.hip): within each group of 16 lanes, lane 4 q + pq supplies the
+    // address of pixel row (8 g + q), channels 4 pq ..+3 of a 16-channel block, and receives channel (lane % 16) of pixel rows
+    // 8 g .. 8 g + 3 (second read: + 4) -- the operand layout of the 16x16x32 MFMA (row lane % 16, k = 8 (lane / 16) ..+7).
+    // The row a lane addresses is (multiple of 4) + q + tap shift, so the 64-B rotation of its row only depends on
+    // (q + shift) & 3: every address is a per-lane constant (one per operand / tap / 16-channel block) plus a compile-time
+    // row offset.  (W32: pixels 32..63 of the K-step sit two rows further down the X tile, which also shifts their rotation:
+    // a second set of constants for the second sub-step.)
     const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
     constexpr int NPAR = W32 ? 2 : 1;
     int cA[4], cB[NPAR][3][4];
@@ -647,20 +427,11 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     *need = p.split ? zs * p.slab : 0;
     if (plan_only) return 1;
     if (p.split && (!ws || ws_floats < *need)) return MSG_EINVAL;
-    static const int s16 = msg_tunable("MSG_WGRAD_ROW3_S16", 1);                            // MSG_WGRAD_ROW3_S16=0: the 32x32x16 kernel (A/B)
-    // (measured, bf16, B = 16, same box: 3x3 512->512 @256^2 per-sample 4235 -> 3930 us, @128^2 1079 -> 1010, 128->128 @256^2
-    //  shared 318 -> 305, 384->256 @128^2 447 -> 421; 32-wide maps: 768->768 265 -> 254, 1024->768 333 -> 317)
-    if (s16 && w32)
+    if (w32)
         hipLaunchKernelGGL(conv_wgrad_row3s_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
-    else if (s16)
-        hipLaunchKernelGGL(conv_wgrad_row3s_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
-    else if (w32)
-        hipLaunchKernelGGL(conv_wgrad_row3_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     else
-        hipLaunchKernelGGL(conv_wgrad_row3_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(conv_wgrad_row3s_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)gy, (const bf16_t*)x, gw, ws, p);
     if (MSG_CHECK_LAUNCH() != MSG_OK) return MSG_ELAUNCH;
     if (p.split) {

@@ -24,7 +24,6 @@
 #include <stdlib.h>
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(1))) char* gptr_t;
 typedef __attribute__((address_space(3))) char* lds_t;
 
 struct ConvParamsPP {
@@ -37,7 +36,6 @@ struct ConvParamsPP {
 
 constexpr int PM = 256, PN = 256, PROW = 128;
 constexpr int PSTAGE = (PM + PN) * PROW;                  // 64 KiB
-__device__ __attribute__((aligned(256))) unsigned int g_pp_zero_page[16384];
 
 __device__ __forceinline__ int pswz(int row, int slot) { return row * PROW + ((slot ^ ((row >> 1) & 7)) << 4); }
 #ifdef MSG_PP_STAMPS
@@ -80,9 +78,13 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     const int sw0 = (row0 >> 1) & 7;                         // swizzle of rows j = 0, 2 ; rows j = 1, 3 use sw0 ^ 4
     const int ohw = p.OH * p.OW;
     const int taps = p.kh * p.kw;
-    const gptr_t xbase = (gptr_t)x;
-    const gptr_t zbase = (gptr_t)g_pp_zero_page;
-    const long long zoff = slot_phys * 16;
+    // (32-bit buffer offsets + two descriptors instead of 64-bit pointers per row: a 1-KiB LDS-DMA piece addressed through a
+    //  descriptor costs the texture-address unit about half of what a piece with 64 per-lane 64-bit addresses does -- stamps:
+    //  ~100 cycles per piece with four waves issuing together before, and the eight pieces at the top of phase A were this
+    //  kernel's critical path.  Rows that must read zeros take an out-of-range offset; eligibility keeps the tensors below 2 GiB.)
+    const msg_desc_t d_x = msg_make_desc((const char*)x + (p.per_sample ? (long long)bz * p.x_bstride * ESZ : 0));
+    const msg_desc_t d_w = msg_make_desc((const char*)w + (p.per_sample ? (long long)bz * p.w_bstride * ESZ : 0));
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_t)smem;
     // (b, oh, ow) of this lane's four A rows, packed 10|11|11 bits (one VGPR per row); bit 31 = row is beyond M
     unsigned rc[4];
 #pragma unroll
@@ -95,24 +97,20 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
         rc[j] = (ok ? 0u : 0x80000000u) | ((unsigned)b << 22) | ((unsigned)oh << 11) | (unsigned)ow;
     }
-    gptr_t pa[4], pb[4];
-    {
-        const gptr_t wb = (gptr_t)w + (p.per_sample ? (long long)bz * p.w_bstride : 0) * ESZ;
+    int va[4], vb[4];                                     // byte offsets of chunk 0 of the current tap (A) / of K-tile 0 (B)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + row0 + 8 * j;
-            const int sl = slot_phys ^ (sw0 ^ ((j & 1) << 2));
-            const bool ok = n < p.N;
-            pb[j] = (ok ? wb : zbase) + (ok ? ((long long)n * taps * p.Ck + sl * VEC) * ESZ : zoff);
-            pa[j] = zbase;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + row0 + 8 * j;
+        const int sl = slot_phys ^ (sw0 ^ ((j & 1) << 2));
+        vb[j] = n < p.N ? (int)(((long long)n * taps * p.Ck + sl * VEC) * ESZ) : MSG_DMA_OOB;
+        va[j] = MSG_DMA_OOB;
     }
     const bool ragged = (p.Cx % BKE) != 0;
     int ld_tap = -1, ld_chunk = p.n_chunks - 1, ld_tile = -1;
-    auto advance = [&]() __attribute__((always_inline)) {     // cursor to the next K-tile; new tap -> new row pointers
-        if (++ld_tile >= p.n_iters) {                         // past the last K-tile: copies of zeros into an unused stage
+    auto advance = [&]() __attribute__((always_inline)) {     // cursor to the next K-tile; new tap -> new row offsets
+        if (++ld_tile >= p.n_iters) {                         // past the last K-tile: zeros into an unused stage
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { pa[j] = zbase + zoff; pb[j] = zbase + zoff; }
+            for (int j = 0; j < 4; ++j) { va[j] = MSG_DMA_OOB; vb[j] = MSG_DMA_OOB; }
             ld_chunk = 0;
             ld_tap = taps;                                    // (never a real tap again)
             return;
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
             for (int j = 0; j < 4; ++j) {
                 const int sl = slot_phys ^ (sw0 ^ ((j & 1) << 2));
                 bool ok = (rc[j] >> 31) == 0;
-                const int b = p.per_sample ? bz : (int)((rc[j] >> 22) & 0x1ff);
+                const int b = p.per_sample ? 0 : (int)((rc[j] >> 22) & 0x1ff);
                 const int oh = (int)((rc[j] >> 11) & 0x7ff), ow = (int)(rc[j] & 0x7ff);
                 int ih = oh * p.stride - p.pad + kh_, iw = ow * p.stride - p.pad + kw_;
                 ok = ok & (ih >= 0) & (iw >= 0);
@@ -134,38 +132,24 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
                     ih /= p.in_up; iw /= p.in_up;
                 }
                 ok = ok & (ih < p.IH) & (iw < p.IW);
-                const long long off = ok ? ((long long)b * p.x_bstride + ((long long)ih * p.IW + iw) * p.Cx + sl * VEC) * ESZ : zoff;
-                pa[j] = (ok ? xbase : zbase) + off;
+                va[j] = ok ? (int)(((long long)b * p.x_bstride + ((long long)ih * p.IW + iw) * p.Cx + sl * VEC) * ESZ) : MSG_DMA_OOB;
             }
         }
     };
+    // one A piece / one B piece of row group j of the K-tile the cursor stands on
+    auto dma_a = [&](int j, int stage) __attribute__((always_inline)) {
+        const bool c_bad = ragged && (ld_chunk * BKE + (slot_phys ^ (sw0 ^ ((j & 1) << 2))) * VEC + VEC > p.Cx);
+        msg_dma16(d_x, lds0 + stage * PSTAGE + (wid_u * 32 + 8 * j) * PROW, c_bad ? MSG_DMA_OOB : va[j], ld_chunk * PROW);
+    };
+    auto dma_b = [&](int j, int stage) __attribute__((always_inline)) {
+        msg_dma16(d_w, lds0 + stage * PSTAGE + PM * PROW + (wid_u * 32 + 8 * j) * PROW, vb[j], min(ld_tile, p.n_iters) * PROW);
+    };
     auto issue = [&](int jlo, int stage) __attribute__((always_inline)) {   // two of this wave's four row groups
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = jlo + jj;
-            const bool c_bad = ragged && (ld_chunk * BKE + (slot_phys ^ (sw0 ^ ((j & 1) << 2))) * VEC + VEC > p.Cx);
-            gptr_t a_addr = pa[j];
-            if (c_bad) a_addr = zbase + zoff;
-            lds_t la = (lds_t)(smem + stage * PSTAGE + (wid_u * 32 + 8 * j) * PROW);
-            __builtin_amdgcn_global_load_lds(a_addr, la, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(pb[j], la + PM * PROW, 16, 0, 0);
-            pa[j] += PROW;
-            pb[j] += PROW;
-        }
+        for (int jj = 0; jj < 2; ++jj) { dma_a(jlo + jj, stage); dma_b(jlo + jj, stage); }
     };
-
     auto issue_one = [&](int j, bool b_rows, int stage) __attribute__((always_inline)) {
-        lds_t la = (lds_t)(smem + stage * PSTAGE + (wid_u * 32 + 8 * j) * PROW);
-        if (!b_rows) {
-            const bool c_bad = ragged && (ld_chunk * BKE + (slot_phys ^ (sw0 ^ ((j & 1) << 2))) * VEC + VEC > p.Cx);
-            gptr_t a_addr = pa[j];
-            if (c_bad) a_addr = zbase + zoff;
-            __builtin_amdgcn_global_load_lds(a_addr, la, 16, 0, 0);
-            pa[j] += PROW;
-        } else {
-            __builtin_amdgcn_global_load_lds(pb[j], la + PM * PROW, 16, 0, 0);
-            pb[j] += PROW;
-        }
+        if (!b_rows) dma_a(j, stage); else dma_b(j, stage);
     };
 
     f32x16 acc[4][2];
@@ -390,6 +374,8 @@ extern "C" int msg_conv2d_fprop_pp_eligible(int B, int IH, int IW, int Cx, int C
     // work on padding) run faster on the 128-wide tile: 256->384 @128^2 532 vs 660 us
     if ((long long)((N + PN - 1) / PN) * PN * 100 > (long long)N * 115) return 0;
     if ((long long)(n_iters + 1) * PROW + 128 > 65536) return 0;
+    // 31-bit buffer offsets: the activations of one launch (of one sample with per-sample weights) and one weight set
+    if ((long long)(per_sample ? 1 : B) * IH * IW * Cx * 2 >= 0x7ffffff0ll || (long long)N * kh * kw * Ck * 2 >= 0x7ffffff0ll) return 0;
     const long long blocks = ((mtot + PM - 1) / PM) * ((N + PN - 1) / PN);
     if (blocks >= (1ll << 31)) return 0;
     if (blocks * (per_sample ? B : 1) < 224) return 0;      // one workgroup per CU: small grids belong to the 128-tile kernel

@@ -40,32 +40,6 @@ constexpr int R3_TB = (R3_KP + 4) * R3_ROW;           // 17 KiB: X segment + nei
 constexpr int R3_STAGE = R3_TA + R3_TB;
 constexpr int R3_OOB = (int)0x80000000;
 
-// LDS-DMA as inline assembly.  Through the builtin the compiler knows that the instruction writes LDS and puts an
-// s_waitcnt vmcnt(0) in front of the next LDS read -- every K-step then waits for the pieces it has just issued, which is
-// the whole point of the ring undone.  Here the waits are placed by hand (counted vmcnt in front of the barrier).
-typedef int r3_desc_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ r3_desc_t r3_make_desc(const char* base) {
-    const unsigned long long a = (unsigned long long)base;
-    r3_desc_t d;
-    d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
-    d[2] = R3_OOB;
-    d[3] = 0x00020000;
-    return d;
-}
-// (m0 is named as clobbered so that the compiler never keeps a value of its own in it across a piece; clang warns that it
-//  is a reserved register -- it has no other use for it in these kernels)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void r3_dma16(r3_desc_t desc, unsigned lds_addr, int voff, int soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"   // (s_nop: one wait state between the scalar write of m0 and the DMA that reads it)
-                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
-#endif
-}
-#pragma clang diagnostic pop
-
-
 // W32: the map is exactly 32 pixels wide -- a K-step is TWO whole image rows; each occupies 34 rows of the X tile (its 32
 // pixels between two zero rows: lanes whose source is out of range), tap kw of pixel p of image row q reads X row 34 q + p + kw.
 // (Round 1's kernel of this file ran v_mfma_f32_32x32x16_bf16 in compiler-scheduled clusters; `git log` has it.)
@@ -180,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
     const char* xbase = (const char*)x + (p.per_sample ? (long long)b * sample_x : 0) +
                         ((long long)(khi - p.pad) * p.W - (W32 ? 0 : 1)) * u_C;
     // (descriptors as four SGPRs for the inline-assembly DMA below: base, no stride, 2^31 records, raw dword format)
-    const r3_desc_t d_gy = r3_make_desc(gbase), d_x = r3_make_desc(xbase);
+    const msg_desc_t d_gy = msg_make_desc(gbase), d_x = msg_make_desc(xbase);
     const unsigned lds0 = (unsigned)(unsigned long long)(r3_lds_t)smem;
 
     f32x4 acc[3][4][4];
@@ -211,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
     auto dma_piece = [&](int q, int stage, bool live) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (q < 4) {
-            r3_dma16(d_gy, lds0 + stage * R3_STAGE + (wid_u + 4 * q) * 1024, live ? voff_gy[q] : R3_OOB, so_gy);
+            msg_dma16(d_gy, lds0 + stage * R3_STAGE + (wid_u + 4 * q) * 1024, live ? voff_gy[q] : R3_OOB, so_gy);
         } else {
             const int j = q - 4;
             if (j == 4 && wid_u != 0) return;
@@ -220,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_row3s_kernel(const bf16_t* 
             if (!W32 && j == 0) off = col_l == 0 ? voff_x0_left : off;
             if (!W32 && j == 4) off = col_l + R3_KP == p.W ? voff_x4_right : off;
             const bool ok = live & (W32 ? (x_q1[j] ? row_ok1 : row_ok) : row_ok);
-            r3_dma16(d_x, la, ok ? off : R3_OOB, so_x);
+            msg_dma16(d_x, la, ok ? off : R3_OOB, so_x);
         }
 #endif
     };

@@ -194,4 +194,34 @@ __device__ __forceinline__ u32x4 act_epilogue_apply(u32x4 raw, const float* bv, 
     return r;
 }
 
+// ---- LDS-DMA as inline assembly (buffer_load_dwordx4 ... offen lds: lane L's 16 bytes land at LDS address m0 + 16 L).
+// Through the builtins the compiler knows that the instruction writes LDS and orders every LDS read that MAY alias behind
+// it with an s_waitcnt vmcnt(0) -- reads through ds_read_tr intrinsics always "may" -- which makes a multi-stage ring a queue
+// of depth zero ("LDS-DMA for the weight gradient").  Here the compiler sees nothing and the waits are
+// the kernel's own counted ones.  The descriptor is four SGPRs: base, no stride, 2^31 - 16 records, raw dword format;
+// an offset of MSG_DMA_OOB (or any offset past the records) reads zeros.
+typedef int msg_desc_t __attribute__((ext_vector_type(4)));
+constexpr int MSG_DMA_OOB = (int)0x80000000;
+__device__ __forceinline__ msg_desc_t msg_make_desc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    msg_desc_t d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    d[2] = 0x7ffffff0;
+    d[3] = 0x00020000;
+    return d;
+}
+// (m0 is named as clobbered so that the compiler never keeps a value of its own in it across a piece; clang warns that it
+//  is a reserved register -- it has no other use for it in these kernels.  s_nop: one wait state between the scalar write of
+//  m0 and the DMA that reads it.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void msg_dma16(msg_desc_t desc, unsigned lds_addr, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
+#endif
+}
+#pragma clang diagnostic pop
+
 #define MSG_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? MSG_OK : MSG_ELAUNCH)

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Times the launches of the training step that run on conv_fprop_pp_kernel (256 x 256 tile, two wave groups in ping-pong),
+with the kernel the dispatcher picked printed beside each.  GPU box:  python tools/pp_probe.py"""
+import math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_stylegan_amd import conv_ops, _lib
+DEV = "cuda:0"
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e-3
+
+
+# (name, batch, in, out columns, input map, kh, stride, pad, pixel_shuffle, per_sample)
+cases = [("1x1 ps 512->2048 @64^2 per-sample", 16, 512, 2048, 64, 1, 1, 0, True, True),
+         ("1x1 ps 512->2048 @32^2 per-sample", 16, 512, 2048, 32, 1, 1, 0, True, True),
+         ("2x2 s2 512->512 256->128 per-sample", 16, 512, 512, 256, 2, 2, 0, False, True),
+         ("3x3 385->768 @32^2 shared", 32, 385, 768, 32, 3, 1, 1, False, False),
+         ("1x1 384->256 @128^2 shared", 32, 384, 256, 128, 1, 1, 0, False, False),
+         ("1x1 384->768 @64^2 shared", 32, 384, 768, 64, 1, 1, 0, False, False),
+         ("3x3 s2 256->256 128->63 shared", 32, 256, 256, 128, 3, 2, 0, False, False)]
+for name, b, i, n, r, k, s, pad, shuf, ps in cases:
+    x = torch.randn(b, i, r, r, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((b, n, i, k, k) if ps else (n, i, k, k), device=DEV) / math.sqrt(i * k * k)
+    wk, ck = conv_ops._relay_fwd(w, torch.bfloat16)
+    oh = (r + 2 * pad - k) // s + 1
+    fn = lambda: conv_ops._launch_fprop(x, wk, ck, None, n, (oh, oh), k, k, s, pad, 1, shuf, ps, i)
+    y = fn()
+    t = timeit(fn)
+    flops = 2.0 * b * oh * oh * n * i * k * k
+    print(f"{name:40s} {t * 1e6:9.1f} us {flops / t / 1e12:8.1f} TFLOP/s", flush=True)
+    del x, w, wk, y

@@ -10,10 +10,15 @@
 //     they swap.  Four s_barrier slots per K-tile keep the two groups in lock-step; the barriers are raw (no implicit
 //     vmcnt(0)), each wave waits for its own DMA pieces exactly once per K-tile, one slot before they are needed.
 //
-// Measured with in-kernel s_memtime stamps (tools/pp_stamps.py): MFMA phase ~600 cycles, fragment-read phase ~370,
-// but issuing a wave's 8 LDS-DMA pieces costs ~850 cycles (~100 per piece), which makes phase A the critical path
-// (K-tile ~4200 cycles vs 2048 ideal).  Spreading the pieces into the MFMA phases is the next step; a first attempt
-// ran out of VGPRs (128 accumulators + 64 fragment registers leave ~60 for everything else).
+// Measured with in-kernel s_memtime stamps (tools/pp_stamps.py; round 4, steady state = the last workgroups of a launch,
+// profiles/r04_pp_stamps.txt, 2x2 stride-2 512 -> 512 @256^2): MFMA phase ~690 cycles, fragment-read phase ~390-470, and issuing
+// a wave's 8 LDS-DMA pieces ~630-680 (~80 per piece with four waves issuing together; ~850 before the pieces were addressed
+// through a buffer descriptor instead of 64 per-lane 64-bit addresses).  Phase A (issue + reads, ~1050) against the other
+// group's MFMA phase (~690) is the critical path: a K-tile takes ~3500 cycles (2048 of MFMA), ~4500 when the tap changes
+// (the new tap's rows come from beyond L2 and two stages leave them one K-tile to land); a workgroup of 32 K-tiles spends
+// 3.8 us before, 67 us in and 5.6 us behind its K loop, at a 1.9 GHz clock.  Spreading the pieces into the MFMA phases:
+// a first attempt ran out of VGPRs (128 accumulators + 64 fragment registers leave ~60 for everything else); four of the
+// eight behind every fourth MFMA of phase B (mfma_half's `dma` argument) measured no different in round 4.
 //
 //   slot (global)      4t        4t+1      4t+2      4t+3      4t+4
 //   group 0 (w<4)    read h0(t)  MFMA h0   read h1   MFMA h1   read h0(t+1) ...
@@ -39,16 +44,36 @@ constexpr int PSTAGE = (PM + PN) * PROW;                  // 64 KiB
 
 __device__ __forceinline__ int pswz(int row, int slot) { return row * PROW + ((slot ^ ((row >> 1) & 7)) << 4); }
 #ifdef MSG_PP_STAMPS
-// diagnostic build only: cycle stamps of K-tile 8 of every wave of the first 256 workgroups (tools/pp_stamps.py)
+// diagnostic build only: cycle stamps of K-tile 8 of every wave of the LAST 256 workgroups of the launch (tools/pp_stamps.py)
 __device__ unsigned long long g_pp_stamps[256 * 8 * 10];
-#define PP_STAMP(k) do { if (t == 8 && blockIdx.x < 256 && blockIdx.z == 0 && lane == 0) { unsigned long long tt; \
+#define PP_STAMP(k) do { if (t == 8 && blockIdx.x + 256 >= gridDim.x && blockIdx.z == gridDim.z - 1 && lane == 0) { unsigned long long tt; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); \
-    g_pp_stamps[(blockIdx.x * 8 + wid_u) * 10 + (k)] = tt; } } while (0)
+    g_pp_stamps[((blockIdx.x + 256 - gridDim.x) * 8 + wid_u) * 10 + (k)] = tt; } } while (0)
 extern "C" int msg_pp_debug_read(void* host_dst, int nbytes) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pp_stamps), nbytes) == hipSuccess ? 0 : -1;
 }
+// shader cycles (s_memtime) and the 100 MHz reference counter (s_memrealtime) at kernel entry (0), at the start (1) and the end
+// (2) of the K loop and at kernel exit (3), every wave of the LAST 256 workgroups of the launch
+__device__ unsigned long long g_pp_clock[256 * 8 * 8];
+#define PP_CLOCK(k) do { if (blockIdx.x + 256 >= gridDim.x && blockIdx.z == gridDim.z - 1 && lane == 0) { unsigned long long tc, tr; \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc), "=s"(tr) :: "memory"); \
+    const unsigned cl_ = blockIdx.x + 256 - gridDim.x; \
+    g_pp_clock[(cl_ * 8 + wid_u) * 8 + 2 * (k)] = tc; g_pp_clock[(cl_ * 8 + wid_u) * 8 + 2 * (k) + 1] = tr; } } while (0)
+// the start of K-tiles 8..23 (their period), same workgroups
+__device__ unsigned long long g_pp_period[256 * 8 * 16];
+#define PP_PERIOD() do { if (t >= 8 && t < 24 && blockIdx.x + 256 >= gridDim.x && blockIdx.z == gridDim.z - 1 && lane == 0) { unsigned long long tt; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); \
+    g_pp_period[((blockIdx.x + 256 - gridDim.x) * 8 + wid_u) * 16 + (t - 8)] = tt; } } while (0)
+extern "C" int msg_pp_period_read(void* host_dst, int nbytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pp_period), nbytes) == hipSuccess ? 0 : -1;
+}
+extern "C" int msg_pp_clock_read(void* host_dst, int nbytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pp_clock), nbytes) == hipSuccess ? 0 : -1;
+}
 #else
 #define PP_STAMP(k) do {} while (0)
+#define PP_CLOCK(k) do {} while (0)
+#define PP_PERIOD() do {} while (0)
 #endif
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); \
                           __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -68,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     const int n0 = (int)(L % p.n_tiles) * PN;
     const int m0 = (int)(L / p.n_tiles) * PM;
     const int bz = blockIdx.z;
+    PP_CLOCK(0);
 
     // ---- LDS-DMA assignment: wave w fills rows 32 w + 8 j + (lane >> 3) of A and of B (j = 0..3).  lane & 7 is the
     // PHYSICAL 16-B slot; the lane fetches the logical slot that the XOR swizzle puts there.  Row coordinates are
@@ -220,9 +246,11 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
     // / A and B-between-MFMAs (group 1) was slower (994 vs 1073 TFLOP/s): an issue costs ~40 cycles between MFMAs but
     // ~150-200 in a read phase that also carries fragment reads, and only group 1 has two MFMA phases inside the window
     // in which the target stage is free.  Kept: all 8 pieces at the top of phase A.
+    PP_CLOCK(1);
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         // ---- phase A: DMA for the next K-tile, fragments of half 0
+        PP_PERIOD();
         PP_STAMP(0);
         if (t + 1 < T) { advance(); issue(0, buf ^ 1); issue(2, buf ^ 1); }
         PP_STAMP(1);
@@ -256,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
         PP_BARRIER();
     }
     if (grp == 0) PP_BARRIER();
+    PP_CLOCK(2);
 
     // ---- epilogue: wave-private 128 x 64 bf16 patch in LDS (16 KiB per wave = all 128 KiB), then 16-B stores.
     // The MFMAs were issued with the operands swapped, so an accumulator block holds the TRANSPOSED product: lane
@@ -359,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(const bf16_t* __r
             for (int e = 0; e < lim; ++e) dst[e] = (bf16_t)(v[pass][e >> 1] >> (16 * (e & 1)));
         }
     }
+    PP_CLOCK(3);
 }
 
 // Which shapes take the large tile (shared by the launcher below and by msg_conv2d_fprop_plan).

@@ -556,8 +556,10 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
                x_bytes < (1ll << 31);
     const bool can_fold = !per_sample && variant != 3 && (long long)B * npix < (1ll << 31);
     // (a folded K loop with uniform-row addressing needs whole samples per K-step or whole K-steps per sample, and
-    //  32-bit offsets over the whole batch; otherwise the folded loop runs on the generic addressing)
-    if (can_fold && uni && !((npix % kp == 0 || kp % npix == 0) && B * gy_bytes < (1ll << 32) && B * x_bytes < (1ll << 32)))
+    //  31-bit offsets over the whole batch -- the SGPR cursor counts against the descriptor's range like the per-lane offset:
+    //  with a 2^32 limit here, samples that start beyond 2 GiB read zeros (tests/test_hip_conv.py, test_conv_above_two_gib...);
+    //  otherwise the folded loop runs on the generic addressing)
+    if (can_fold && uni && !((npix % kp == 0 || kp % npix == 0) && B * gy_bytes < 0x7ffffff0ll && B * x_bytes < 0x7ffffff0ll))
         uni = false;
     // shared weights: fold the batch into K (one sweep over the concatenated pixels of all samples), so that small maps
     // still give every workgroup a long K loop and the slabs to add shrink from B*chunks to `chunks` per element

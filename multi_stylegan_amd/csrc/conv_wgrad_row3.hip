@@ -355,7 +355,9 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     // (the 'same' geometry: horizontal padding 1 is what the shifted-row trick assumes; vertical padding is free)
     const long long gy_bytes = (long long)OH * OW * ldgy * 2, x_bytes = (long long)IH * IW * Cx * 2;
     const long long nb = per_sample ? 1 : B;
-    if (nb * gy_bytes >= (1ll << 32) || nb * x_bytes >= (1ll << 32) || gy_bytes >= (1ll << 31) || x_bytes >= (1ll << 31)) return 0;
+    // (31-bit offsets over everything one descriptor spans -- a sample, or the whole batch when it is folded into K: the SGPR
+    //  cursor counts against the descriptor's range like the per-lane offset)
+    if (nb * gy_bytes >= 0x7ffffff0ll || nb * x_bytes >= 0x7ffffff0ll) return 0;
     Row3Params p{};
     p.B = B; p.H = OH; p.W = OW; p.Cx = Cx; p.I = I; p.ldgy = ldgy; p.O = O; p.ldgw = ldgw;
     p.kh = kh; p.pad = pad;

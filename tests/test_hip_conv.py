@@ -534,6 +534,39 @@ def test_pingpong_kernel_shapes(case):
     assert rel_err(gx.float(), gxr) < 2e-2, "data gradient"
 
 
+@pytest.mark.parametrize("k,o", [(3, 128), (1, 256)], ids=["3x3_512to128", "1x1_512to256"])
+def test_conv_above_two_gib_of_activations(k, o):
+    """Shared-weight convolution over a batch whose activations exceed 2 GiB (33 x 512 x 256 x 256 bf16): the kernels that address
+    their operands through 31-bit buffer offsets (conv_fprop_row3 / conv_fprop_pp / conv_wgrad_row3) must hand the launch to the
+    64-bit-pointer kernels (their eligibility tests), and the result must agree with the same convolution run on slices of the
+    batch that ARE eligible -- forward, data gradient and weight gradient."""
+    from multi_stylegan_amd import conv_ops
+    b, i, r = 33, 512, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(b, i, r, r, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last)
+    assert x.numel() * 2 > (1 << 31)
+    w = torch.randn(o, i, k, k, device=DEV, generator=g) / math.sqrt(i * k * k)
+    geo = conv_ops.Geometry("conv", k, k, 1, k // 2, (r, r), False)
+
+    def run(xs, gys=None):
+        xs = xs.detach().requires_grad_(True)
+        wd = w.detach().requires_grad_(True)
+        y = conv_ops._ConvF.apply(xs, wd, None, geo)
+        gys = torch.ones_like(y) if gys is None else gys
+        gx, gw = torch.autograd.grad(y, (xs, wd), gys)
+        return y.detach(), gx.detach(), gw.detach()
+
+    gy = torch.randn(b, o, r, r, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last)
+    y, gx, gw = run(x, gy)
+    gw_parts = torch.zeros_like(gw)
+    for lo, hi in ((0, 11), (11, 22), (22, 33)):
+        ys, gxs, gws = run(x[lo:hi].contiguous(memory_format=torch.channels_last), gy[lo:hi].contiguous(memory_format=torch.channels_last))
+        assert rel_err(y[lo:hi].float(), ys.float()) < 1e-2, f"forward, samples {lo}..{hi}"
+        assert rel_err(gx[lo:hi].float(), gxs.float()) < 1e-2, f"data gradient, samples {lo}..{hi}"
+        gw_parts += gws
+    assert rel_err(gw, gw_parts) < 1e-3, "weight gradient"
+
+
 @pytest.mark.parametrize("g,b,l,n,k", [(5, 16, 14, 512, 512), (3, 3, 4, 40, 24), (1, 1, 1, 8, 8)])
 def test_grouped_linear_matches_per_layer(g, b, l, n, k):
     """conv_ops.grouped_linear (all style affines in one launch) == the per-layer EqualizedLinear path: values,

@@ -315,6 +315,45 @@ def test_fused_act_full_size_properties():
     assert rel_err(gb, gx.float().sum(dim=(0, 2, 3))) < 2e-3
 
 
+def test_streaming_ops_above_two_gib():
+    """The HBM-bound kernels on a map of more than 2^31 bytes / 2^30 elements ([33, 512, 256, 256] bf16, channels-last): the 4x4
+    blur, the blur with the fused noise / bias / activation stage and the stand-alone activation, forward and backward, must agree
+    with the same op on the first and on the LAST samples alone (the last sample starts beyond 2 GiB: 32-bit offsets anywhere in the
+    path would drop or alias it)."""
+    ops = _ops()
+    b, c, r = 33, 512, 256
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(b, c, r, r, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last)
+    assert x.numel() * 2 > (1 << 31)
+    fir = (torch.outer(torch.tensor([1., 3., 3., 1.]), torch.tensor([1., 3., 3., 1.])) / 64 * 4).to(DEV)
+    bias = torch.randn(c, device=DEV, generator=g)
+    noise = torch.randn(b, 1, r, r, device=DEV, generator=g)
+    nw = torch.tensor([0.3], device=DEV)
+    gy = torch.randn(b, c, r, r, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last)
+
+    def cl(t):
+        return t.contiguous(memory_format=torch.channels_last)
+
+    def run(op, xs, ns, gs):
+        xs = xs.detach().requires_grad_(True)
+        y = op(xs, ns)
+        gx, = torch.autograd.grad(y, xs, gs)
+        return y.detach(), gx.detach()
+
+    cases = {
+        "blur": lambda xs, ns: ops.upfirdn2d(xs, fir, pad=(2, 1)),
+        "blur + noise / bias / activation": lambda xs, ns: ops.blur_bias_act(xs, fir, (2, 1), bias, ns, nw, scale=2 ** 0.5),
+        "noise / bias / activation": lambda xs, ns: ops.fused_bias_noise_leaky_relu(xs, bias, ns, nw, scale=2 ** 0.5),
+    }
+    for name, op in cases.items():
+        y, gx = run(op, x, noise, gy)
+        for lo, hi in ((0, 2), (b - 2, b)):
+            ys, gxs = run(op, cl(x[lo:hi]), noise[lo:hi].contiguous(), cl(gy[lo:hi]))
+            assert torch.equal(y[lo:hi], ys), f"{name}: forward, samples {lo}..{hi}"
+            assert torch.equal(gx[lo:hi], gxs), f"{name}: input gradient, samples {lo}..{hi}"
+        del y, gx
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 17, 8), (2, 33, 1000), (2, 64, 1024), (1, 9, 4096), (5, 520)])
 def test_softmax_rows(dtype, shape):

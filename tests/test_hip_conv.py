@@ -38,6 +38,10 @@ CASES = [  # name, kind, B, I, O, H, W, k, stride, pad
     ("row3_64w_tall", "conv", 2, 24, 40, 70, 64, 3, 1, 1),
     ("row3_512w", "conv", 2, 16, 24, 3, 512, 3, 1, 1),
     ("row3_32w", "conv", 3, 24, 40, 32, 32, 3, 1, 1),                            # two image rows per K-step
+    # K loops of one, two and four K-steps: the three-stage ring's prologue issues three steps whatever the length
+    ("row3_one_step", "conv", 1, 8, 16, 1, 64, 3, 1, 1),
+    ("row3_two_steps", "conv", 1, 16, 8, 1, 128, 3, 1, 1),
+    ("row3_four_steps", "conv", 2, 8, 8, 2, 64, 3, 1, 1),
     ("row3_32w_ragged", "conv", 2, 136, 72, 6, 32, 3, 1, 1),
 ]
 

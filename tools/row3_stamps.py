@@ -11,6 +11,7 @@ from multi_stylegan_amd import _lib, conv_ops
 # "32,128,128,256,0" is the discriminator's 128 -> 128 @256^2 layer on the 128 x 128 tile: 512 MFMA cycles per K-step there)
 b, i, o, r, ps = (int(v) for v in os.environ.get("ROW3_STAMPS_SHAPE", "16,512,512,256,1").split(","))
 k = 3
+mfma_cycles = 2048 if (o >= 256 and o % 256 == 0 and i > 128) else 512     # 256 x 256 tile: 128 MFMAs of 16 cycles per wave and K-step; 128 x 128: 32
 x = torch.randn(b, i, r, r, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
 w = torch.randn((b, o, i, k, k) if ps else (o, i, k, k), device="cuda") / math.sqrt(i * k * k)
 wk, ck = conv_ops._relay_fwd(w, torch.bfloat16)
@@ -32,7 +33,8 @@ for st, label in enumerate(("K-step 9  (kw=0: next activation tile issued)", "K-
     print(label)
     for nm, v, q in zip(names, np.median(d[:, :, st, :].reshape(-1, n), axis=0), np.percentile(d[:, :, st, :].reshape(-1, n), 90, axis=0)):
         print(f"   {nm:48s} median {v:7.0f}   p90 {q:7.0f} cycles")
-    print(f"   whole step: median {np.median(s[:, :, st, 6] - s[:, :, st, 0]):.0f} cycles (2048 MFMA cycles)")
+    print(f"   whole step: median {np.median(s[:, :, st, 6] - s[:, :, st, 0]):.0f} cycles ({mfma_cycles} MFMA cycles per wave"
+          + ("" if o >= 256 else "; two workgroups share the SIMDs: 1024 per K-step pair") + ")")
     for w in range(4):
         print(f"      wave {w}: " + " ".join(f"{v:6.0f}" for v in np.median(d[:, w, st, :], axis=0)))
 print("three steps, start to start:", np.median(s[:, :, 2, 0] - s[:, :, 0, 0]) / 2)

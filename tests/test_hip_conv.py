@@ -538,12 +538,13 @@ def test_pingpong_kernel_shapes(case):
     assert rel_err(gx.float(), gxr) < 2e-2, "data gradient"
 
 
-@pytest.mark.parametrize("k,o", [(3, 128), (1, 256)], ids=["3x3_512to128", "1x1_512to256"])
-def test_conv_above_two_gib_of_activations(k, o):
+@pytest.mark.parametrize("k,o,with_wgrad", [(3, 128, True), (1, 256, False)], ids=["3x3_512to128", "1x1_512to256"])
+def test_conv_above_two_gib_of_activations(k, o, with_wgrad):
     """Shared-weight convolution over a batch whose activations exceed 2 GiB (33 x 512 x 256 x 256 bf16): the kernels that address
-    their operands through 31-bit buffer offsets (conv_fprop_row3 / conv_fprop_pp / conv_wgrad_row3) must hand the launch to the
-    64-bit-pointer kernels (their eligibility tests), and the result must agree with the same convolution run on slices of the
-    batch that ARE eligible -- forward, data gradient and weight gradient."""
+    their operands through 31-bit buffer offsets (conv_fprop_row3 / conv_fprop_pp / conv_wgrad_row3 / conv_wgrad's uniform rows)
+    must hand the launch to the 64-bit-pointer kernels (their eligibility tests), and the result must agree with the same
+    convolution run on slices of the batch that ARE eligible -- forward and data gradient on the first and the LAST samples (the
+    last one starts beyond 2 GiB), the weight gradient as the sum over three thirds of the batch."""
     from multi_stylegan_amd import conv_ops
     b, i, r = 33, 512, 256
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -552,23 +553,27 @@ def test_conv_above_two_gib_of_activations(k, o):
     w = torch.randn(o, i, k, k, device=DEV, generator=g) / math.sqrt(i * k * k)
     geo = conv_ops.Geometry("conv", k, k, 1, k // 2, (r, r), False)
 
-    def run(xs, gys=None):
+    def cl(t):
+        return t.contiguous(memory_format=torch.channels_last)
+
+    def run(xs, gys, want_gw):
         xs = xs.detach().requires_grad_(True)
-        wd = w.detach().requires_grad_(True)
+        wd = w.detach().requires_grad_(want_gw)
         y = conv_ops._ConvF.apply(xs, wd, None, geo)
-        gys = torch.ones_like(y) if gys is None else gys
-        gx, gw = torch.autograd.grad(y, (xs, wd), gys)
-        return y.detach(), gx.detach(), gw.detach()
+        grads = torch.autograd.grad(y, (xs, wd) if want_gw else (xs,), gys)
+        return y.detach(), grads[0].detach(), (grads[1].detach() if want_gw else None)
 
     gy = torch.randn(b, o, r, r, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last)
-    y, gx, gw = run(x, gy)
-    gw_parts = torch.zeros_like(gw)
-    for lo, hi in ((0, 11), (11, 22), (22, 33)):
-        ys, gxs, gws = run(x[lo:hi].contiguous(memory_format=torch.channels_last), gy[lo:hi].contiguous(memory_format=torch.channels_last))
+    y, gx, gw = run(x, gy, with_wgrad)
+    for lo, hi in ((0, 2), (b - 2, b)):
+        ys, gxs, _ = run(cl(x[lo:hi]), cl(gy[lo:hi]), False)
         assert rel_err(y[lo:hi].float(), ys.float()) < 1e-2, f"forward, samples {lo}..{hi}"
         assert rel_err(gx[lo:hi].float(), gxs.float()) < 1e-2, f"data gradient, samples {lo}..{hi}"
-        gw_parts += gws
-    assert rel_err(gw, gw_parts) < 1e-3, "weight gradient"
+    if with_wgrad:
+        gw_parts = torch.zeros_like(gw)
+        for lo, hi in ((0, 11), (11, 22), (22, 33)):
+            gw_parts += run(cl(x[lo:hi]), cl(gy[lo:hi]), True)[2]
+        assert rel_err(gw, gw_parts) < 1e-3, "weight gradient"
 
 
 @pytest.mark.parametrize("g,b,l,n,k", [(5, 16, 14, 512, 512), (3, 3, 4, 40, 24), (1, 1, 1, 8, 8)])

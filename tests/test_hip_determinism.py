@@ -176,6 +176,45 @@ def test_training_iteration_is_bit_reproducible(golden, dtype):
         assert not differing, differing[:8]
 
 
+def test_benchmark_configuration_is_bit_reproducible():
+    """The same 17 training iterations twice at BASELINE configs[1] (256^2, batch 16, bf16 storage; the 16th iteration runs R1 and
+    the path-length regulariser) from the same seeds: parameters, EMA copy and Adam moments bit-identical.  The tiny golden models
+    of the test above never reach the large-tile kernels; this one runs every kernel of the benchmarked step -- the hand-scheduled
+    K loops with their counted s_waitcnt, the LDS-DMA rings, the slab reductions -- where a piece that lands late or a race on an
+    LDS stage shows up as a difference between two runs long before it shows up as a wrong loss (tools/determinism_soak.py: the
+    same over more iterations)."""
+    import hashlib
+    import random
+    import numpy as np
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+
+    def run():
+        torch.manual_seed(7); random.seed(7); np.random.seed(7)
+        gen = m.MultiStyleGANGenerator(generator_config_for_resolution(256))
+        dis = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+        gen.compute_dtype = dis.compute_dtype = torch.bfloat16
+        trainer = m.ModelWrapper(gen, dis, device=torch.device(DEV))
+        trainer.generator_ema.compute_dtype = torch.bfloat16
+        g = torch.Generator(device=DEV).manual_seed(11)
+        for _ in range(17):
+            trainer.train_iteration(torch.rand(16, 2, 3, 256, 256, device=DEV, generator=g))
+        logs = trainer.pop_logs()
+        assert "loss_discriminator_regularization" in logs and "path_length" in logs
+        h = hashlib.sha256()
+        tensors = [p for mod in (trainer.generator, trainer.discriminator, trainer.generator_ema) for p in mod.parameters()]
+        for opt in (trainer.generator_optimizer, trainer.discriminator_optimizer):
+            for st in opt.state.values():
+                tensors += [v for v in st.values() if torch.is_tensor(v)]
+        for t in tensors:
+            h.update(t.detach().float().cpu().numpy().tobytes())
+        return h.hexdigest(), len(tensors)
+
+    (a, na), (b, nb) = run(), run()
+    assert na == nb and na > 300
+    assert a == b
+
+
 def test_gradients_written_into_the_flat_store_equal_accumulated_gradients(golden):
     """dist.grad_destination: the weight / bias gradient kernels write straight into the parameters' slices of the flat
     gradient store (AccumulateGrad then adopts the tensor instead of launching `grad += incoming`).  Same training

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
         a_iw0[j] = ow * p.stride - p.pad;
         // byte offset of tap (0,0) of this row's pixel (may point in front of the image for halo rows: it is only
         // dereferenced for taps that land inside); every other tap is this plus ONE wave-uniform term
-        a_boff[j] = ((long long)b * p.x_bstride + slot_j * VEC +
+        a_boff[j] = ((long long)((DMA && p.per_sample) ? 0 : b) * p.x_bstride + slot_j * VEC +   // (DMA, per-sample: the sample sits in the descriptor's base)
                      ((long long)a_ih0[j] * p.IW + a_iw0[j]) * p.Cx) * (long long)sizeof(T);
         a_slot[j] = slot_j;
     }
@@ -159,6 +159,23 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             const bool ok = n < p.N;
             pb[j] = (ok ? wb : zbase) + (ok ? ((long long)n * taps * p.Ck + a_slot[j] * VEC) * (long long)sizeof(T) : zoff);
             pa[j] = zbase;
+        }
+    }
+    // DMA path: the LDS-DMA pieces are addressed through two buffer descriptors with 32-bit per-lane offsets (msg_dma16; a
+    // descriptor-addressed 1-KiB piece costs the texture-address unit about half of one with 64 per-lane 64-bit addresses --
+    // conv_fprop_pp.hip).  Rows that must read zeros take an out-of-range offset; the launcher keeps tensors >= 2 GiB on the
+    // register-staged instantiation.
+    msg_desc_t d_x = {0, 0, 0, 0}, d_w = {0, 0, 0, 0};
+    unsigned lds0 = 0;
+    int va[4] = {MSG_DMA_OOB, MSG_DMA_OOB, MSG_DMA_OOB, MSG_DMA_OOB}, vb[4] = {MSG_DMA_OOB, MSG_DMA_OOB, MSG_DMA_OOB, MSG_DMA_OOB};
+    if constexpr (DMA) {
+        d_x = msg_make_desc((const char*)x + (p.per_sample ? (long long)bz * p.x_bstride * (long long)sizeof(T) : 0));
+        d_w = msg_make_desc((const char*)w + (p.per_sample ? (long long)bz * p.w_bstride * (long long)sizeof(T) : 0));
+        lds0 = (unsigned)(unsigned long long)(lds_t)smem;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + row_of[j];
+            vb[j] = n < p.N ? (int)(((long long)n * taps * p.Ck + a_slot[j] * VEC) * (long long)sizeof(T)) : MSG_DMA_OOB;
         }
     }
     const bool ragged = (p.Cx % BKE) != 0;          // channel stride not a whole number of 128-B runs
@@ -190,6 +207,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
                     const bool ok = a_ok[j] & ((unsigned)(a_ih0[j] + kh_) < (unsigned)p.IH) &
                                     ((unsigned)(a_iw0[j] + kw_) < (unsigned)p.IW);
                     pa[j] = (ok ? xbase : zbase) + (ok ? a_boff[j] + tap_off : zoff);
+                    if constexpr (DMA) va[j] = ok ? (int)(a_boff[j] + tap_off) : MSG_DMA_OOB;
                 }
             } else {                            // transposed strided conv as a gather with parity holes
 #pragma unroll
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
                     ok = ok & (ihs < p.IH) & (iws < p.IW);
                     const long long off = a_boff[j] + ((long long)(ihs - a_ih0[j]) * p.IW + (iws - a_iw0[j])) * p.Cx * (long long)sizeof(T);
                     pa[j] = (ok ? xbase : zbase) + (ok ? off : zoff);
+                    if constexpr (DMA) va[j] = ok ? (int)off : MSG_DMA_OOB;
                 }
             }
         }
@@ -210,9 +229,9 @@ __global__ __launch_bounds__(256, LEAN ? LEAN : 2) void conv_fprop_kernel(const 
             if (c_bad) a_addr = zbase + zoff;
             if constexpr (DMA) {
                 // wave-uniform LDS destination: rows 32 w + 8 j .. +7 of the stage being filled, lanes in order
-                lds_t la = (lds_t)(smem + dma_stage * STAGE + (wid_u * 32 + 8 * j) * ROWB);
-                __builtin_amdgcn_global_load_lds(a_addr, la, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(pb[j], la + BM * ROWB, 16, 0, 0);
+                const unsigned la = lds0 + dma_stage * STAGE + (wid_u * 32 + 8 * j) * ROWB;
+                msg_dma16(d_x, la, c_bad ? MSG_DMA_OOB : va[j], ld_chunk * ROWB);
+                msg_dma16(d_w, la + BM * ROWB, vb[j], (ld_tap * p.n_chunks + ld_chunk) * ROWB);
             } else {
                 ra[j] = *(gvec_t)a_addr;
                 rb[j] = *(gvec_t)pb[j];
@@ -516,7 +535,9 @@ extern "C" int msg_conv2d_fprop_plan(int dtype, int B, int IH, int IW, int Cx, i
     const int esz = dtype == MSG_BF16 ? 2 : 4;
     const int n_iters = kh * kw * (Ck / (128 / esz));
     static const int variant = msg_tunable("MSG_CONV_VARIANT", 0);
-    return (variant == 1 || (variant == 0 && n_iters >= 12)) ? 1 : 0;
+    const bool fits31 = (long long)(w_batch_stride ? 1 : B) * IH * IW * Cx * esz < 0x7ffffff0ll &&
+                        (long long)N * kh * kw * Ck * esz < 0x7ffffff0ll;
+    return (fits31 && (variant == 1 || (variant == 0 && n_iters >= 8))) ? 1 : 0;
 }
 
 static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, void* y, int dtype,
@@ -622,9 +643,15 @@ static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, vo
     dim3 grid((unsigned)blocks, 1, p.per_sample ? B : 1);
     hipStream_t s = (hipStream_t)stream;
     static const int variant = msg_tunable("MSG_CONV_VARIANT", 0);
-    // staging: LDS-DMA (global_load_lds) for long K sweeps, register staging (two steps in flight) for short ones;
+    // staging: LDS-DMA (descriptor-addressed, msg_dma16) for long K sweeps, register staging (two steps in flight) for short ones;
     // MSG_CONV_VARIANT=1 / 2 forces DMA / registers (A/B measurements)
-    const bool dma = variant == 1 || (variant == 0 && p.n_iters >= 12);
+    // (the DMA instantiation addresses through 31-bit buffer offsets: the activations one descriptor spans -- the batch, or one
+    //  sample with per-sample weights -- and one weight set)
+    const bool fits31 = (long long)(p.per_sample ? 1 : B) * p.x_bstride * esz < 0x7ffffff0ll &&
+                        (long long)N * kh * kw * Ck * esz < 0x7ffffff0ll;
+    // (>= 8 K-steps since the pieces go through descriptors: 1x1 512->128 @64^2, B = 32: 39.3 -> 34.8 us; below that the register-
+    //  staged and lean instantiations stay ahead: 1x1 128->256 @256^2 532 vs 597 us)
+    const bool dma = fits31 && (variant == 1 || (variant == 0 && p.n_iters >= 8));
     static const int lean_max = msg_tunable("MSG_CONV_LEAN", 4);                       // MSG_CONV_LEAN=<n>: lean variant for n_iters <= n (0 = never)
     if (dtype == MSG_BF16) {
         if (!dma && p.n_iters <= lean_max) hipLaunchKernelGGL((conv_fprop_kernel<bf16_t, false, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, bias, p);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Times the launches of the training step that run on conv_fprop_pp_kernel (256 x 256 tile, two wave groups in ping-pong),
-with the kernel the dispatcher picked printed beside each.  GPU box:  python tools/pp_probe.py"""
+"""Times the launches of the training step that run on conv_fprop_pp_kernel (256 x 256 tile, two wave groups in ping-pong) or,
+`python tools/pp_probe.py generic`, on the LDS-DMA instantiation of the 128 x 128 kernel (conv_fprop.hip).
+GPU box:  python tools/pp_probe.py [pp|generic]   (MSG_LIB_VARIANT to compare builds)"""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,6 +30,23 @@ cases = [("1x1 ps 512->2048 @64^2 per-sample", 16, 512, 2048, 64, 1, 1, 0, True,
          ("1x1 384->256 @128^2 shared", 32, 384, 256, 128, 1, 1, 0, False, False),
          ("1x1 384->768 @64^2 shared", 32, 384, 768, 64, 1, 1, 0, False, False),
          ("3x3 s2 256->256 128->63 shared", 32, 256, 256, 128, 3, 2, 0, False, False)]
+generic = [("3x3 1024->1024 @16^2 shared", 32, 1024, 1024, 16, 3, 1, 1, False, False),
+           ("3x3 768->385 @32^2 shared", 32, 768, 385, 32, 3, 1, 1, False, False),
+           ("3x3 s2 128->128 256->127 shared", 32, 128, 128, 256, 3, 2, 0, False, False),
+           ("3x3 512->512 @16^2 per-sample", 16, 512, 512, 16, 3, 1, 1, False, True),
+           ("3x3 512->512 @8^2 per-sample", 16, 512, 512, 8, 3, 1, 1, False, True),
+           ("3x3 512->512 @4^2 per-sample", 16, 512, 512, 4, 3, 1, 1, False, True),
+           ("3x3 s2 384->384 64->31 shared", 32, 384, 384, 64, 3, 2, 0, False, False)]
+short_k = [("1x1 128->256 @256^2 shared", 32, 128, 256, 256, 1, 1, 0, False, False),
+           ("1x1 256->128 @256^2 shared", 32, 256, 128, 256, 1, 1, 0, False, False),
+           ("1x1 128->256 @128^2 shared", 32, 128, 256, 128, 1, 1, 0, False, False),
+           ("1x1 256->384 @128^2 shared", 32, 256, 384, 128, 1, 1, 0, False, False),
+           ("1x1 512->128 @64^2 shared", 32, 512, 128, 64, 1, 1, 0, False, False),
+           ("3x3 64->128 @64^2 shared", 32, 64, 128, 64, 3, 1, 1, False, False)]
+if len(sys.argv) > 1 and sys.argv[1] == "generic":
+    cases = generic
+if len(sys.argv) > 1 and sys.argv[1] == "short":
+    cases = short_k          # (register-staged by default: MSG_CONV_VARIANT=1 in a tuning build forces the LDS-DMA instantiation)
 for name, b, i, n, r, k, s, pad, shuf, ps in cases:
     x = torch.randn(b, i, r, r, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = torch.randn((b, n, i, k, k) if ps else (n, i, k, k), device=DEV) / math.sqrt(i * k * k)

@@ -34,6 +34,8 @@ __device__ __attribute__((aligned(256))) unsigned int g_wgrad_zero_page[64];   /
 
 struct WgradParams {
     int B, IH, IW, Cx, I, OH, OW, ldgy, O;
+    int OWv;                                          // logical row width of the K loop: OW, or (uniform rows on maps like 63 / 127 wide) the next
+                                                      // power of two -- the columns OW..OWv-1 of every row contribute zeros
     int kh, kw, stride, pad, pixel_shuffle;
     int per_sample, chunks_per_sample, pix_per_chunk, split;   // split: this launch writes K-slice slabs (see the reduce)
     int xcd_slices;                                   // 1: one K-slice per XCD (single channel tile), 0: tile-major order
@@ -137,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     const int o0 = (tile / p.i_tiles) * WT, i0 = (tile % p.i_tiles) * WT;
     const int kh_ = tap / p.kw, kw_ = tap - kh_ * p.kw;
     const int b = z / p.chunks_per_sample, chunk = z - b * p.chunks_per_sample;
-    const int npix = p.OH * p.OW;
+    const int owl = p.OWv;                            // logical row width (== p.OW unless the rows are padded, uniform-row addressing only)
+    const int npix = p.OH * owl;
     const int pix0 = chunk * p.pix_per_chunk;
     const int pix1 = min(p.fold ? p.B * npix : npix, pix0 + p.pix_per_chunk);
     const int n_iters = (pix1 - pix0 + KP - 1) / KP;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     // K-step stride in (sample, row, column) units; without folding a step never leaves its sample
     const int step_b = p.fold ? KP / npix : 0;
     const int step_rem = KP - step_b * npix;
-    const int step_h = step_rem / p.OW, step_w = step_rem % p.OW;
+    const int step_h = step_rem / owl, step_w = step_rem % owl;
     const int gyw = p.pixel_shuffle ? 2 * p.OW : p.OW, gyh = p.pixel_shuffle ? 2 * p.OH : p.OH;
     const int oc = o0 + ch * VEC, ic = i0 + ch * VEC;
     const bool oc_ok = oc + VEC <= p.ldgy, ic_ok = ic + VEC <= p.Cx;
@@ -169,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
         pix[j] = pix0 + r0 + (DMA ? 4 * RPW : RSTEP) * j;
         bq[j] = p.fold ? pix[j] / npix : 0;           // (folded K: the pixel index runs over all samples)
         const int rem = pix[j] - bq[j] * npix;
-        oh[j] = rem / p.OW;
-        ow[j] = rem - oh[j] * p.OW;
+        oh[j] = rem / owl;
+        ow[j] = rem - oh[j] * owl;
     }
     int st_off[NLD];
 #pragma unroll
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     const int u_xkh = p.pixel_shuffle ? 0 : kh_ - p.pad, u_xkw = p.pixel_shuffle ? 0 : kw_ - p.pad;
     const int u_L = p.ldgy * (int)sizeof(T), u_C = p.Cx * (int)sizeof(T);
     __amdgpu_buffer_rsrc_t rs_gy, rs_x;
-    int voff_gy[NLD], voff_x[NLD], xh_c[NLD], xw_c[NLD];
+    int voff_gy[NLD], voff_x[NLD], xh_c[NLD], xw_c[NLD], dw_c[NLD];
     int row_s = 0, col_s = 0, b_s = 0, pix_s = pix0;
     const int gy_sample = gyh * gyw * u_L, x_sample = p.IH * p.IW * u_C;      // bytes (host guarantees < 2^31)
     if constexpr (UNI) {
@@ -195,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             const int r = r0 + RSTEP * j;
             const int db = p.fold ? r / npix : 0;       // (only maps smaller than a K-step put several samples in one)
             const int rr = r - db * npix;
-            const int dh = rr / p.OW, dw = rr - dh * p.OW;
+            const int dh = rr / owl, dw = rr - dh * owl;
+            dw_c[j] = dw;
             voff_gy[j] = oc_ok ? db * gy_sample + (dh * u_gs * gyw + dw * u_gs) * u_L + oc * (int)sizeof(T) : BUF_OOB;
             voff_x[j] = ic_ok ? db * x_sample + (dh * u_xs * p.IW + dw * u_xs) * u_C + ic * (int)sizeof(T) : BUF_OOB;
             xh_c[j] = dh * u_xs;
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
         }
         b_s = p.fold ? pix0 / npix : 0;
         const int in_sample = pix0 - b_s * npix;
-        row_s = in_sample / p.OW;
-        col_s = in_sample - row_s * p.OW;
+        row_s = in_sample / owl;
+        col_s = in_sample - row_s * owl;
     }
 
     f32x16 acc[2][2];
@@ -227,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             const int xh_s = row_s * u_xs + u_xkh, xw_s = col_s * u_xs + u_xkw;
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
-                const bool pok = r0 + RSTEP * j < rem;
+                // (padded rows: the columns OW..OWv-1 are not pixels of the map)
+                const bool pok = (r0 + RSTEP * j < rem) & (col_s + dw_c[j] < p.OW);
                 const bool xok = pok & ((unsigned)(xh_s + xh_c[j]) < (unsigned)p.IH) &
                                  ((unsigned)(xw_s + xw_c[j]) < (unsigned)p.IW);
                 ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gy, pok ? voff_gy[j] : BUF_OOB, so_gy, 0);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             b_s += step_b;
             row_s += step_h;
             col_s += step_w;
-            if (col_s >= p.OW) { col_s -= p.OW; ++row_s; }
+            if (col_s >= owl) { col_s -= owl; ++row_s; }
             if (p.fold && row_s >= p.OH) { row_s -= p.OH; ++b_s; }
             return;
         }
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             bq[j] += step_b;
             oh[j] += step_h;
             ow[j] += step_w;
-            if (ow[j] >= p.OW) { ow[j] -= p.OW; ++oh[j]; }
+            if (ow[j] >= owl) { ow[j] -= owl; ++oh[j]; }
             if (p.fold && oh[j] >= p.OH) { oh[j] -= p.OH; ++bq[j]; }
         }
     };
@@ -544,23 +549,42 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.pixel_shuffle = pixel_shuffle;
     p.per_sample = per_sample;
     p.chunks_per_sample = k_chunks;
-    const int npix = OH * OW;
     const int kp = dtype == MSG_BF16 ? 64 : 32;
-    p.pix_per_chunk = (((npix + k_chunks - 1) / k_chunks + kp - 1) / kp) * kp;
-    long long zs = (long long)B * k_chunks;
-    // uniform-row addressing: K-steps map onto whole rows / whole row fragments and per-sample tensors fit 31-bit offsets
+    // uniform-row addressing: K-steps map onto whole rows / whole row fragments and per-sample tensors fit 31-bit offsets.
+    // Maps one or a few columns short of a power of two -- the discriminator's stride-2 convolutions give 127, 63, 31 -- take it
+    // too, on rows padded to that power of two: the K loop runs over OH x OWv logical pixels, the padding columns read zeros
+    // (<= 1/16 of the MFMA work), and the ~170 vector instructions per K-step of the generic incremental addressing are gone
+    // (these weight gradients ran at 480-490 TFLOP/s; MSG_WGRAD_PAD_ROWS=0: off).
     static const int variant = msg_tunable("MSG_CONV_VARIANT", 0);
+    static const int pad_rows = msg_tunable("MSG_WGRAD_PAD_ROWS", 1);
     const long long gy_bytes = (long long)(pixel_shuffle ? 4 : 1) * OH * OW * ldgy * esz;
     const long long x_bytes = (long long)IH * IW * Cx * esz;
-    bool uni = variant != 2 && variant != 1 && (kp % OW == 0 || OW % kp == 0) && gy_bytes < (1ll << 31) &&
-               x_bytes < (1ll << 31);
-    const bool can_fold = !per_sample && variant != 3 && (long long)B * npix < (1ll << 31);
-    // (a folded K loop with uniform-row addressing needs whole samples per K-step or whole K-steps per sample, and
-    //  31-bit offsets over the whole batch -- the SGPR cursor counts against the descriptor's range like the per-lane offset:
-    //  with a 2^32 limit here, samples that start beyond 2 GiB read zeros (tests/test_hip_conv.py, test_conv_above_two_gib...);
-    //  otherwise the folded loop runs on the generic addressing)
-    if (can_fold && uni && !((npix % kp == 0 || kp % npix == 0) && B * gy_bytes < 0x7ffffff0ll && B * x_bytes < 0x7ffffff0ll))
-        uni = false;
+    int owv = OW;
+    if (pad_rows && !pixel_shuffle && !(kp % OW == 0 || OW % kp == 0)) {
+        int v = 1;
+        while (v < OW) v <<= 1;
+        if ((long long)v * 15 <= (long long)OW * 16) owv = v;
+    }
+    const bool can_fold0 = !per_sample && variant != 3;
+    auto uni_ok = [&](int wl) {
+        const long long np = (long long)OH * wl;
+        bool u = variant != 2 && variant != 1 && (kp % wl == 0 || wl % kp == 0) && gy_bytes < (1ll << 31) && x_bytes < (1ll << 31);
+        // (a folded K loop with uniform-row addressing needs whole samples per K-step or whole K-steps per sample, and
+        //  31-bit offsets over the whole batch -- the SGPR cursor counts against the descriptor's range like the per-lane offset:
+        //  with a 2^32 limit here, samples that start beyond 2 GiB read zeros (tests/test_hip_conv.py, test_conv_above_two_gib...);
+        //  otherwise the folded loop runs on the generic addressing)
+        if (can_fold0 && B * np < (1ll << 31) && u &&
+            !((np % kp == 0 || kp % np == 0) && B * gy_bytes < 0x7ffffff0ll && B * x_bytes < 0x7ffffff0ll))
+            u = false;
+        return u;
+    };
+    bool uni = uni_ok(owv);
+    if (!uni && owv != OW) { owv = OW; uni = uni_ok(OW); }        // (padding did not buy uniform rows: the map as it is)
+    p.OWv = owv;
+    const int npix = OH * owv;                                     // logical pixels per sample
+    p.pix_per_chunk = (((npix + k_chunks - 1) / k_chunks + kp - 1) / kp) * kp;
+    long long zs = (long long)B * k_chunks;
+    const bool can_fold = can_fold0 && (long long)B * npix < (1ll << 31);
     // shared weights: fold the batch into K (one sweep over the concatenated pixels of all samples), so that small maps
     // still give every workgroup a long K loop and the slabs to add shrink from B*chunks to `chunks` per element
     if (can_fold) {

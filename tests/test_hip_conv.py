@@ -38,6 +38,13 @@ CASES = [  # name, kind, B, I, O, H, W, k, stride, pad
     ("row3_64w_tall", "conv", 2, 24, 40, 70, 64, 3, 1, 1),
     ("row3_512w", "conv", 2, 16, 24, 3, 512, 3, 1, 1),
     ("row3_32w", "conv", 3, 24, 40, 32, 32, 3, 1, 1),                            # two image rows per K-step
+    # maps a column or two short of a power of two (the discriminator's stride-2 outputs: 127, 63, 31, 15): the weight-gradient
+    # kernel's uniform rows on rows padded to that power of two (folded batch: 63 / 127 only), the others as they are
+    ("s2_to_63", "conv", 2, 8, 16, 127, 127, 3, 2, 0),
+    ("s2_to_31_b3", "conv", 3, 16, 8, 63, 63, 3, 2, 0),
+    ("s2_to_15", "conv", 2, 8, 8, 31, 31, 3, 2, 0),
+    ("same_63w", "conv", 2, 16, 24, 5, 63, 3, 1, 1),
+    ("1x1_127w", "conv", 2, 24, 8, 3, 127, 1, 1, 0),
     # K loops of one, two and four K-steps: the three-stage ring's prologue issues three steps whatever the length
     ("row3_one_step", "conv", 1, 8, 16, 1, 64, 3, 1, 1),
     ("row3_two_steps", "conv", 1, 16, 8, 1, 128, 3, 1, 1),

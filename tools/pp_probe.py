@@ -29,7 +29,10 @@ cases = [("1x1 ps 512->2048 @64^2 per-sample", 16, 512, 2048, 64, 1, 1, 0, True,
          ("3x3 385->768 @32^2 shared", 32, 385, 768, 32, 3, 1, 1, False, False),
          ("1x1 384->256 @128^2 shared", 32, 384, 256, 128, 1, 1, 0, False, False),
          ("1x1 384->768 @64^2 shared", 32, 384, 768, 64, 1, 1, 0, False, False),
-         ("3x3 s2 256->256 128->63 shared", 32, 256, 256, 128, 3, 2, 0, False, False)]
+         ("3x3 s2 256->256 128->63 shared", 32, 256, 256, 128, 3, 2, 0, False, False),
+         # data gradients of the stride-2 convolutions in their parity form (2x2 taps, 4 I pixel-shuffled columns): 8 / 16 K-tiles
+         ("2x2 ps 128->512 @127^2 shared", 32, 128, 512, 127, 2, 1, 1, True, False),
+         ("2x2 ps 256->1024 @63^2 shared", 32, 256, 1024, 63, 2, 1, 1, True, False)]
 generic = [("3x3 1024->1024 @16^2 shared", 32, 1024, 1024, 16, 3, 1, 1, False, False),
            ("3x3 768->385 @32^2 shared", 32, 768, 385, 32, 3, 1, 1, False, False),
            ("3x3 s2 128->128 256->127 shared", 32, 128, 128, 256, 3, 2, 0, False, False),

@@ -29,6 +29,48 @@ __device__ __forceinline__ void linear_fprop_body(const float* __restrict__ x, l
     if (n >= N) return;
     const float* wn = w + (size_t)n * K;
     const float bv = bias ? bias_gain * bias[n] : 0.f;
+    // 16-byte loads where the rows allow them (K, ldx multiples of 4, 16-byte aligned bases -- every layer of the models): a
+    // quarter of the load instructions on the one wave's latency chain that bounds this kernel (M = 16, N = K = 512: 17 us
+    // with 4-byte loads).
+    if (((K | (int)(ldx & 3)) & 3) == 0 && ((((size_t)x) | ((size_t)w)) & 15u) == 0) {
+        constexpr int KV = LIN_KC / 256;                          // float4 per lane and chunk
+        for (int m0 = 0; m0 < M; m0 += LIN_MB) {
+            float acc[LIN_MB];
+#pragma unroll
+            for (int mm = 0; mm < LIN_MB; ++mm) acc[mm] = 0.f;
+            for (int kc = 0; kc < K; kc += LIN_KC) {
+                f32x4 wr[KV];
+#pragma unroll
+                for (int j = 0; j < KV; ++j) {
+                    const int k = kc + 4 * (lane + 64 * j);
+                    wr[j] = k < K ? *reinterpret_cast<const f32x4*>(wn + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int mm = 0; mm < LIN_MB; ++mm) {
+                    const int m = m0 + mm;
+                    if (m >= M) break;
+                    const float* xm = x + (size_t)m * ldx;
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < KV; ++j) {
+                        const int k = kc + 4 * (lane + 64 * j);
+                        const f32x4 xv = k < K ? *reinterpret_cast<const f32x4*>(xm + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        a = fmaf(wr[j][0], xv[0], a); a = fmaf(wr[j][1], xv[1], a);
+                        a = fmaf(wr[j][2], xv[2], a); a = fmaf(wr[j][3], xv[3], a);
+                    }
+                    acc[mm] += a;
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < LIN_MB; ++mm) {
+                const int m = m0 + mm;
+                if (m >= M) break;
+                const float tot = wave_sum(acc[mm]);
+                if (lane == 0) y[(size_t)m * N + n] = gain * tot + bv;
+            }
+        }
+        return;
+    }
     for (int m0 = 0; m0 < M; m0 += LIN_MB) {
         float acc[LIN_MB];
 #pragma unroll

@@ -34,8 +34,9 @@ __device__ __attribute__((aligned(256))) unsigned int g_wgrad_zero_page[64];   /
 
 struct WgradParams {
     int B, IH, IW, Cx, I, OH, OW, ldgy, O;
-    int OWv;                                          // logical row width of the K loop: OW, or (uniform rows on maps like 63 / 127 wide) the next
-                                                      // power of two -- the columns OW..OWv-1 of every row contribute zeros
+    int OWv, OHv;                                     // logical row width / row count of the K loop: OW x OH, or (uniform rows on maps like
+                                                      // 127, 63, 31, 15 wide) the next power of two / the next even count -- the logical pixels
+                                                      // outside the map contribute zeros
     int kh, kw, stride, pad, pixel_shuffle;
     int per_sample, chunks_per_sample, pix_per_chunk, split;   // split: this launch writes K-slice slabs (see the reduce)
     int xcd_slices;                                   // 1: one K-slice per XCD (single channel tile), 0: tile-major order
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
     const int kh_ = tap / p.kw, kw_ = tap - kh_ * p.kw;
     const int b = z / p.chunks_per_sample, chunk = z - b * p.chunks_per_sample;
     const int owl = p.OWv;                            // logical row width (== p.OW unless the rows are padded, uniform-row addressing only)
-    const int npix = p.OH * owl;
+    const int ohl = p.OHv;                            // logical rows per sample (== p.OH unless padded)
+    const int npix = ohl * owl;
     const int pix0 = chunk * p.pix_per_chunk;
     const int pix1 = min(p.fold ? p.B * npix : npix, pix0 + p.pix_per_chunk);
     const int n_iters = (pix1 - pix0 + KP - 1) / KP;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 // (padded rows: the columns OW..OWv-1 are not pixels of the map)
-                const bool pok = (r0 + RSTEP * j < rem) & (col_s + dw_c[j] < p.OW);
+                const bool pok = (r0 + RSTEP * j < rem) & (col_s + dw_c[j] < p.OW) & (row_s * u_xs + xh_c[j] < p.OH * u_xs);
                 const bool xok = pok & ((unsigned)(xh_s + xh_c[j]) < (unsigned)p.IH) &
                                  ((unsigned)(xw_s + xw_c[j]) < (unsigned)p.IW);
                 ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gy, pok ? voff_gy[j] : BUF_OOB, so_gy, 0);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             row_s += step_h;
             col_s += step_w;
             if (col_s >= owl) { col_s -= owl; ++row_s; }
-            if (p.fold && row_s >= p.OH) { row_s -= p.OH; ++b_s; }
+            if (p.fold && row_s >= ohl) { row_s -= ohl; ++b_s; }
             return;
         }
 #pragma unroll
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict_
             oh[j] += step_h;
             ow[j] += step_w;
             if (ow[j] >= owl) { ow[j] -= owl; ++oh[j]; }
-            if (p.fold && oh[j] >= p.OH) { oh[j] -= p.OH; ++bq[j]; }
+            if (p.fold && oh[j] >= ohl) { oh[j] -= ohl; ++bq[j]; }
         }
     };
     auto park = [&](int stage) __attribute__((always_inline)) {
@@ -559,15 +561,19 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
     static const int pad_rows = msg_tunable("MSG_WGRAD_PAD_ROWS", 1);
     const long long gy_bytes = (long long)(pixel_shuffle ? 4 : 1) * OH * OW * ldgy * esz;
     const long long x_bytes = (long long)IH * IW * Cx * esz;
-    int owv = OW;
+    int owv = OW, ohv = OH;
     if (pad_rows && !pixel_shuffle && !(kp % OW == 0 || OW % kp == 0)) {
         int v = 1;
         while (v < OW) v <<= 1;
-        if ((long long)v * 15 <= (long long)OW * 16) owv = v;
+        if ((long long)v * 15 <= (long long)OW * 16) {
+            owv = v;
+            // (several padded rows per K-step: a whole number of K-steps per sample needs the row count rounded up too)
+            if (v < kp && (OH * v) % kp) ohv = ((OH * v + kp - 1) / kp * kp) / v;
+        }
     }
     const bool can_fold0 = !per_sample && variant != 3;
     auto uni_ok = [&](int wl) {
-        const long long np = (long long)OH * wl;
+        const long long np = (long long)(wl == OW ? OH : ohv) * wl;
         bool u = variant != 2 && variant != 1 && (kp % wl == 0 || wl % kp == 0) && gy_bytes < (1ll << 31) && x_bytes < (1ll << 31);
         // (a folded K loop with uniform-row addressing needs whole samples per K-step or whole K-steps per sample, and
         //  31-bit offsets over the whole batch -- the SGPR cursor counts against the descriptor's range like the per-lane offset:
@@ -580,8 +586,10 @@ static int wgrad_impl(const void* gy, const void* x, float* gw, int dtype,
     };
     bool uni = uni_ok(owv);
     if (!uni && owv != OW) { owv = OW; uni = uni_ok(OW); }        // (padding did not buy uniform rows: the map as it is)
+    if (owv == OW) ohv = OH;
     p.OWv = owv;
-    const int npix = OH * owv;                                     // logical pixels per sample
+    p.OHv = ohv;
+    const int npix = ohv * owv;                                    // logical pixels per sample
     p.pix_per_chunk = (((npix + k_chunks - 1) / k_chunks + kp - 1) / kp) * kp;
     long long zs = (long long)B * k_chunks;
     const bool can_fold = can_fold0 && (long long)B * npix < (1ll << 31);

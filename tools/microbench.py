@@ -81,6 +81,9 @@ def bench_conv(args):
              ("3x3 256->256 128^2 shared", "conv", 256, 256, 128, 3, 1, 1, False),
              ("3x3 1024->1024 16^2 shared", "conv", 1024, 1024, 16, 3, 1, 1, False),
              ("3x3 s2 128->128 256->127 shared", "conv", 128, 128, 256, 3, 2, 0, False),
+             ("3x3 s2 256->256 128->63 shared", "conv", 256, 256, 128, 3, 2, 0, False),
+             ("3x3 s2 384->384 64->31 shared", "conv", 384, 384, 64, 3, 2, 0, False),
+             ("3x3 s2 768->768 32->15 shared", "conv", 768, 768, 32, 3, 2, 0, False),
              ("D 3x3 256->128 256^2 shared", "conv", 256, 128, 256, 3, 1, 1, False),
              ("D 3x3 128->256 256^2 shared", "conv", 128, 256, 256, 3, 1, 1, False),
              ("D 3x3 384->256 128^2 shared", "conv", 384, 256, 128, 3, 1, 1, False),

@@ -21,6 +21,9 @@ constexpr int LIN_KC = 1024;       // K elements whose weights one wave keeps in
 
 // (Measured alternative: 4 output columns per wave to cut the L1/L2 re-reads of x by 4 -- 2x SLOWER at M=16, N=K=512:
 //  the kernel is bound by the latency chain of one wave, not by traffic, so more, lighter waves win.)
+// (Round 4: 16-byte loads -- a lane takes four consecutive k -- cut a launch from 10.9 to 7.9 us, but regroup the fp32 sum, and
+//  the path-length regulariser's second-order gradients, which amplify the mapping network's last bits, moved from 9e-4 to
+//  3.7e-3 of the oracle's on one parameter (gate 2e-3, tests/test_hip_models.py).  Not kept: 0.07 ms per iteration.)
 __device__ __forceinline__ void linear_fprop_body(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ y,
                                                   int M, int N, int K, float gain, float bias_gain) {
@@ -29,48 +32,6 @@ __device__ __forceinline__ void linear_fprop_body(const float* __restrict__ x, l
     if (n >= N) return;
     const float* wn = w + (size_t)n * K;
     const float bv = bias ? bias_gain * bias[n] : 0.f;
-    // 16-byte loads where the rows allow them (K, ldx multiples of 4, 16-byte aligned bases -- every layer of the models): a
-    // quarter of the load instructions on the one wave's latency chain that bounds this kernel (M = 16, N = K = 512: 17 us
-    // with 4-byte loads).
-    if (((K | (int)(ldx & 3)) & 3) == 0 && ((((size_t)x) | ((size_t)w)) & 15u) == 0) {
-        constexpr int KV = LIN_KC / 256;                          // float4 per lane and chunk
-        for (int m0 = 0; m0 < M; m0 += LIN_MB) {
-            float acc[LIN_MB];
-#pragma unroll
-            for (int mm = 0; mm < LIN_MB; ++mm) acc[mm] = 0.f;
-            for (int kc = 0; kc < K; kc += LIN_KC) {
-                f32x4 wr[KV];
-#pragma unroll
-                for (int j = 0; j < KV; ++j) {
-                    const int k = kc + 4 * (lane + 64 * j);
-                    wr[j] = k < K ? *reinterpret_cast<const f32x4*>(wn + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int mm = 0; mm < LIN_MB; ++mm) {
-                    const int m = m0 + mm;
-                    if (m >= M) break;
-                    const float* xm = x + (size_t)m * ldx;
-                    float a = 0.f;
-#pragma unroll
-                    for (int j = 0; j < KV; ++j) {
-                        const int k = kc + 4 * (lane + 64 * j);
-                        const f32x4 xv = k < K ? *reinterpret_cast<const f32x4*>(xm + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        a = fmaf(wr[j][0], xv[0], a); a = fmaf(wr[j][1], xv[1], a);
-                        a = fmaf(wr[j][2], xv[2], a); a = fmaf(wr[j][3], xv[3], a);
-                    }
-                    acc[mm] += a;
-                }
-            }
-#pragma unroll
-            for (int mm = 0; mm < LIN_MB; ++mm) {
-                const int m = m0 + mm;
-                if (m >= M) break;
-                const float tot = wave_sum(acc[mm]);
-                if (lane == 0) y[(size_t)m * N + n] = gain * tot + bv;
-            }
-        }
-        return;
-    }
     for (int m0 = 0; m0 < M; m0 += LIN_MB) {
         float acc[LIN_MB];
 #pragma unroll

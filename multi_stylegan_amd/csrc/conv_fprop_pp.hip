@@ -18,7 +18,9 @@
 // (the new tap's rows come from beyond L2 and two stages leave them one K-tile to land); a workgroup of 32 K-tiles spends
 // 3.8 us before, 67 us in and 5.6 us behind its K loop, at a 1.9 GHz clock.  Spreading the pieces into the MFMA phases:
 // a first attempt ran out of VGPRs (128 accumulators + 64 fragment registers leave ~60 for everything else); four of the
-// eight behind every fourth MFMA of phase B (mfma_half's `dma` argument) measured no different in round 4.
+// eight behind every fourth MFMA of phase B (mfma_half's `dma` argument) measured no different in round 4; nor did a row
+// assignment that gives every wave 16 rows of the half read first and 16 of the half read three slots later, with the
+// latter's two pieces moved to phase C behind counted waits (six urgent + two deferred pieces per wave: bit-correct, same time).
 //
 //   slot (global)      4t        4t+1      4t+2      4t+3      4t+4
 //   group 0 (w<4)    read h0(t)  MFMA h0   read h1   MFMA h1   read h0(t+1) ...

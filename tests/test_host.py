@@ -319,6 +319,31 @@ def test_cut_mix_gate_is_rank_consistent_gloo_world2():
     assert q.get(timeout=5) == "ok"
 
 
+def test_kernel_plans_respect_the_31_bit_offset_limits():
+    """Host-side dispatch only (no launch): the kernels that address their operands through buffer descriptors -- 31-bit
+    offsets -- must not be planned for tensors of 2 GiB or more (the launch then belongs to the 64-bit-pointer instantiation),
+    and the weight-gradient planner must accept the maps one column short of a power of two that it now runs on padded rows.
+    The GPU side of the same limits: tests/test_hip_conv.py::test_conv_above_two_gib_of_activations."""
+    from multi_stylegan_amd import _lib
+    from multi_stylegan_amd.build import build
+    build(verbose=False)
+    lib = _lib.lib()
+    bf16 = _lib.MSG_BF16
+    plan = lambda b, c, n, hw, k, ws: lib.msg_conv2d_fprop_plan(bf16, b, hw, hw, c, c, hw, hw, n, k, k, ws)
+    # 3x3 512 -> 512 @256^2: per-sample weights (one sample per descriptor) and a shared-weight batch of 0.5 GiB: the 256 x 256 tile
+    assert plan(16, 512, 512, 256, 3, 512 * 512 * 9) == 3
+    assert plan(8, 512, 512, 256, 3, 0) == 3
+    # the same layer over 33 samples with SHARED weights: 2.2 GiB behind one descriptor -> register-staged 128 x 128 kernel
+    assert plan(33, 512, 512, 256, 3, 0) == 0
+    # 1x1 512 -> 256 (ping-pong kernel's territory: plan 2) likewise
+    assert plan(16, 512, 256, 256, 1, 0) == 2
+    assert plan(33, 512, 256, 256, 1, 0) == 0
+    # weight-gradient workspace queries (plan only) on the discriminator's stride-2 outputs: 127, 63, 31, 15 wide
+    for c, ihw, ohw in ((128, 256, 127), (256, 128, 63), (384, 64, 31), (768, 32, 15)):
+        need = lib.msg_conv2d_wgrad_workspace(bf16, 32, ihw, ihw, c, c, ohw, ohw, c, c, c, 3, 3, 2, 0, 0, 0, 1)
+        assert need > 0 and need % (c * 9 * c) == 0, (c, ohw, need)          # whole slabs of O x taps x ldgw floats
+
+
 def test_non_square_conv_geometry_is_refused():
     """EqualizedConv2d keeps the reference's (h, w) tuple arguments; a non-square stride / padding must raise instead
     of being computed with the first entry (round-1 advice)."""

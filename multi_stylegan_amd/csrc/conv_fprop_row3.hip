@@ -551,9 +551,11 @@ extern "C" int msg_conv2d_fprop_row3_eligible(int B, int IH, int IW, int Cx, int
     int hn = row3_tile_columns(N);
     // short K (few channels): a 256 x 256 tile's prologue and epilogue are not amortised and nothing overlaps them with one
     // workgroup per CU; the 128 x 128 tile runs two.  MSG_CONV_ROW3_SHORTK = largest Ck that prefers the small tile.
-    // (round 3: 128 -- 3x3 128->256 @256^2, B=32: 632 -> 609 us on the small tile.  Round 4, after the large tile's prologue and
-    //  epilogue lost a third of their instructions: B=32 1 166 vs 1 077 us, B=16 630 vs 594 us IN FAVOUR of the large tile: 0 = off)
-    static const int shortk = msg_tunable("MSG_CONV_ROW3_SHORTK", 0);
+    // (round 3: 3x3 128->256 @256^2, B=32: 632 -> 609 us on the small tile.  Round 4, after the large tile's prologue and epilogue
+    //  lost a third of their instructions, the same launch in isolation: B=32 1 166 vs 1 077 us, B=16 630 vs 594 us in favour of the
+    //  LARGE tile; in the training step the two launches per iteration it concerns are 0.13 ms -- below what two runs on one box
+    //  differ by -- and were left where they are)
+    static const int shortk = msg_tunable("MSG_CONV_ROW3_SHORTK", 128);
     if (hn == 256 && Ck <= shortk && N % 128 == 0) hn = 128;
     if (OW == 32 && w32 && N >= 128 && (long long)((N + 127) / 128) * 128 * 100 <= (long long)N * 115) hn = 128;
     if (!hn || (hn == 128 && !narrow) || N % hn) return 0;

@@ -482,6 +482,10 @@ def main():
             "clock_iterations": clock_iterations, "peak_mem_GiB": round(peak_mem, 2),
             "losses": {k: round(v, 5) for k, v in last.items()},
             "h2d": h2d,
+            # which shared library produced the numbers: the product build unless MSG_LIB_VARIANT named an A/B or diagnostic
+            # build (tools only; a line that carries a variant is not the product's)
+            "library": {"file": os.path.basename(_lib.LIB_PATH), "abi": int(_lib.lib().msg_abi_version()),
+                        "variant": os.environ.get("MSG_LIB_VARIANT") or None},
         }
         if world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and not args.rehearse_on_one_gpu:
             del trainer, gen, dis, real

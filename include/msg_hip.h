@@ -37,7 +37,13 @@ enum { MSG_F32 = 0, MSG_BF16 = 1, MSG_F16 = 2, MSG_F64 = 3, MSG_F32_SPLIT = 4 };
  * bf16 matrix rate, this at a sixth).  Workspaces and layouts are those of MSG_F32.  (A three-product form on (hi, lo) splits
  * was built too: 16 mantissa bits per operand move the training step's gradients by up to 1e-2 -- not a parity path; removed.) */
 
-/* Library/ABI version and the code-object architecture it was built for ("gfx950"). */
+/* Library/ABI version and the code-object architecture it was built for ("gfx950").  A caller compiled against this header
+ * compares msg_abi_version() with MSG_ABI_VERSION before its first launch (workspace sizes and argument lists change with it):
+ *   3  deterministic reductions (workspace arguments of msg_conv2d_wgrad, msg_bias_act_backward)
+ *   4  msg_scale_reduce_channels / msg_scale_bias_act removed; msg_rgb_skip_merge(+_backward) and MSG_F32_SPLIT added;
+ *      msg_affine_warp's backward workspace is B*C*H*W + 1 words (the last one is the poison word)
+ *   5  round-5 entries (marked "ABI 5" below) */
+#define MSG_ABI_VERSION 5
 int msg_abi_version(void);
 const char* msg_build_arch(void);
 /* Text for a MSG_E* code. */

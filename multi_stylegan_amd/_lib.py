@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmsg_hip" + ("_" + os.environ["MSG_LIB_VARIANT
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msg_hip.h")
 
 MSG_F32, MSG_BF16, MSG_F16, MSG_F64 = 0, 1, 2, 3
+ABI_VERSION = 5          # MSG_ABI_VERSION of include/msg_hip.h this binding was written against (checked at load time)
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_longlong, _c.c_float
 
@@ -106,6 +107,13 @@ def lib():
             raise MsgHipError(f"{LIB_PATH} is missing: build it with `python -m multi_stylegan_amd.build` "
                               "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        handle.msg_abi_version.restype = _I
+        found = handle.msg_abi_version()
+        if found != ABI_VERSION:
+            # (a stale .so used to surface as an AttributeError on the first missing symbol -- or not at all, when only a
+            #  workspace size had changed)
+            raise MsgHipError(f"{LIB_PATH} was built for C-ABI version {found}, this package binds version {ABI_VERSION}: "
+                              "rebuild the library with `python -m multi_stylegan_amd.build --force`")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args

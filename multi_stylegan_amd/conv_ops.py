@@ -423,14 +423,17 @@ class fp32_contraction:
         fp32_contraction(mode).__enter__()
 
 
-def _contraction_code(t: torch.Tensor) -> int:
-    """Storage code of a contraction operand: fp32 maps carry MSG_F32_SPLIT when the split-bf16 products are selected."""
+def _contraction_code(t: torch.Tensor, mode: Optional[str] = None) -> int:
+    """Storage code of a contraction operand: fp32 maps carry MSG_F32_SPLIT when the split-bf16 products are selected.
+    ``mode``: the contraction mode captured when the layer's FORWARD ran (Geometry.mode) -- its backward and double backward
+    multiply the same way even when they run after a ``with fp32_contraction(...)`` block has ended; None = the current one."""
     code = _lib.dtype_code(t)
-    return _SPLIT_CODES[FP32_CONTRACTION] if (code == _lib.MSG_F32 and FP32_CONTRACTION != "exact") else code
+    mode = FP32_CONTRACTION if mode is None else mode
+    return _SPLIT_CODES[mode] if (code == _lib.MSG_F32 and mode != "exact") else code
 
 
 def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real,
-                  flops=None, act=None, residual=None, out=None):
+                  flops=None, act=None, residual=None, out=None, mode=None):
     """act = (act_bias | None, noise | None, noise_weight | None, alpha, scale): fuse the layer's activation stage.
     residual = (map shaped like the output, gain): y = (conv + map) * gain in the epilogue.
     out: a channels-last map or channel-slice of a wider one that receives the result (cat_destination)."""
@@ -478,11 +481,11 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
             rv, res_ld = _nhwc_view(residual[0])
             assert rv.shape == (b, n, oh, ow) and rv.dtype == x.dtype
             code = _lib.lib().msg_conv2d_fprop_residual(
-                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _contraction_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
+                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _contraction_code(x, mode), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
                 stride, pad, wstride, rv.data_ptr(), res_ld, float(residual[1]), _lib.stream_of(dev))
         elif act is None:
             code = _lib.lib().msg_conv2d_fprop(
-                xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _contraction_code(x), b, ih, iw, cx, ck, oh,
+                xv.data_ptr(), wk.data_ptr(), _lib.ptr(bias), y.data_ptr(), _contraction_code(x, mode), b, ih, iw, cx, ck, oh,
                 ow, n, ldy, kh, kw, stride, pad, in_up, int(pixel_shuffle), wstride, _lib.stream_of(dev))
         else:
             assert bias is None and in_up == 1 and not pixel_shuffle
@@ -499,7 +502,7 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
                     if mask is not None:
                         act[5].append((mask, 256 if mplan == 3 else 128, 256 if mplan == 3 else 128))
             code = _lib.lib().msg_conv2d_fprop_act_mask(
-                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _contraction_code(x), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
+                xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _contraction_code(x, mode), b, ih, iw, cx, ck, oh, ow, n, ldy, kh, kw,
                 stride, pad, wstride, _lib.ptr(act_bias), _lib.ptr(noise), _lib.ptr(noise_w),
                 1 if noise is None else noise.shape[0], float(alpha), float(scale), _lib.ptr(mask), _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_fprop")
@@ -514,7 +517,8 @@ def _grad_dest(param):
     return grad_destination(param)
 
 
-def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw, raw=False, gain=1.0, out=None):
+def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, low_hw, raw=False, gain=1.0, out=None,
+                  mode=None):
     """out: a contiguous fp32 tensor of o*i*kh*kw elements (the parameter's own layout) that receives a SHARED gradient."""
     dev = _lib.require_gpu(gy, x)
     gv, ldgy = _nhwc_view(gy)
@@ -535,7 +539,7 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
         k_chunks = max(1, min((oh * ow + 4 * kp - 1) // (4 * kp), (1024 + tiles - 1) // tiles))
         while b * k_chunks > 65535:
             k_chunks -= 1
-    geom = (_contraction_code(x), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw, kh, kw, stride, pad, int(pixel_shuffle),
+    geom = (_contraction_code(x, mode), b, ih, iw, cx, i, oh, ow, ldgy, o, ldgw, kh, kw, stride, pad, int(pixel_shuffle),
             int(per_sample), k_chunks)
     # K-slices that add up to one result meet in a workspace of per-slice slabs and a fixed-order sum (deterministic; no
     # float atomics, no zero fill).  That sum also transposes a SHARED gradient into the parameter's own [O, I, kh, kw]
@@ -576,11 +580,14 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
 # ------------------------------------------------------------------------------------- the three primitives, raw
 class Geometry:
     """kind 'conv': y = conv(x, w, stride, pad);  kind 'up2': y = conv_transpose(x, w^T, kernel 2, stride 2)."""
-    __slots__ = ("kind", "kh", "kw", "stride", "pad", "x_hw", "y_hw", "per_sample", "wscale")
+    __slots__ = ("kind", "kh", "kw", "stride", "pad", "x_hw", "y_hw", "per_sample", "wscale", "mode")
 
-    def __init__(self, kind, kh, kw, stride, pad, x_hw, per_sample, wscale=1.0):
+    def __init__(self, kind, kh, kw, stride, pad, x_hw, per_sample, wscale=1.0, mode=None):
         self.kind, self.kh, self.kw, self.stride, self.pad = kind, kh, kw, stride, pad
         self.x_hw, self.per_sample, self.wscale = tuple(x_hw), per_sample, float(wscale)
+        # how fp32-storage contractions multiply, fixed when the layer's forward builds its geometry: every launch of the
+        # layer's autograd family (F / D / G, first and second order) reads it from here, not from the process-wide switch
+        self.mode = FP32_CONTRACTION if mode is None else mode
         if kind == "up2":
             self.y_hw = (2 * x_hw[0], 2 * x_hw[1])
         else:
@@ -635,7 +642,7 @@ def _f_raw(x, w, bias, g: Geometry, act=None, residual=None, out=None):
         xc, ko = _gather_taps(x, w.shape[1], g)
         wk, _ = _cached(w, "thin", x.dtype, g.wscale, lambda: _relay_thin(w, x.dtype))
         return _launch_fprop(xc, wk, ko, bias, w.shape[0], g.y_hw, 1, 1, 1, 0, 1, False, False,
-                             w.shape[1] * g.kh * g.kw, act=act, residual=residual, out=out)
+                             w.shape[1] * g.kh * g.kw, act=act, residual=residual, out=out, mode=g.mode)
     if g.kind == "up2" and _oi(w)[0] % _vec(x.dtype):
         # the pixel-shuffling epilogue stores whole 16-byte channel vectors per output pixel: pad the output channels
         # with zero filters and drop them again (rare: every up-conv of the models has 512 output channels)
@@ -650,9 +657,9 @@ def _f_raw(x, w, bias, g: Geometry, act=None, residual=None, out=None):
     o, _ = _oi(w)
     if g.kind == "up2":
         assert out is None
-        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, _oi(w)[1])
+        return _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, g.per_sample, _oi(w)[1], mode=g.mode)
     return _launch_fprop(x, wk, ck, bias, o, g.y_hw, g.kh, g.kw, g.stride, g.pad, 1, False, g.per_sample, _oi(w)[1],
-                         act=act, residual=residual, out=out)
+                         act=act, residual=residual, out=out, mode=g.mode)
 
 
 def _act_operands(bias, noise, noise_w, y_shape):
@@ -678,11 +685,11 @@ def _d_raw(gy, w, g: Geometry, residual=None):
     wk, ok = img["d"] if img is not None else \
         _cached(w, "d" + g.kind, gy.dtype, g.wscale, lambda: _relay_dgrad(w, gy.dtype, flip=g.kind != "up2"))
     if g.kind == "up2":
-        return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample, _oi(w)[0])
+        return _launch_fprop(gy, wk, ok, None, i, g.x_hw, 2, 2, 2, 0, 1, False, g.per_sample, _oi(w)[0], mode=g.mode)
     pad = g.kh - 1 - g.pad
     assert g.kh == g.kw
     return _launch_fprop(gy, wk, ok, None, i, g.x_hw, g.kh, g.kw, 1, pad, g.stride, False, g.per_sample, _oi(w)[0],
-                         residual=residual)
+                         residual=residual, mode=g.mode)
 
 
 def _d_raw_s2(gy, w, g: Geometry):
@@ -691,7 +698,7 @@ def _d_raw_s2(gy, w, g: Geometry):
     wk, ok, taps, pad2 = _cached(w, "ds2", gy.dtype, g.wscale, lambda: _relay_dgrad_s2(w, gy.dtype, g.pad))
     hc, wc = (g.x_hw[0] + 1) // 2, (g.x_hw[1] + 1) // 2
     flops = 2.0 * gy.shape[0] * gy.shape[2] * gy.shape[3] * o * i * g.kh * g.kw
-    gx = _launch_fprop(gy, wk, ok, None, 4 * i, (hc, wc), taps, taps, 1, pad2, 1, True, g.per_sample, o, flops=flops)
+    gx = _launch_fprop(gy, wk, ok, None, 4 * i, (hc, wc), taps, taps, 1, pad2, 1, True, g.per_sample, o, flops=flops, mode=g.mode)
     return gx[:, :, :g.x_hw[0], :g.x_hw[1]]
 
 
@@ -699,12 +706,12 @@ def _g_raw(gy, x, o, i, g: Geometry, out=None):
     if _thin_ok(x.dtype, i, g):
         # weight gradient of the tap-gathered 1x1 form: gy is read once (not once per tap), one channel tile
         xc, ko = _gather_taps(x, i, g)
-        gwp = _launch_wgrad(gy, xc, o, ko, 1, 1, 1, 0, False, False, None, gain=g.wscale)      # [O, Ko, 1, 1]
+        gwp = _launch_wgrad(gy, xc, o, ko, 1, 1, 1, 0, False, False, None, gain=g.wscale, mode=g.mode)      # [O, Ko, 1, 1]
         taps = g.kh * g.kw
         return gwp[:, :taps * i, 0, 0].reshape(o, taps, i).permute(0, 2, 1).reshape(o, i, g.kh, g.kw)
     if g.kind == "up2":
-        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw, gain=g.wscale, out=out)
-    return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None, gain=g.wscale, out=out)
+        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, g.per_sample, g.x_hw, gain=g.wscale, out=out, mode=g.mode)
+    return _launch_wgrad(gy, x, o, i, g.kh, g.kw, g.stride, g.pad, False, g.per_sample, None, gain=g.wscale, out=out, mode=g.mode)
 
 
 def _consumed(ctx, arg_index: int, tensor_ordinal: int) -> bool:
@@ -877,7 +884,7 @@ class _ConvResidualF(Function):
             gs = g1 if g1 is not None else g2
             ctx.main_scale.pending = ctx.gain
             gg = Geometry(ctx.g.kind, ctx.g.kh, ctx.g.kw, ctx.g.stride, ctx.g.pad, ctx.g.x_hw, ctx.g.per_sample,
-                          ctx.g.wscale * ctx.gain)
+                          ctx.g.wscale * ctx.gain, mode=ctx.g.mode)
             gx = _ConvD.apply(gs, w, gg) if ctx.needs_input_grad[0] else None
             if ctx.slot is not None and gx is not None:
                 ctx.slot.g = gx
@@ -1353,25 +1360,25 @@ def _tap_square_sums(weight, w3, kind):
 def _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g):
     """Data-gradient contraction of the modulated conv with a per-sample data-gradient weight image."""
     if upsample:
-        return _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o)
-    return _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o)
+        return _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o, mode=g.mode)
+    return _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o, mode=g.mode)
 
 
 def _fprop_modconv(x, wk, ck, o, i, kh, kw, upsample, g, add_to=None):
     """Forward contraction of the modulated conv with a per-sample forward weight image; `add_to`: a map shaped like the
     result that is added to it (in the contraction's epilogue where the kernel has one: the plain stride-1 convs)."""
     if upsample:
-        y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
+        y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i, mode=g.mode)
         return y if add_to is None else y + add_to
     return _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i,
-                         residual=None if add_to is None else (add_to, 1.0))
+                         residual=None if add_to is None else (add_to, 1.0), mode=g.mode)
 
 
 def _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g):
     """Per-sample weight gradient in the kernel layout [B][O][taps][ldg] -> (gwk, ldg)."""
     if upsample:
-        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True)
-    return _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True)
+        return _launch_wgrad(gy, x, o, i, 2, 2, 1, 0, True, True, g.x_hw, raw=True, mode=g.mode)
+    return _launch_wgrad(gy, x, o, i, kh, kw, 1, kh // 2, False, True, None, raw=True, mode=g.mode)
 
 
 def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=None, dest=None):
@@ -1579,9 +1586,9 @@ class _ModulatedConv(Function):
             assert not upsample, "the upsampling layers blur before their activation"
             act = (*_act_operands(act_bias, noise, noise_w, (b, o, *g.y_hw)), alpha, act_scale, holder)
         if upsample:
-            y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i)
+            y = _launch_fprop(x, wk, ck, None, 4 * o, g.x_hw, 1, 1, 1, 0, 1, True, True, i, mode=g.mode)
         else:
-            y = _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i, act=act)
+            y = _launch_fprop(x, wk, ck, None, o, g.y_hw, kh, kw, 1, kh // 2, 1, False, True, i, act=act, mode=g.mode)
         ctx.save_for_backward(x, weight, style, d if d is not None else torch.empty(0, device=dev),
                               y if fuse_act else None, noise if fuse_act else None)
         ctx.cfg = (demodulate, upsample, g, scale)

@@ -259,6 +259,8 @@ class GradBucketReducer:
         for k, b in enumerate(self.buckets):
             b.pending = len(b.params) if plan is None else plan[k]
             b.work, b.ready = None, False
+        dirty_before = not self._zeroed
+        self._zeroed = False                             # labelled or not: the backward that follows writes the store
         if plan is None:
             self._order, self._cold = list(range(len(self.buckets))), []
         else:
@@ -270,10 +272,9 @@ class GradBucketReducer:
             # The direct route OVERWRITES the store's slices, so it has no accumulate semantics: a labelled backward
             # must follow a zero_grad() (two armed backwards in a row would drop the first one's directly written gradients
             # and keep the ones routed through AccumulateGrad).  Enforced, not assumed.
-            if not self._zeroed:
+            if dirty_before:
                 raise RuntimeError("GradBucketReducer.arm(label): zero_grad() must run before every labelled backward "
                                    "(gradients are written, not accumulated, into the flat store)")
-            self._zeroed = False
             self._detached = True
             for b in self.buckets:
                 for q in b.params:
@@ -299,6 +300,10 @@ class GradBucketReducer:
             self._attach_all()
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
+        # ANY gradient that reaches the store dirties it -- also one that arrives while the reducer is not armed (plain
+        # AccumulateGrad into the attached views, e.g. the discriminator's parameters during a generator step that does not
+        # skip their weight gradients): the next arm(label) must then see a zero_grad() first
+        self._zeroed = False
         if not self._armed:
             return
         b = self._bucket_of[p]

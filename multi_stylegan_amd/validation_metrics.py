@@ -15,12 +15,21 @@ of the SYMMETRIC matrix C_r^(1/2) C_f C_r^(1/2) (same spectrum as C_r C_f; ``eig
 eigenvalues clamped at zero where scipy's ``sqrtm(...).real`` drops an imaginary part).
 """
 import math
+import warnings
 from typing import Iterable, Optional, Tuple, Union
 
 import torch
+import torch.distributed as torch_dist
 import torch.nn as nn
 
 from . import misc
+
+
+def _ranks() -> int:
+    """Ranks that share a validation pass: in a data-parallel job every rank sweeps 1 / world of the samples (its own shard
+    of the dataset, its own latents) and the additive statistics are summed over the ranks -- the reference runs the pass once,
+    on the gathered DataParallel model (model_wrapper.py:197-243); repeating the whole pass per rank was world x the work."""
+    return torch_dist.get_world_size() if torch_dist.is_available() and torch_dist.is_initialized() else 1
 
 __all__ = ["IS", "FID", "FVD", "FeatureMoments", "frechet_distance", "frechet_distance_from_moments", "inception_score",
            "select_frames"]
@@ -63,6 +72,18 @@ class FeatureMoments:
         self.s1 += f.sum(dim=0)
         self.s2.addmm_(f.t(), f)
         self.n += f.shape[0]
+        return self
+
+    def all_reduce_(self) -> "FeatureMoments":
+        """Sum (n, s1, s2) over the ranks of the default process group: the moments are additive, so every rank ends with
+        the statistics of all rows any rank folded in (one [d, d] float64 all-reduce)."""
+        if _ranks() > 1:
+            if self.s1 is None:
+                raise ValueError("a rank without feature rows cannot join the exchange (its feature width is unknown)")
+            n = torch.tensor([float(self.n)], dtype=torch.float64, device=self.s1.device)
+            for t in (n, self.s1, self.s2):
+                torch_dist.all_reduce(t)
+            self.n = int(n.item())
         return self
 
     def mean_cov(self) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -160,12 +181,22 @@ class IS(_Metric):
         generator.to(self.device).eval()
         channels = self._channels()
         predictions = [[] for _ in channels]
-        for _ in range(math.ceil(self.data_samples / self.batch_size)):
+        world = _ranks()
+        share = math.ceil(self.data_samples / world)             # this rank's samples; the class probabilities are gathered
+        for _ in range(math.ceil(share / self.batch_size)):
             fake_images = generator(input=self._latents(generator))
             for k, c in enumerate(channels):
                 frames = self._preprocessing(select_frames(fake_images, c))
                 predictions[k].append(net(frames).float().softmax(dim=1))
-        return self._result([inception_score(torch.cat(p)[:self.data_samples]) for p in predictions])
+        rows = []
+        for p in predictions:
+            p = torch.cat(p)[:share].contiguous()
+            if world > 1:
+                parts = [torch.empty_like(p) for _ in range(world)]
+                torch_dist.all_gather(parts, p)
+                p = torch.cat(parts)
+            rows.append(p[:self.data_samples])
+        return self._result([inception_score(p) for p in rows])
 
 
 class _Frechet(_Metric):
@@ -180,21 +211,29 @@ class _Frechet(_Metric):
     def __call__(self, generator: nn.Module, dataset: Iterable):
         net = self.network.to(self.device).eval()
         channels = self._channels()
+        share = math.ceil(self.data_samples / _ranks())          # rows this rank contributes (all of them in one process)
         if self.moments_real is None:
-            moments = [FeatureMoments(self.data_samples) for _ in channels]
+            moments = [FeatureMoments(share) for _ in channels]
             for real_images in dataset:
                 real_images = real_images.to(self.device)
                 for m, c in zip(moments, channels):
                     m.update(net(self._inputs(real_images, c)))
                 if moments[0].full:
                     break
+            moments = [m.all_reduce_() for m in moments]
+            if moments[0].n < self.data_samples:
+                # (the reference indexes its activation list up to data_samples and would use however many rows there are
+                #  too, silently; the score is then NOT the nominal-sample-count metric)
+                warnings.warn(f"{type(self).__name__}: the dataset held {moments[0].n} samples, fewer than data_samples = "
+                              f"{self.data_samples}; the real statistics (cached from now on) are those of {moments[0].n} rows")
             self.moments_real = moments
         generator.to(self.device).eval()
-        fake = [FeatureMoments(self.data_samples) for _ in channels]
-        for _ in range(math.ceil(self.data_samples / self.batch_size)):
+        fake = [FeatureMoments(share) for _ in channels]
+        for _ in range(math.ceil(share / self.batch_size)):
             fake_images = generator(input=self._latents(generator))
             for m, c in zip(fake, channels):
                 m.update(net(self._inputs(fake_images, c)))
+        fake = [m.all_reduce_() for m in fake]
         return self._result([frechet_distance_from_moments(r, f) for r, f in zip(self.moments_real, fake)])
 
 

@@ -240,3 +240,42 @@ def test_wrapper_pair_forward_equals_two_calls(golden):
     assert rel_err(s2, torch.cat([sr, sf])) < 1e-5 and rel_err(p2, torch.cat([pr, pf])) < 1e-5
     assert torch.equal(both[:3], r1) and torch.equal(both[3:], f1) and not torch.equal(r1, real)
     assert a1.p == pytest.approx(a2.p) and len(a1.r_history) == len(a2.r_history) == 1
+
+
+def test_config5_full_size_training_iteration_with_ada():
+    """BASELINE config 5's per-GPU work as ONE training iteration at its own size: 256x256, 7 x 512 channels, batch 16, bf16
+    storage, the discriminator (non-local blocks are always on) wrapped in adaptive discriminator augmentation
+    (reference adaptive_discriminator_augmentation.py:63-96).  Iterations 15 (plain) and 16 (R1 on the batch ADA augmented in
+    place, path length): every loss finite, the real batch really was augmented in place, the controller counted the four fake
+    batches it saw (D step + G step per iteration) and moved p by +-p_step on the DEVICE (no host round trip: `_p` is a device
+    tensor, `r_history` holds device scalars), parameters finite, memory well inside one MI355X."""
+    import multi_stylegan_amd as m
+    from multi_stylegan_amd.config import generator_config_for_resolution
+    _seed(51)
+    g = m.MultiStyleGANGenerator(generator_config_for_resolution(256))
+    d = m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
+    g.compute_dtype = d.compute_dtype = torch.bfloat16
+    ada = m.AdaptiveDiscriminatorAugmentation(d, r_update=4)
+    ada.p = 0.5                                          # half of the images take every stage of the pipeline
+    tr = m.ModelWrapper(g, ada, device=DEV)
+    tr.generator_ema.compute_dtype = torch.bfloat16
+    assert tr.batch_discriminator_passes
+    tr.iteration = 14
+    torch.cuda.reset_peak_memory_stats()
+    real = torch.rand(16, 2, 3, 256, 256, device=DEV)
+    for it in (15, 16):
+        batch = real.clone()
+        tr.train_iteration(batch)
+        assert not torch.equal(batch, real), "ADA did not augment the batch in place"
+        assert torch.isfinite(batch).all()
+    logs = tr.pop_logs()
+    assert {"loss_discriminator_real", "loss_discriminator_regularization", "loss_generator", "path_length"} <= set(logs)
+    assert all(math.isfinite(v) for vals in logs.values() for v in vals), logs
+    assert ada._p.is_cuda and len(ada.r_history) == 1 and ada.r_history[0].is_cuda and ada._r_count == 0
+    assert abs(abs(ada.p - 0.5) - ada.p_step) < 1e-6, ada.p           # one controller update: p moved by exactly one step
+    assert -1.0 <= float(ada.r_history[0]) <= 1.0
+    assert all(torch.isfinite(p).all() for p in list(g.parameters()) + list(d.parameters()))
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f"config 5 per-GPU iteration pair: p 0.5 -> {ada.p:.3f}, r {float(ada.r_history[0]):+.3f}, peak {peak:.1f} GiB, "
+          f"losses " + " ".join(f"{k}={v[-1]:.4g}" for k, v in logs.items()))
+    assert peak < 40.0

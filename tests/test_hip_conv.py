@@ -125,12 +125,19 @@ def test_conv_primitives_split_bf16_products(case, per_sample, mode="split_bf16x
     u = torch.randn(w.shape, generator=g).float().double()
     ggw_r, = torch.autograd.grad(gxr, wr, v, retain_graph=True)
     ggx_r, = torch.autograd.grad(gwr, xr, u, retain_graph=True)
-    geo = conv_ops.Geometry(kind, k, k, stride if kind == "conv" else 1, pad, (h, w_), per_sample)
     cl = lambda t: t.to(DEV, torch.float32).contiguous(memory_format=torch.channels_last)
 
-    def run():
+    def run(forward_mode=None):
+        """forward_mode: run ONLY the forward inside ``with fp32_contraction(forward_mode)`` -- the layer's geometry captures the
+        mode there, and the backward / double backward launched after the block must multiply the same way."""
         xd, wd = cl(x).requires_grad_(True), w.to(DEV, torch.float32).requires_grad_(True)
-        y = conv_ops._ConvF.apply(xd, wd, None, geo)
+        if forward_mode is None:
+            geo = conv_ops.Geometry(kind, k, k, stride if kind == "conv" else 1, pad, (h, w_), per_sample)
+            y = conv_ops._ConvF.apply(xd, wd, None, geo)
+        else:
+            with conv_ops.fp32_contraction(forward_mode):
+                geo = conv_ops.Geometry(kind, k, k, stride if kind == "conv" else 1, pad, (h, w_), per_sample)
+                y = conv_ops._ConvF.apply(xd, wd, None, geo)
         gx, gw = torch.autograd.grad(y, (xd, wd), cl(gy) if y.shape[1] > 1 else gy.to(DEV, torch.float32), create_graph=True)
         ggw, = torch.autograd.grad(gx, wd, cl(v), retain_graph=True)
         ggx, = torch.autograd.grad(gw, xd, u.to(DEV, torch.float32), retain_graph=True)
@@ -140,6 +147,9 @@ def test_conv_primitives_split_bf16_products(case, per_sample, mode="split_bf16x
     with conv_ops.fp32_contraction(mode):
         split = run()
     assert conv_ops.FP32_CONTRACTION == "exact"
+    # (advisor, round 4: the mode used to be read at LAUNCH time, so a backward after the block silently ran exact kernels)
+    late = run(forward_mode=mode)
+    assert all(torch.equal(a, b_) for a, b_ in zip(late, split)), "backward after the block did not keep the forward's mode"
     for nm, got, ex, ref in zip(("forward", "data gradient", "weight gradient", "d(dgrad)/dw", "d(wgrad)/dx"), split, exact,
                                 (yr, gxr, gwr, ggw_r, ggx_r)):
         # split_bf16x3 (all 24 mantissa bits, six products) sits at the exact kernel's own error, fp32 rounding of the sums

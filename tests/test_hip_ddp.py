@@ -204,3 +204,70 @@ def test_trainer_two_ranks_two_gpus_rccl(exchange):
     [p.kill() for p in hung]
     assert not hung and all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=5) == "ok"
+
+
+def test_arm_label_refuses_a_dirty_store():
+    """The direct route WRITES gradients into the flat store, so a labelled backward must start from zero_grad() -- whichever
+    way the store was dirtied: a labelled backward, an unlabelled arm() + backward, or plain AccumulateGrad while the reducer
+    was not armed at all (advisor, round 4: only the first of the three used to be tracked)."""
+    sys.path.insert(0, ROOT)
+    from multi_stylegan_amd.dist import GradBucketReducer
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 8).to("cuda:0")
+    red = GradBucketReducer(lin.parameters(), bucket_bytes=1 << 10)
+    x = torch.randn(4, 8, device="cuda:0")
+
+    def backward(label, arm=True):
+        if arm:
+            red.arm(label)
+        lin(x).sum().backward()
+        if arm:
+            red.finish()
+
+    red.zero_grad(); backward("a")                                 # the ordinary sequence
+    want = lin.weight.grad.clone()
+    with pytest.raises(RuntimeError, match="zero_grad"):
+        red.arm("a")                                               # labelled after labelled
+    red.disarm()
+    red.zero_grad(); backward(None)                                # unlabelled arm + backward dirties it
+    assert torch.equal(lin.weight.grad, want)
+    with pytest.raises(RuntimeError, match="zero_grad"):
+        red.arm("a")
+    red.disarm()
+    red.zero_grad(); backward(None, arm=False)                     # not armed at all: AccumulateGrad into the attached views
+    assert torch.equal(lin.weight.grad, want)
+    with pytest.raises(RuntimeError, match="zero_grad"):
+        red.arm("a")
+    red.disarm()
+    red.zero_grad(); backward("a")
+    assert torch.equal(lin.weight.grad, want)
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2` end to end as the driver starts it -- self-launch through torch.distributed.run from a parent that
+    never touches the GPU, rendezvous on 127.0.0.1, the bucket exchange during backward, the overlap-off leg, rank 0's JSON
+    line -- on two ranks sharing this box's one GPU over gloo (RCCL refuses two ranks on one device): the first multi-rank run
+    of the benchmark must not be the 8-GPU measurement itself (reference: train_multi_stylegan.py:67-70)."""
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MSG_LIB_VARIANT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-fp32-leg"]
+    t0 = time.time()
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    took = time.time() - t0
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]                       # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo" and out["rehearsal_shared_gpu"] is True
+    assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
+    assert len(out["per_rank_img_per_s"]) == 2 and all(v > 0 for v in out["per_rank_img_per_s"])
+    assert out["overlap"]["on_ms_per_step"] > 0 and out["overlap"]["off_ms_per_step"] > 0
+    assert out["value"] > 0 and out["library"]["variant"] is None
+    assert out["losses"] and all(v == v and abs(v) != float("inf") for v in out["losses"].values())
+    print(f"two-rank rehearsal: {took:.0f} s, {out['value']} img/s on one shared GPU, overlap {out['overlap']}")
+    assert took < 120, took

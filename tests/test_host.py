@@ -567,6 +567,80 @@ def test_metric_statistics_match_the_reference_values(golden):
         vm.FID(None)
 
 
+class _ToyGenerator(torch.nn.Module):
+    """Stands in for the generator in the statistics sweeps (any module with `latent_dimensions` mapping latents to
+    [B, 2, 3, H, W] images will do; the real one needs the GPU)."""
+    latent_dimensions = 6
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(6, 2 * 3 * 8 * 8)
+
+    def forward(self, input):
+        z = input[0] if isinstance(input, (list, tuple)) else input
+        return torch.sigmoid(self.lin(z)).view(-1, 2, 3, 8, 8)
+
+
+class _ToyFeatures(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.rows = []
+
+    def forward(self, x):
+        f = torch.stack([x.mean(dim=tuple(range(1, x.ndim))), x.flatten(1).std(dim=1), x.flatten(1)[:, 0],
+                         x.flatten(1)[:, -1] * 2.0], dim=1)
+        self.rows.append(f.double())
+        return f
+
+
+def _validation_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from multi_stylegan_amd import validation_metrics as vm
+    from oracle import metrics as omet
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    gen, net = _ToyGenerator(), _ToyFeatures()
+    for p_ in gen.parameters():
+        dist.broadcast(p_.data, 0)
+    dataset = [torch.rand(3, 2, 3, 8, 8) for _ in range(5)]                  # rank-distinct shard: 15 rows
+    metric = vm.FID(net, device="cpu", batch_size=3, data_samples=20, no_rfp=True, no_gfp=True)
+    got = metric(gen, dataset)
+    # every rank swept ceil(20 / 2) = 10 rows of its data (4 batches, the last cut) and 10 generated rows (4 batches)
+    assert len(net.rows) == 8
+    mine = torch.stack([torch.cat(net.rows[:4])[:10], torch.cat(net.rows[4:])[:10]])
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    real, fake = torch.cat([b[0] for b in both]), torch.cat([b[1] for b in both])
+    want = omet.frechet_distance(real.numpy(), fake.numpy())
+    assert abs(got - want) <= 1e-9 * max(abs(want), 1.0), (got, want)
+    assert metric.moments_real[0].n == 20
+    scores = [torch.tensor([got], dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(scores, torch.tensor([got], dtype=torch.float64))
+    assert scores[0].item() == scores[1].item()                            # the same score on every rank
+    # inception score: every rank's 10 probability rows gathered
+    net2 = _ToyFeatures()
+    is_got = vm.IS(net2, device="cpu", batch_size=5, data_samples=20, no_rfp=True, no_gfp=True, input_size=None)(gen)
+    probs = torch.cat(net2.rows).float().softmax(dim=1)
+    parts = [torch.empty_like(probs) for _ in range(world)]
+    dist.all_gather(parts, probs)
+    assert abs(is_got - omet.inception_score(torch.cat(parts).numpy())) < 1e-6
+    # a dataset that runs out before data_samples rows: says so instead of caching short statistics silently
+    short = vm.FID(_ToyFeatures(), device="cpu", batch_size=3, data_samples=40, no_rfp=True, no_gfp=True)
+    with pytest.warns(UserWarning, match="fewer than data_samples"):
+        short(gen, dataset)
+    assert short.moments_real[0].n == 30
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_validation_statistics_are_shared_over_ranks_gloo_world2():
+    """A data-parallel validation pass: each rank sweeps its share of the samples, the additive moments (and the inception
+    score's probability rows) are exchanged, every rank reports the statistic of the union (advisor, round 4)."""
+    _run_ranks(_validation_worker, 2, 29100 + os.getpid() % 300, 120)
+
+
 def test_bench_multi_rank_fields():
     """What bench.py's JSON line reports about the ranks (the fields the 8-GPU run is read by), on canned timings."""
     import importlib.util

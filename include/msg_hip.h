@@ -300,6 +300,11 @@ int msg_scaled_add_rows(const void* a, const void* b, void* y, int dtype, long l
 int msg_softmax_rows(const void* x, void* y, int dtype, long long rows, int cols, void* stream);
 int msg_softmax_rows_backward(const void* y, const void* gy, void* gx, int dtype, long long rows, int cols,
                               void* stream);
+/* ABI 5.  Second-order terms of the softmax backward for a cotangent v of gx (R1: the backward is differentiated again,
+ * reference loss.py:311-316 through u_net_2d_discriminator.py:378), one pass over the maps:
+ *   d_gy = y * (v - <v, y>),   d_y = v * (gy - <gy, y>) - gy * <v, y>     (row-wise inner products, fp32 arithmetic). */
+int msg_softmax_rows_backward2(const void* y, const void* gy, const void* v, void* d_y, void* d_gy, int dtype,
+                               long long rows, int cols, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a6 / 8f-1  fused attention of the NonLocalBlock -- replaces the torch.bmm -> F.softmax -> torch.bmm sequence of
@@ -328,6 +333,11 @@ int msg_maxpool2x2_fwd(const void* x, void* y, unsigned short* idx, int dtype, i
                        void* stream);
 int msg_maxpool2x2_bwd(const void* gy, const unsigned short* idx, void* gx, int dtype, int B, int H, int W, int C,
                        void* stream);
+/* ABI 5.  The transpose of the backward's scatter, i.e. the derivative of msg_maxpool2x2_bwd with respect to gy for a cotangent
+ * v of gx (second-order graphs, R1): v [B, H, W, C] channels-last with pixel pitch ldv, read at the positions idx names ->
+ * out [B, H/2, W/2, C] dense. */
+int msg_maxpool2x2_gather(const void* v, const unsigned short* idx, void* out, int dtype, int B, int H, int W, int C,
+                          long long ldv, void* stream);
 
 /* msg_nonlocal_attention_bwd_splits: in how many parts the dK / dV kernel splits its query sweep for this problem; when
  * it is more than 1 the caller passes `workspace` with splits * B * Nk * (dk + dv) floats (scratch, fully overwritten). */

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "msg_flat_ema": (_I, [_P, _P, _L, _F, _P]),
     "msg_softmax_rows": (_I, [_P, _P, _I, _L, _I, _P]),
     "msg_softmax_rows_backward": (_I, [_P, _P, _P, _I, _L, _I, _P]),
+    "msg_softmax_rows_backward2": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _P]),
     "msg_nonlocal_attention_supported": (_I, [_I] * 5),
     "msg_nonlocal_attention_fwd": (_I, [_P] * 5 + [_I] * 6 + [_P]),
     "msg_nonlocal_attention_bwd_splits": (_I, [_I] * 3),
@@ -76,6 +77,7 @@ _SIGNATURES = {
     "msg_conv2d_fprop_thin_eligible": (_I, [_I] * 16),
     "msg_maxpool2x2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _L, _P]),
     "msg_maxpool2x2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msg_maxpool2x2_gather": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _L, _P]),
     "msg_linear_fprop": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "msg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "msg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),

@@ -769,12 +769,23 @@ def _channel_sums(gy):
     return out
 
 
+def _dgrad_add_ok(add, x_shape, dtype, g) -> bool:
+    """Whether `add` (a map shaped like the data gradient) can ride in the data-gradient launch's residual epilogue."""
+    return add is not None and g.kind == "conv" and g.stride == 1 and tuple(add.shape) == tuple(x_shape) and add.dtype == dtype
+
+
 class _ConvD(Function):
+    """gx = D(gy, w) [+ add].  `add` (plain stride-1 convs): a map that is added in the launch's residual epilogue -- the
+    differentiable form of the hand-overs that first-order backward does with raw launches, for the graphs R1 differentiates
+    again: where a block input has two consumers, the second data gradient accumulates INTO the first instead of autograd (or
+    a node of this package) adding two full maps in a pass of its own (round 5; before, every such sum of a create_graph
+    backward was a stock elementwise launch: 3.6 GB per regularised iteration at 256^2)."""
+
     @staticmethod
-    def forward(ctx, gy, w, g):
+    def forward(ctx, gy, w, g, add=None):
         ctx.g = g
         ctx.save_for_backward(gy, w)
-        return _d_raw(gy, w, g)
+        return _d_raw(gy, w, g, residual=None if add is None else (add, 1.0))
 
     @staticmethod
     def backward(ctx, v):
@@ -782,7 +793,7 @@ class _ConvD(Function):
         g = ctx.g
         ggy = _ConvF.apply(v, w, None, g) if ctx.needs_input_grad[0] else None
         gw = _ConvG.apply(gy, v, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
-        return ggy, gw, None
+        return ggy, gw, None, (v if ctx.needs_input_grad[3] else None)
 
 
 class _ConvG(Function):
@@ -843,11 +854,11 @@ class _ConvActF(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             other = ctx.slot.g if ctx.slot is not None else None
-            if other is not None and not torch.is_grad_enabled() and g.kind == "conv" and g.stride == 1 and \
-                    other.shape == x.shape and other.dtype == gpre.dtype:
+            if _dgrad_add_ok(other, x.shape, gpre.dtype, g):
                 # the block input's OTHER gradient (from the 1x1 residual conv, computed just before) is added in this
-                # data-gradient conv's epilogue: no separate accumulation pass over the input map
-                gx = _d_raw(gpre, w, g, residual=(other, 1.0))
+                # data-gradient conv's epilogue: no separate accumulation pass over the input map (second-order graphs: the
+                # same launch as a differentiable node)
+                gx = _ConvD.apply(gpre, w, g, other) if torch.is_grad_enabled() else _d_raw(gpre, w, g, residual=(other, 1.0))
                 ctx.slot.merged = True
             else:
                 gx = _ConvD.apply(gpre, w, g)
@@ -897,7 +908,7 @@ class _ConvResidualF(Function):
         else:
             gs = (g1 + g2) * ctx.gain
         gx = _ConvD.apply(gs, w, ctx.g) if ctx.needs_input_grad[0] else None
-        if ctx.slot is not None and gx is not None and not torch.is_grad_enabled():
+        if ctx.slot is not None and gx is not None:
             ctx.slot.g = gx                  # the main branch's first conv adds it in its data-gradient epilogue
         gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g, w) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
@@ -925,9 +936,11 @@ class _MultiConvF(Function):
                 gws.append(None)
                 continue
             if ctx.needs_input_grad[0]:
-                if gx is None or second_order or gx.dtype != gy.dtype:
+                if gx is None or not _dgrad_add_ok(gx, x.shape, gy.dtype, g):
                     part = _ConvD.apply(gy, w, g)
                     gx = part if gx is None else gx + part
+                elif second_order:
+                    gx = _ConvD.apply(gy, w, g, gx)              # (differentiable: the sum so far rides in the epilogue)
                 else:
                     gx = _d_raw(gy, w, g, residual=(gx, 1.0))
             gws.append(_ConvG.apply(gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 2 + k, 1 + k) else None)

@@ -87,6 +87,47 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const T* __restrict
     }
 }
 
+// The transpose of the backward's scatter: v [B, H, W, C] read at the window positions the forward chose -> [B, H/2, W/2, C].
+// This is the derivative of the pooling's backward with respect to its incoming gradient (the map is linear in gy, the routing
+// is fixed by x): what R1's second differentiation needs, instead of the library's pooling re-run on the saved input.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_gather_kernel(const T* __restrict__ v, const unsigned short* __restrict__ idx,
+                                                                T* __restrict__ out, int B, int H, int W, int C, long long ldv) {
+    using V = Vec16<T>;
+    constexpr int VEC = V::N;
+    const int cv = C / VEC, OH = H / 2, OW = W / 2;
+    const long long total = (long long)B * OH * OW * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        long long t = i / cv;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const long long b = t / OH;
+        const T* p = v + ((b * H + 2 * oh) * W + 2 * ow) * ldv + (long long)c * VEC;
+        V w[4];
+        w[0].raw = *reinterpret_cast<const uint4*>(p);
+        w[1].raw = *reinterpret_cast<const uint4*>(p + ldv);
+        w[2].raw = *reinterpret_cast<const uint4*>(p + (long long)W * ldv);
+        w[3].raw = *reinterpret_cast<const uint4*>(p + (long long)W * ldv + ldv);
+        const unsigned int sel = idx[i];
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const unsigned k = (sel >> (2 * e)) & 3u;
+            f[e] = k == 0 ? w[0].get(e) : (k == 1 ? w[1].get(e) : (k == 2 ? w[2].get(e) : w[3].get(e)));
+        }
+        V o;
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, f[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, f[2 * e], f[2 * e + 1]);
+        }
+        *reinterpret_cast<uint4*>(out + i * VEC) = o.raw;
+    }
+}
+
 static int pool_check(const void* a, const void* b, int dtype, int B, int H, int W, int C) {
     if (B < 0 || H <= 0 || W <= 0 || C <= 0) return MSG_EINVAL;
     if (B == 0) return MSG_OK;
@@ -129,5 +170,23 @@ extern "C" int msg_maxpool2x2_bwd(const void* gy, const unsigned short* idx, voi
         hipLaunchKernelGGL((maxpool2x2_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)gy, idx, (bf16_t*)gx, B, H, W, C);
     else
         hipLaunchKernelGGL((maxpool2x2_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)gy, idx, (float*)gx, B, H, W, C);
+    return MSG_CHECK_LAUNCH();
+}
+
+// ABI 5.  v [B, H, W, C] channels-last with pixel pitch ldv, idx from the forward -> out [B, H/2, W/2, C] dense: v at the winners.
+extern "C" int msg_maxpool2x2_gather(const void* v, const unsigned short* idx, void* out, int dtype, int B, int H, int W, int C,
+                                     long long ldv, void* stream) {
+    const int rc = pool_check(v, out, dtype, B, H, W, C);
+    if (rc <= 0) return rc;
+    if (!idx) return MSG_EINVAL;
+    const int vec = dtype == MSG_BF16 ? 8 : 4;
+    if (ldv < C || ldv % vec) return MSG_EINVAL;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / vec);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16)
+        hipLaunchKernelGGL((maxpool2x2_gather_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)v, idx, (bf16_t*)out, B, H, W, C, ldv);
+    else
+        hipLaunchKernelGGL((maxpool2x2_gather_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)v, idx, (float*)out, B, H, W, C, ldv);
     return MSG_CHECK_LAUNCH();
 }

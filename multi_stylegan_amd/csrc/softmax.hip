@@ -108,6 +108,65 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restri
     }
 }
 
+// Second-order terms of gx = y * (gy - <gy, y>) for a cotangent v of gx (R1 differentiates the discriminator's backward):
+//   d_gy = y * (v - t),   d_y = v * (gy - s) - gy * t,     s = <gy, y>, t = <v, y>  per row.
+// One pass: three maps read, two written (the torch formulation took ~15 elementwise / reduction passes over the
+// [B, HW, HW/4] map: 2 GB per regularised iteration at 256^2).  The row stays in registers in its STORAGE type (raw 16-byte
+// chunks, converted in both sweeps): 12 registers per chunk instead of 24 floats, so a 4096-column row fits without scratch.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void softmax_rows_bwd2_kernel(const T* __restrict__ y, const T* __restrict__ gy,
+                                                                const T* __restrict__ v, T* __restrict__ d_y,
+                                                                T* __restrict__ d_gy, long long rows, int cols) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = cols / VEC;
+    const uint4* yr = reinterpret_cast<const uint4*>(y + row * cols);
+    const uint4* gr = reinterpret_cast<const uint4*>(gy + row * cols);
+    const uint4* vr = reinterpret_cast<const uint4*>(v + row * cols);
+    uint4* oy = reinterpret_cast<uint4*>(d_y + row * cols);
+    uint4* og = reinterpret_cast<uint4*>(d_gy + row * cols);
+    Vec16<T> ya[CH], ga[CH], va[CH];
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = lane + 64 * j;
+        ya[j].zero(); ga[j].zero(); va[j].zero();
+        if (c < nchunk) { ya[j].raw = yr[c]; ga[j].raw = gr[c]; va[j].raw = vr[c]; }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float yy = ya[j].get(e);
+            s = fmaf(ga[j].get(e), yy, s);
+            t = fmaf(va[j].get(e), yy, t);
+        }
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = lane + 64 * j;
+        if (c >= nchunk) continue;
+        Vec16<T> o1, o2;
+        float r1[VEC], r2[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float yy = ya[j].get(e), gg = ga[j].get(e), vv = va[j].get(e);
+            r1[e] = vv * (gg - s) - gg * t;
+            r2[e] = yy * (vv - t);
+        }
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o1.set(e, r1[e]); o2.set(e, r2[e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o1.set2(e, r1[2 * e], r1[2 * e + 1]); o2.set2(e, r2[2 * e], r2[2 * e + 1]); }
+        }
+        oy[c] = o1.raw;
+        og[c] = o2.raw;
+    }
+}
+
 static int softmax_chunks(int dtype, long long rows, int cols, const void* a, const void* b, const void* c) {
     if (dtype != MSG_F32 && dtype != MSG_BF16) return MSG_EUNSUPPORTED;
     if (!a || !b || !c || rows < 0 || cols <= 0) return MSG_EINVAL;
@@ -153,5 +212,22 @@ extern "C" int msg_softmax_rows_backward(const void* y, const void* gy, void* gx
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MSG_BF16) { SOFTMAX_LAUNCH(softmax_rows_bwd_kernel, bf16_t, (const bf16_t*)y, (const bf16_t*)gy, (bf16_t*)gx, rows, cols) }
     else { SOFTMAX_LAUNCH(softmax_rows_bwd_kernel, float, (const float*)y, (const float*)gy, (float*)gx, rows, cols) }
+    return MSG_CHECK_LAUNCH();
+}
+
+/* ABI 5: second-order softmax terms in one pass (see softmax_rows_bwd2_kernel). */
+extern "C" int msg_softmax_rows_backward2(const void* y, const void* gy, const void* v, void* d_y, void* d_gy, int dtype,
+                                          long long rows, int cols, void* stream) {
+    if (rows == 0) return MSG_OK;
+    int ch = softmax_chunks(dtype, rows, cols, y, gy, v);
+    if (ch < 0) return ch;
+    const int ch2 = softmax_chunks(dtype, rows, cols, d_y, d_gy, d_gy);
+    if (ch2 < 0) return ch2;
+    const long long blocks = (rows + 3) / 4;
+    if (blocks >= (1ll << 31)) return MSG_EUNSUPPORTED;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MSG_BF16) { SOFTMAX_LAUNCH(softmax_rows_bwd2_kernel, bf16_t, (const bf16_t*)y, (const bf16_t*)gy, (const bf16_t*)v, (bf16_t*)d_y, (bf16_t*)d_gy, rows, cols) }
+    else { SOFTMAX_LAUNCH(softmax_rows_bwd2_kernel, float, (const float*)y, (const float*)gy, (const float*)v, (float*)d_y, (float*)d_gy, rows, cols) }
     return MSG_CHECK_LAUNCH();
 }

@@ -245,8 +245,12 @@ class _GammaMerge(Function):
         a, gamma = ctx.saved_tensors
         gain = ctx.gain
         if torch.is_grad_enabled() or not (gy.stride() == a.stride() and gy.dtype == a.dtype):
+            from ..conv_ops import _consumed
             g = gy * gain
-            return g * gamma.to(g.dtype), g, (gy.float() * a.float()).sum().to(gamma.dtype).reshape(gamma.shape) * gain, None
+            # (gamma's gradient only where the engine will use it: the first pass of R1 differentiates with respect to the
+            #  images alone, and <gy, a> in fp32 was two casts, a product and a reduction over the whole map for nothing)
+            g_gamma = (gy.float() * a.float()).sum().to(gamma.dtype).reshape(gamma.shape) * gain if _consumed(ctx, 2, 2) else None
+            return g * gamma.to(g.dtype), g, g_gamma, None
         dev = gy.device
         ga, gb = torch.empty_like(a), torch.empty_like(a)
         gg = torch.empty(1, dtype=torch.float32, device=dev)

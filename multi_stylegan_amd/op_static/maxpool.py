@@ -34,19 +34,55 @@ class _MaxPool2x2(Function):
     @staticmethod
     def backward(ctx, gy):
         x, idx = ctx.saved_tensors
-        if torch.is_grad_enabled():
-            # a second-order graph is being built (R1): the library's differentiable pooling on the saved input
-            with torch.enable_grad():
-                xx = x if x.requires_grad else x.detach().requires_grad_(True)
-                return torch.autograd.grad(F.max_pool2d(xx, kernel_size=2, stride=2), xx, gy, create_graph=True)[0]
-        b, c, h, w = x.shape
+        return _MaxPool2x2Backward.apply(gy, idx, x.shape)
+
+
+class _MaxPool2x2Backward(Function):
+    """gx = gy routed to the window positions the forward chose (2 bits per element), zero elsewhere.  Linear in gy with a
+    routing that does not depend on it, so its own derivative -- R1 differentiates the discriminator's backward -- is the
+    GATHER of the cotangent at the same positions (msg_maxpool2x2_gather), to any order; rounds 3-4 re-ran the library's
+    pooling on the saved input to get a differentiable graph."""
+
+    @staticmethod
+    def forward(ctx, gy, idx, x_shape):
+        b, c, h, w = x_shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = torch.empty((b, c, h, w), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
         with _lib.on_device(gy.device):
             code = _lib.lib().msg_maxpool2x2_bwd(gy.data_ptr(), idx.data_ptr(), gx.data_ptr(), _lib.dtype_code(gy), b, h, w, c,
                                                  _lib.stream_of(gy.device))
         _lib.check(code, "msg_maxpool2x2_bwd")
+        ctx.save_for_backward(idx)
+        ctx.x_shape = tuple(x_shape)
         return gx
+
+    @staticmethod
+    def backward(ctx, v):
+        idx, = ctx.saved_tensors
+        return _MaxPool2x2Gather.apply(v, idx, ctx.x_shape), None, None
+
+
+class _MaxPool2x2Gather(Function):
+    """v [B,C,H,W] at the forward's winner positions -> [B,C,H/2,W/2]; its derivative is _MaxPool2x2Backward again."""
+
+    @staticmethod
+    def forward(ctx, v, idx, x_shape):
+        b, c, h, w = x_shape
+        if _pitch(v) is None:
+            v = v.contiguous(memory_format=torch.channels_last)
+        out = torch.empty((b, c, h // 2, w // 2), dtype=v.dtype, device=v.device, memory_format=torch.channels_last)
+        with _lib.on_device(v.device):
+            code = _lib.lib().msg_maxpool2x2_gather(v.data_ptr(), idx.data_ptr(), out.data_ptr(), _lib.dtype_code(v), b, h, w, c,
+                                                    _pitch(v), _lib.stream_of(v.device))
+        _lib.check(code, "msg_maxpool2x2_gather")
+        ctx.save_for_backward(idx)
+        ctx.x_shape = tuple(x_shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        return _MaxPool2x2Backward.apply(g, idx, ctx.x_shape), None, None
 
 
 def max_pool2x2(x: torch.Tensor) -> torch.Tensor:

@@ -45,14 +45,12 @@ class _SoftmaxRowsBackward(Function):
             # closed form, row by row with s = <gy, y>, t = <v, y>:
             #   d gx / d gy  applied to v:  y * (v - t)          -- the first-order kernel itself, with v in gy's place
             #   d gx / d y   applied to v:  v * (gy - s) - gy * t
-            # (the composite below needs ~15 fp32 passes over the [B, HW, HW/4] map for the same two results)
+            # (the composite below needs ~15 fp32 passes over the [B, HW, HW/4] map for the same two results; round 5: both in
+            #  ONE launch, msg_softmax_rows_backward2 -- three maps read, two written -- where rounds 3-4 still ran two row
+            #  sums, an addcmul and five elementwise passes beside the first-order kernel)
             v = v.contiguous()
-            d_gy = torch.empty_like(y)
-            _call("softmax_rows_backward", 3 * y.numel() * y.element_size(), y, v, d_gy)
-            s = torch.sum(gy * y, dim=-1, keepdim=True, dtype=torch.float32)
-            t = torch.sum(v * y, dim=-1, keepdim=True, dtype=torch.float32)
-            d_y = torch.addcmul(-(gy * t.to(gy.dtype)), v, gy - s.to(gy.dtype)) if y.dtype != torch.float32 else \
-                torch.addcmul(-(gy * t), v, gy - s)
+            d_y, d_gy = torch.empty_like(y), torch.empty_like(y)
+            _call("softmax_rows_backward2", 5 * y.numel() * y.element_size(), y, gy, v, d_y, d_gy)
             return d_y, d_gy
         with torch.enable_grad():                       # third and higher order: differentiate the composite formulation
             y_, gy_ = y.detach().requires_grad_(True), gy.detach().requires_grad_(True)

@@ -246,7 +246,8 @@ def test_config5_full_size_training_iteration_with_ada():
     """BASELINE config 5's per-GPU work as ONE training iteration at its own size: 256x256, 7 x 512 channels, batch 16, bf16
     storage, the discriminator (non-local blocks are always on) wrapped in adaptive discriminator augmentation
     (reference adaptive_discriminator_augmentation.py:63-96).  Iterations 15 (plain) and 16 (R1 on the batch ADA augmented in
-    place, path length): every loss finite, the real batch really was augmented in place, the controller counted the four fake
+    place -- the trainer's concatenated real + fake batch, test_wrapper_augments_in_place_and_skips_cut_mix --, path length):
+    every loss finite, the controller counted the four fake
     batches it saw (D step + G step per iteration) and moved p by +-p_step on the DEVICE (no host round trip: `_p` is a device
     tensor, `r_history` holds device scalars), parameters finite, memory well inside one MI355X."""
     import multi_stylegan_amd as m
@@ -264,10 +265,7 @@ def test_config5_full_size_training_iteration_with_ada():
     torch.cuda.reset_peak_memory_stats()
     real = torch.rand(16, 2, 3, 256, 256, device=DEV)
     for it in (15, 16):
-        batch = real.clone()
-        tr.train_iteration(batch)
-        assert not torch.equal(batch, real), "ADA did not augment the batch in place"
-        assert torch.isfinite(batch).all()
+        tr.train_iteration(real.clone())
     logs = tr.pop_logs()
     assert {"loss_discriminator_real", "loss_discriminator_regularization", "loss_generator", "path_length"} <= set(logs)
     assert all(math.isfinite(v) for vals in logs.values() for v in vals), logs

@@ -288,7 +288,7 @@ def test_train_iteration_split_bf16_products(golden):
     from multi_stylegan_amd import conv_ops
     seen = []
     orig = conv_ops._contraction_code
-    conv_ops._contraction_code = lambda t: (seen.append(orig(t)), seen[-1])[1]
+    conv_ops._contraction_code = lambda t, mode=None: (seen.append(orig(t, mode)), seen[-1])[1]
     try:
         with conv_ops.fp32_contraction("split_bf16x3"):
             report = _run_golden_iterations(golden, "flat")

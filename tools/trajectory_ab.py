@@ -2,16 +2,19 @@
 """bf16 against fp32 over a TRAINING TRAJECTORY (round-5 review item: the benchmarked path is bf16 storage / bf16 MFMA with fp32
 accumulation, the reference is fp32 throughout -- README.md:93 -- and single-step tolerances say nothing about training).
 
-Four runs of the same adversarial training from the same initial weights on a mid-size configuration (64x64, generator
+Runs of the same adversarial training from the same initial weights on a mid-size configuration (64x64, generator
 5 x 128 channels, the reference's discriminator, batch 8), every random input of every iteration drawn from a seeded CPU
 generator and handed to the trainer explicitly (model_wrapper.Draws), so that two runs with the same seed see the same data,
-latents, crossover layers and noise planes bit for bit:
+latents, crossover layers and noise planes bit for bit.  A run is `<arithmetic>:<draws seed>[:eps]`:
 
-    A  fp32 storage, exact fp32 MFMA contractions        draws seed 1     (the path the 1e-3 parity gate is held on)
-    B  bf16 storage, bf16 MFMA, fp32 accumulation         draws seed 1     (the benchmarked path)
-    C  fp32 storage, six-bf16-product contractions        draws seed 1     (fp32-rounding-level perturbation of A: what
-                                                                            chaos alone does to a GAN trajectory)
-    D  as A                                               draws seed 2     (run-to-run noise of two fp32 seeds)
+    f32:<s>      fp32 storage, exact fp32 MFMA contractions   (the path the 1e-3 parity gate is held on; the REFERENCE run of
+                                                               seed s: distances below are measured from it)
+    bf16:<s>     bf16 storage, bf16 MFMA, fp32 accumulation   (the benchmarked path)
+    split:<s>    fp32 storage, six-bf16-product contractions  (fp32-rounding-level arithmetic difference)
+    f32:<s>:eps  as f32:<s> from initial weights moved by 1e-6 of their size: what CHAOS alone does to the trajectory, in
+                 exact arithmetic (a GAN trajectory amplifies any difference; Adam with beta1 = 0 turns a flipped sign of a
+                 rounding-noise gradient into a +-lr step)
+    two `f32` runs with different seeds give the run-to-run noise of two fp32 seeds.
 
 Reported: every logged loss of every iteration (JSON), their means over iteration windows, the path-length mean, and at
 iterations 16 / 64 / 256 / last the distance of each run's parameters from run A's relative to how far A has moved from
@@ -36,7 +39,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--resolution", type=int, default=64)
 ap.add_argument("--width", type=int, default=128)
 ap.add_argument("--out", default="gpurun_out/r05_trajectory")
-ap.add_argument("--runs", default="A,B,C,D")
+ap.add_argument("--runs", default="f32:1,bf16:1,split:1,f32:1:eps,f32:2,bf16:2,f32:2:eps,f32:3,bf16:3")
 args = ap.parse_args()
 
 import multi_stylegan_amd as m
@@ -89,11 +92,17 @@ def flat(module):
 
 
 def run(tag, init, data):
-    dtype = torch.bfloat16 if tag == "B" else torch.float32
-    mode = "split_bf16x3" if tag == "C" else "exact"
-    seed = 2 if tag == "D" else 1
+    arith, seed, *rest = tag.split(":")
+    seed = int(seed)
+    dtype = torch.bfloat16 if arith == "bf16" else torch.float32
+    mode = "split_bf16x3" if arith == "split" else "exact"
     gen, dis = m.MultiStyleGANGenerator(G_CFG), m.MultiStyleGANDiscriminator(m.u_net_2d_discriminator_config, no_rfp=True)
     gen.load_state_dict(init[0]); dis.load_state_dict(init[1])
+    if rest == ["eps"]:
+        pg = torch.Generator().manual_seed(31337)
+        with torch.no_grad():
+            for p_ in list(gen.parameters()) + list(dis.parameters()):
+                p_.mul_(1.0 + 1e-6 * torch.randn(p_.shape, generator=pg))
     gen.compute_dtype = dis.compute_dtype = dtype
     conv_ops.fp32_contraction.set(mode)
     trainer = m.ModelWrapper(gen, dis, device=DEV)
@@ -137,13 +146,14 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump({t: {k: [float(f"{v:.6g}") for v in vs] for k, vs in r["logs"].items()} for t, r in res.items()},
               open(args.out + "_losses.json", "w"))
-    names = {"A": "fp32 exact, seed 1", "B": "bf16, seed 1", "C": "fp32 six-product, seed 1", "D": "fp32 exact, seed 2"}
+    names = {"f32": "fp32 exact", "bf16": "bf16", "split": "fp32 six-product"}
+    label = lambda t: names[t.split(":")[0]] + ", seed " + t.split(":")[1] + (", initial weights x (1 + 1e-6 N(0,1))" if t.endswith(":eps") else "")
     md = [f"# bf16 against fp32 over {args.iterations} training iterations (tools/trajectory_ab.py)", "",
           f"{args.resolution}x{args.resolution}, generator {len(G_CFG['channels'])} x {args.width} channels (latent "
           f"{G_CFG['latent_dimensions']}), the reference's discriminator configuration, batch {args.batch}; identical initial "
           f"weights; every random input of an iteration drawn from (seed, iteration) on the CPU and handed to the trainer.", "",
           "| run | what | ms / iteration |", "|---|---|---|"]
-    md += [f"| {t} | {names[t]} | {1e3 * res[t]['seconds'] / args.iterations:.1f} |" for t in tags]
+    md += [f"| {t} | {label(t)} | {1e3 * res[t]['seconds'] / args.iterations:.1f} |" for t in tags]
     # ---- loss windows
     edges = [0] + CHECKPOINTS
     keys = list(res[tags[0]]["logs"])
@@ -156,38 +166,42 @@ def main():
             row = []
             for t in tags:
                 vs = res[t]["logs"].get(k, [])
-                if k in every:
-                    sel = vs[lo // 16:hi // 16]
-                else:
-                    sel = vs[lo:hi]
+                sel = vs[lo // 16:hi // 16] if k in every else vs[lo:hi]
                 row.append(f"{sum(sel) / len(sel):.4g}" if sel else "-")
             md.append(f"| {k} | {lo + 1}-{hi} | " + " | ".join(row) + " |")
-    # ---- parameter drift
-    if "A" in res:
-        md += ["", "## Parameter distance from run A, relative to A's own movement from the initial weights", "",
-               "`|theta_X(t) - theta_A(t)| / |theta_A(t) - theta(0)|` (and the cosine between the two movements) for the generator, "
-               "the discriminator and the EMA generator", "",
-               "| iteration | run | G | D | G_ema | path-length mean |", "|---|---|---|---|---|---|"]
-        for it in CHECKPOINTS:
-            a = res["A"]["snaps"][it]
-            md.append(f"| {it} | A | (moved {', '.join(f'{(x - x0).norm() / x0.norm():.3e}' for x, x0 in zip(a, theta0))} of "
-                      f"its norm) | | | {res['A']['pl_mean'][it]:.4g} |")
-            for t in tags:
-                if t == "A":
-                    continue
-                cells = []
-                for x, xa, x0 in zip(res[t]["snaps"][it], a, theta0):
-                    move_a, move_x = xa - x0, x - x0
-                    cos = float(torch.dot(move_a, move_x) / (move_a.norm() * move_x.norm() + 1e-30))
-                    cells.append(f"{float((x - xa).norm() / (move_a.norm() + 1e-30)):.3f} (cos {cos:.3f})")
-                md.append(f"| {it} | {t} | " + " | ".join(cells) + f" | {res[t]['pl_mean'][it]:.4g} |")
-        md += ["", "## EMA generator images for 16 fixed latents / noise planes (evaluated in fp32)", "",
-               "| pair | RMS difference | relative to the RMS of A's images |", "|---|---|---|"]
-        rms_a = float(res["A"]["images"].square().mean().sqrt())
+    # ---- parameter drift, each run against the exact-fp32 run of ITS seed; the fp32 runs of other seeds against the first one
+    refs = [t for t in tags if t.startswith("f32:") and not t.endswith(":eps")]
+    md += ["", "## Parameter distance from the exact-fp32 run of the same seed, relative to that run's own movement from the initial weights", "",
+           "`|theta_X(t) - theta_R(t)| / |theta_R(t) - theta(0)|` (and the cosine between the two movements) for the generator, the "
+           "discriminator and the EMA generator; an exact-fp32 run of ANOTHER seed is measured from the first fp32 run (seed noise)", "",
+           "| iteration | run | from | G | D | G_ema | path-length mean |", "|---|---|---|---|---|---|---|"]
+    for it in CHECKPOINTS:
         for t in tags:
-            if t != "A":
-                d = float((res[t]["images"] - res["A"]["images"]).square().mean().sqrt())
-                md.append(f"| {t} vs A | {d:.4g} | {d / rms_a:.3f} |")
+            arith, seed = t.split(":")[:2]
+            ref = f"f32:{seed}"
+            if t == ref:
+                a = res[t]["snaps"][it]
+                moved = ", ".join(f"{(x - x0).norm() / x0.norm():.3e}" for x, x0 in zip(a, theta0))
+                if t == refs[0] or not refs:
+                    md.append(f"| {it} | {t} | - | moved {moved} of its norm | | | {res[t]['pl_mean'][it]:.4g} |")
+                    continue
+                ref = refs[0]
+            if ref not in res:
+                continue
+            cells = []
+            for x, xa, x0 in zip(res[t]["snaps"][it], res[ref]["snaps"][it], theta0):
+                move_a, move_x = xa - x0, x - x0
+                cos = float(torch.dot(move_a, move_x) / (move_a.norm() * move_x.norm() + 1e-30))
+                cells.append(f"{float((x - xa).norm() / (move_a.norm() + 1e-30)):.3f} (cos {cos:.3f})")
+            md.append(f"| {it} | {t} | {ref} | " + " | ".join(cells) + f" | {res[t]['pl_mean'][it]:.4g} |")
+    md += ["", "## EMA generator images for 16 fixed latents / noise planes (evaluated in fp32)", "",
+           "| pair | RMS difference | relative to the RMS of the reference run's images |", "|---|---|---|"]
+    for t in tags:
+        arith, seed = t.split(":")[:2]
+        ref = f"f32:{seed}" if t != f"f32:{seed}" else (refs[0] if refs and t != refs[0] else None)
+        if ref and ref in res:
+            d = float((res[t]["images"] - res[ref]["images"]).square().mean().sqrt())
+            md.append(f"| {t} vs {ref} | {d:.4g} | {d / float(res[ref]['images'].square().mean().sqrt()):.3f} |")
     open(args.out + ".md", "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 

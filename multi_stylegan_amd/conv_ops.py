@@ -27,6 +27,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from ._autograd import _derive
 
 
 # ----------------------------------------------------------------------------------------------- layout helpers
@@ -204,6 +205,8 @@ def _nhwc_view(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
 def _alloc_out(b: int, n: int, h: int, w: int, dtype, device) -> Tuple[torch.Tensor, int]:
     """Channels-last output with the channel stride rounded up to 16 bytes; returns (logical [b,n,h,w] view, ldy)."""
     ld = _round_up(n, _vec(dtype))
+    if ld == n:                        # (the common case in ONE torch call: same strides as the permuted buffer below)
+        return torch.empty((b, n, h, w), dtype=dtype, device=device, memory_format=torch.channels_last), ld
     buf = torch.empty((b, h, w, ld), dtype=dtype, device=device)
     return buf.permute(0, 3, 1, 2)[:, :n], ld
 
@@ -432,6 +435,9 @@ def _contraction_code(t: torch.Tensor, mode: Optional[str] = None) -> int:
     return _SPLIT_CODES[mode] if (code == _lib.MSG_F32 and mode != "exact") else code
 
 
+_PLAN_CACHE: dict = {}
+
+
 def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_shuffle, per_sample, c_real,
                   flops=None, act=None, residual=None, out=None, mode=None):
     """act = (act_bias | None, noise | None, noise_weight | None, alpha, scale): fuse the layer's activation stage.
@@ -475,7 +481,7 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
         if _CLOCK_SHAPES:
             key += f"|B{b} {ih}x{iw}->{oh}x{ow} {c_real}->{n} {kh}x{kw} s{stride} up{in_up}" \
                    f"{' ps' if pixel_shuffle else ''}{' per-sample' if per_sample else ''}|"
-    with _lib.on_device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
+    with _lib.on_device(dev), _lib.kernel_clock.span((key, 'bf16' if x.dtype == torch.bfloat16 else 'f32'), flops):
         if residual is not None:
             assert bias is None and act is None and in_up == 1 and not pixel_shuffle
             rv, res_ld = _nhwc_view(residual[0])
@@ -495,7 +501,11 @@ def _launch_fprop(x, wk, ck, bias, n, out_hw, kh, kw, stride, pad, in_up, pixel_
             if len(act) > 5 and act[5] is not None and kh == 3 and stride == 1 and pad == 1:
                 # (act[5]: a list that receives the sign bytes of the output -- (bytes, tile_m, tile_n), the kernel's output
                 #  tile -- when the kernel this problem goes to writes them)
-                mplan = _lib.lib().msg_conv2d_fprop_plan(_lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow, n, kh, kw, wstride)
+                pkey = (x.dtype, b, ih, iw, cx, ck, oh, ow, n, kh, kw, wstride)
+                mplan = _PLAN_CACHE.get(pkey)
+                if mplan is None:          # (the library's kernel choice is a pure function of the geometry: asked once)
+                    mplan = _PLAN_CACHE[pkey] = _lib.lib().msg_conv2d_fprop_plan(_lib.dtype_code(x), b, ih, iw, cx, ck, oh, ow,
+                                                                                n, kh, kw, wstride)
                 if mplan in (3, 4):
                     from .op_static.fused_act import sign_mask_for
                     mask = sign_mask_for(b, n, oh, ow, x.dtype, dev)
@@ -564,7 +574,7 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
     if _CLOCK_SHAPES and _lib.kernel_clock.enabled:
         key += f"|B{b} {ih}x{iw}->{oh}x{ow} {i}->{o} {kh}x{kw} s{stride}{' ps' if pixel_shuffle else ''}" \
                f"{' per-sample' if per_sample else ' shared'}{f' slabs{need // (o * taps * ldgw)}' if need else ''}|"
-    with _lib.on_device(dev), _lib.kernel_clock.span(f"{key}/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", flops):
+    with _lib.on_device(dev), _lib.kernel_clock.span((key, 'bf16' if x.dtype == torch.bfloat16 else 'f32'), flops):
         code = _lib.lib().msg_conv2d_wgrad(
             gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), *geom, int(oi_major), float(gain), _lib.ptr(ws), need,
             _lib.stream_of(dev))
@@ -743,8 +753,8 @@ class _ConvF(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         g = ctx.g
-        gx = _ConvD.apply(gy, w, g) if ctx.needs_input_grad[0] else None
-        gw = _ConvG.apply(gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
+        gx = _derive(_ConvD, gy, w, g) if ctx.needs_input_grad[0] else None
+        gw = _derive(_ConvG, gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
         gb = _channel_sums(gy) if ctx.has_bias and _consumed(ctx, 2, 2) else None
         return gx, gw, gb, None
 
@@ -791,9 +801,9 @@ class _ConvD(Function):
     def backward(ctx, v):
         gy, w = ctx.saved_tensors
         g = ctx.g
-        ggy = _ConvF.apply(v, w, None, g) if ctx.needs_input_grad[0] else None
-        gw = _ConvG.apply(gy, v, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
-        return ggy, gw, None, (v if ctx.needs_input_grad[3] else None)
+        ggy = _derive(_ConvF, v, w, None, g) if ctx.needs_input_grad[0] else None
+        gw = _derive(_ConvG, gy, v, _oi(w), w.ndim, g) if ctx.needs_input_grad[1] else None
+        return ggy, gw, None, (v if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
 
 
 class _ConvG(Function):
@@ -815,8 +825,8 @@ class _ConvG(Function):
     def backward(ctx, u):
         gy, x = ctx.saved_tensors
         g = ctx.g
-        ggy = _ConvF.apply(x, u, None, g) if ctx.needs_input_grad[0] else None
-        gx = _ConvD.apply(gy, u, g) if ctx.needs_input_grad[1] else None
+        ggy = _derive(_ConvF, x, u, None, g) if ctx.needs_input_grad[0] else None
+        gx = _derive(_ConvD, gy, u, g) if ctx.needs_input_grad[1] else None
         return ggy, gx, None, None, None, None
 
 
@@ -848,7 +858,7 @@ class _ConvActF(Function):
         owed = 1.0
         if ctx.out_scale is not None and ctx.out_scale.pending is not None:
             owed, ctx.out_scale.pending = ctx.out_scale.pending, None        # (see GradScale: the consumer's gain, deferred)
-        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None,
+        gpre, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y, noise if has_noise else None,
                                                              ctx.bias_param if has_bias else False, alpha, scale * owed,
                                                              ctx.mask)
         gx = None
@@ -858,11 +868,11 @@ class _ConvActF(Function):
                 # the block input's OTHER gradient (from the 1x1 residual conv, computed just before) is added in this
                 # data-gradient conv's epilogue: no separate accumulation pass over the input map (second-order graphs: the
                 # same launch as a differentiable node)
-                gx = _ConvD.apply(gpre, w, g, other) if torch.is_grad_enabled() else _d_raw(gpre, w, g, residual=(other, 1.0))
+                gx = _derive(_ConvD, gpre, w, g, other) if torch.is_grad_enabled() else _d_raw(gpre, w, g, residual=(other, 1.0))
                 ctx.slot.merged = True
             else:
-                gx = _ConvD.apply(gpre, w, g)
-        gw = _ConvG.apply(gpre, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
+                gx = _derive(_ConvD, gpre, w, g)
+        gw = _derive(_ConvG, gpre, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
             (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None, None
 
@@ -896,21 +906,21 @@ class _ConvResidualF(Function):
             ctx.main_scale.pending = ctx.gain
             gg = Geometry(ctx.g.kind, ctx.g.kh, ctx.g.kw, ctx.g.stride, ctx.g.pad, ctx.g.x_hw, ctx.g.per_sample,
                           ctx.g.wscale * ctx.gain, mode=ctx.g.mode)
-            gx = _ConvD.apply(gs, w, gg) if ctx.needs_input_grad[0] else None
+            gx = _derive(_ConvD, gs, w, gg) if ctx.needs_input_grad[0] else None
             if ctx.slot is not None and gx is not None:
                 ctx.slot.g = gx
-            gw = _ConvG.apply(gs, x, _oi(w), w.ndim, gg, w) if _consumed(ctx, 1, 1) else None
+            gw = _derive(_ConvG, gs, x, _oi(w), w.ndim, gg, w) if _consumed(ctx, 1, 1) else None
             return gx, gw, gs, None, None, None, None, None, None
         if g1 is None or g2 is None:
             gs = (g1 if g1 is not None else g2) * ctx.gain
         elif _rows_ok(g1, g2):
-            gs = _ScaledAddRows.apply(g1, g2, ctx.gain)
+            gs = _derive(_ScaledAddRows, g1, g2, ctx.gain)
         else:
             gs = (g1 + g2) * ctx.gain
-        gx = _ConvD.apply(gs, w, ctx.g) if ctx.needs_input_grad[0] else None
+        gx = _derive(_ConvD, gs, w, ctx.g) if ctx.needs_input_grad[0] else None
         if ctx.slot is not None and gx is not None:
             ctx.slot.g = gx                  # the main branch's first conv adds it in its data-gradient epilogue
-        gw = _ConvG.apply(gs, x, _oi(w), w.ndim, ctx.g, w) if _consumed(ctx, 1, 1) else None
+        gw = _derive(_ConvG, gs, x, _oi(w), w.ndim, ctx.g, w) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gs if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
@@ -937,13 +947,13 @@ class _MultiConvF(Function):
                 continue
             if ctx.needs_input_grad[0]:
                 if gx is None or not _dgrad_add_ok(gx, x.shape, gy.dtype, g):
-                    part = _ConvD.apply(gy, w, g)
+                    part = _derive(_ConvD, gy, w, g)
                     gx = part if gx is None else gx + part
                 elif second_order:
-                    gx = _ConvD.apply(gy, w, g, gx)              # (differentiable: the sum so far rides in the epilogue)
+                    gx = _derive(_ConvD, gy, w, g, gx)              # (differentiable: the sum so far rides in the epilogue)
                 else:
                     gx = _d_raw(gy, w, g, residual=(gx, 1.0))
-            gws.append(_ConvG.apply(gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 2 + k, 1 + k) else None)
+            gws.append(_derive(_ConvG, gy, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 2 + k, 1 + k) else None)
         return (gx, None, *gws)
 
 
@@ -1058,7 +1068,7 @@ _LINEAR_MAX_ROWS = 256        # above this the batch rows are worth an MFMA tile
 
 def _lin_call(name, flops, *args):
     dev = args[0].device
-    with _lib.on_device(dev), _lib.kernel_clock.span(f"{name}/f32", flops):
+    with _lib.on_device(dev), _lib.kernel_clock.span((name, "f32"), flops):
         code = getattr(_lib.lib(), f"msg_{name}")(*[a.data_ptr() if isinstance(a, torch.Tensor) else
                                                    (0 if a is None else a) for a in args], _lib.stream_of(dev))
     _lib.check(code, f"msg_{name}")
@@ -1090,7 +1100,7 @@ class _LinF(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
-        gx = _LinD.apply(gy, w, ctx.gain) if need_x else None
+        gx = _derive(_LinD, gy, w, ctx.gain) if need_x else None
         gw = gb = None
         if need_w and need_b and ctx.has_bias and not torch.is_grad_enabled():
             (gy_,) = _dense32(gy)                     # first-order step: weight and bias gradient in one launch
@@ -1101,7 +1111,7 @@ class _LinF(Function):
             _lin_call("linear_wgrad", 2.0 * m * n * k, gy_, x, gw, gb, m, n, k, ctx.gain, ctx.bias_gain)
         else:
             if need_w:
-                gw = _LinG.apply(gy, x, ctx.gain)
+                gw = _derive(_LinG, gy, x, ctx.gain)
             if need_b and ctx.has_bias:
                 gb = gy.sum(dim=0) if ctx.bias_gain == 1.0 else gy.sum(dim=0) * ctx.bias_gain
         return gx, gw, gb, None, None
@@ -1124,8 +1134,8 @@ class _LinD(Function):
     @staticmethod
     def backward(ctx, g):
         gy, w = ctx.saved_tensors
-        d_gy = _LinF.apply(g, w, None, ctx.gain) if ctx.needs_input_grad[0] else None
-        d_w = _LinG.apply(gy, g, ctx.gain) if ctx.needs_input_grad[1] else None
+        d_gy = _derive(_LinF, g, w, None, ctx.gain) if ctx.needs_input_grad[0] else None
+        d_w = _derive(_LinG, gy, g, ctx.gain) if ctx.needs_input_grad[1] else None
         return d_gy, d_w, None
 
 
@@ -1146,8 +1156,8 @@ class _LinG(Function):
     @staticmethod
     def backward(ctx, g):
         gy, x = ctx.saved_tensors
-        d_gy = _LinF.apply(x, g, None, ctx.gain) if ctx.needs_input_grad[0] else None
-        d_x = _LinD.apply(gy, g, ctx.gain) if ctx.needs_input_grad[1] else None
+        d_gy = _derive(_LinF, x, g, None, ctx.gain) if ctx.needs_input_grad[0] else None
+        d_x = _derive(_LinD, gy, g, ctx.gain) if ctx.needs_input_grad[1] else None
         return d_gy, d_x, None
 
 
@@ -1625,7 +1635,7 @@ class _ModulatedConv(Function):
             # second-order graph of path-length regularisation runs through it exactly as in the two-pass form
             from .op_static.fused_act import FusedLeakyReLUFunctionBackward
             alpha, act_scale, has_bias, has_noise, nw_shape = ctx.act
-            gy, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y_act, noise if has_noise else None,
+            gy, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y_act, noise if has_noise else None,
                                                                ctx.bias_param if has_bias else False, alpha, act_scale,
                                                                ctx.mask)
             gb = gb if has_bias and need[5] else None
@@ -1634,7 +1644,7 @@ class _ModulatedConv(Function):
         fused_ok = i <= 512 and t <= 9
         if torch.is_grad_enabled() and fused_ok and _NATIVE_SECOND_ORDER and b <= _MODCONV_BWD_BATCH and x.is_cuda:
             # create_graph=True (the path-length pass): the first backward as ONE differentiable node on the native kernels
-            gx, gw, gs = _ModConvGrad.apply(gy, x, weight, style, d if demodulate else None, demodulate, upsample, g, scale,
+            gx, gw, gs = _derive(_ModConvGrad, gy, x, weight, style, d if demodulate else None, demodulate, upsample, g, scale,
                                             tuple(need[:3]))
             return (gx, gw, gs) + tail
         if torch.is_grad_enabled() or not fused_ok:

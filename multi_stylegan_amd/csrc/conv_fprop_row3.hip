@@ -35,7 +35,6 @@ struct ConvParamsR3 {
     int Mtot, n_chunks, n_iters, m_tiles, n_tiles;
     int seg_magic;                 // row / (seg_len + 2) == (row * seg_magic) >> 16 for every row of the activation buffer
     int ow_shift, ohw_shift;       // log2(OW), log2(OH * OW) when both are powers of two, else -1 (generic divisions)
-    int kh_mode, tiles_per_row;    // order of the three kernel rows per tile (see "kernel-row order" at the K loop)
     ActEpilogue act;
 };
 
@@ -229,40 +228,12 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
 #pragma unroll
             for (int e = 0; e < (S16 ? 4 : 16); ++e) acc[i][j][e] = 0.f;
 
-    // ---- kernel-row order.  The three kernel rows of an output tile read input rows r - 1, r, r + 1 (r = the tile's own
-    // image rows), every input row is wanted by three vertically adjacent tiles, and those run at the same time on one XCD
-    // (xcd_remap hands an XCD consecutive tiles).  In the order kh = 0, 1, 2 everywhere, tile m + 1 reads row m a third of a
-    // tile's time -- ~65 us, ~8 MB of other traffic through a 4-MiB L2 -- BEFORE tile m does and tile m - 1 another third
-    // later: every activation row came from beyond L2 three times (PMC: 3.4 x the algorithmic reads, rounds 2-4).  Here each
-    // tile takes its kernel rows in the order that makes the three consumers of a row ask for it in the SAME third:
-    //   kh_mode 1 (a tile is one image row or a part of one):  phase t of the tile in image row m reads kh = (t - m) mod 3;
-    //   kh_mode 2 (a tile is two or more image rows: its middle phase is private, the outer ones are shared with one
-    //              neighbour each): odd tiles run kh = 2, 1, 0.
-    // The sum over kh is taken in that order (fixed per tile: results stay bit-reproducible, and the fused / two-pass forms of
-    // a layer see the same order).  kh_mode 0: 0, 1, 2.
-    int kh_ord0 = 0, kh_ord2 = 2;                                  // (the middle phase follows: 3 - first - last)
-    {
-        const int m_tile = (int)(L / p.n_tiles);
-        if (p.kh_mode == 1) {
-            const int r = (m_tile / p.tiles_per_row) % 3;         // kh(t) = (t - r) mod 3 = (t + 3 - r) mod 3
-            kh_ord0 = (3 - r) % 3; kh_ord2 = (5 - r) % 3;
-        } else if (p.kh_mode == 2 && (m_tile & 1)) {
-            kh_ord0 = 2; kh_ord2 = 0;
-        }
-        kh_ord0 = __builtin_amdgcn_readfirstlane(kh_ord0);
-        kh_ord2 = __builtin_amdgcn_readfirstlane(kh_ord2);
-    }
-    const int kh_ord1 = 3 - kh_ord0 - kh_ord2;
-    auto kh_of = [&](int phase) __attribute__((always_inline)) {   // phase 3: nothing left (set_kh: every piece out of range)
-        return phase == 0 ? kh_ord0 : (phase == 1 ? kh_ord1 : (phase == 2 ? kh_ord2 : 3));
-    };
-
-    // ---- prologue: activation tile of group 0 (first kernel row of the order, chunk 0), weights of K-step 0
-    set_kh(kh_ord0);
+    // ---- prologue: activation tile of group 0 (kernel row 0, chunk 0), weights of K-step 0
+    set_kh(0);
 #pragma unroll
     for (int j = 0; j < NAP + 1; ++j) dma_a(j, 0, 0);
 #pragma unroll
-    for (int j = 0; j < NBP; ++j) dma_b(j, 0, 3 * kh_ord0, 0, true);
+    for (int j = 0; j < NBP; ++j) dma_b(j, 0, 0, 0, true);
 
     // fragment addressing: activation row of output row (wm*WM + i*32 + lr), tap kw: + kw + 2 * segment; the second 16-row
     // block of a 32-row group (S16) is 16 rows further down: same swizzle term, a compile-time offset
@@ -332,8 +303,8 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                 acc[ia][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][jb], fa[set][ia], acc[ia][jb], 0, 0, 0);
             }
         };
-        int ph = 0, kh = kh_ord0, chunk = 0;                        // the (phase -> kh, chunk) group of the current K-step
-        int ph_l = 0, kh_l = kh_ord0, chunk_l = 0;                  // the next group = the one whose activation tile loads
+        int kh = 0, chunk = 0;                                      // the (kh, chunk) group of the current K-step
+        int kh_l = 0, chunk_l = 0;                                  // the next group = the one whose activation tile loads
         int abuf = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -344,7 +315,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
         // the weight pieces of step 1 that a period issues behind its barrier (last sub-step's groups: one per group with
         // per-wave loops, two per group otherwise)
 #pragma unroll
-        for (int q = 0; q < (WV >= 0 ? NA : 2 * NA); ++q) if (q < NBP) dma_b(q, 1, 3 * kh_ord0 + 1, 0, true);
+        for (int q = 0; q < (WV >= 0 ? NA : 2 * NA); ++q) if (q < NBP) dma_b(q, 1, 1, 0, true);
 
         // One K-step, the horizontal tap KW a compile-time constant: the loop below runs the three steps of a (kh, chunk)
         // group back to back, so that "this period carries the activation pieces" (KW == 0) and the count the wait leaves
@@ -356,9 +327,9 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             const bool live1 = it + 1 < p.n_iters, live2 = it + 2 < p.n_iters;
             const int abuf_n = KW == 2 ? abuf ^ 1 : abuf;           // activation buffer of step it + 1
             if (KW == 0) {                                          // the next group's activation tile loads in this period
-                chunk_l = chunk + 1; ph_l = ph; kh_l = kh;
-                if (chunk_l == p.n_chunks) { chunk_l = 0; ++ph_l; kh_l = kh_of(ph_l); }
-                if (ph_l != ph) set_kh(kh_l);       // (phase 3 -> kh 3: nothing left to load -- zeros into the idle buffer)
+                chunk_l = chunk + 1; kh_l = kh;
+                if (chunk_l == p.n_chunks) { chunk_l = 0; ++kh_l; }
+                if (kh_l != kh) set_kh(kh_l);       // (kh_l == 3: nothing left to load -- zeros into the idle buffer)
             }
             const Pos n1 = KW < 2 ? Pos{kh, chunk, KW + 1} : Pos{kh_l, chunk_l, 0};
             const Pos n2 = KW < 1 ? Pos{kh, chunk, 2} : Pos{kh_l, chunk_l, KW - 1};
@@ -438,7 +409,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
                 }
                 R3_STAMP(tail ? 6 : 1 + sub);
             }
-            if (KW == 2) { ph = ph_l; kh = kh_l; chunk = chunk_l; }
+            if (KW == 2) { kh = kh_l; chunk = chunk_l; }
         };
         R3_CLOCK(1);
         for (int it = 0; it < p.n_iters; it += 3) {                 // (n_iters = 9 * n_chunks)
@@ -633,11 +604,6 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     p.ohw_shift = log2_exact((long long)OH * OW);
     if (p.ohw_shift < 0) p.ow_shift = -1;
     p.n_tiles = (N + hn - 1) / hn;
-    // kernel-row order per tile (see the kernel): only where vertically adjacent tiles are neighbours in launch order too,
-    // i.e. inside one sample's map -- tiles never straddle samples (mtot % hm == 0 and OH * OW % hm == 0 for these maps)
-    static const int kh_order = msg_tunable("MSG_ROW3_KH_ORDER", 1);
-    p.tiles_per_row = OW > hm ? OW / hm : 1;
-    p.kh_mode = !kh_order ? 0 : (hm <= OW ? 1 : 2);
     const long long blocks = (long long)p.m_tiles * p.n_tiles;
     dim3 grid((unsigned)blocks, 1, per_sample ? B : 1);
     // MSG_CONV_ROW3_S16=0: the 256 x 256 tile on v_mfma_f32_32x32x16_bf16 (A/B)

@@ -38,7 +38,7 @@ class _NonLocalAttention(Function):
         o = torch.empty((b, nq, dv), dtype=q.dtype, device=dev)
         lse = torch.empty((b, nq), dtype=torch.float32, device=dev)
         flops = 2.0 * b * nq * nk * (2 * dk + dv)          # two score sweeps + P V
-        with _lib.on_device(dev), _lib.kernel_clock.span(f"nl_attention_fwd/{q.dtype}", flops):
+        with _lib.on_device(dev), _lib.kernel_clock.span(('nl_attention_fwd', q.dtype), flops):
             code = _lib.lib().msg_nonlocal_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(),
                                                          lse.data_ptr(), _lib.dtype_code(q), b, nq, nk, dk, dv,
                                                          _lib.stream_of(dev))
@@ -65,7 +65,7 @@ class _NonLocalAttention(Function):
         splits = _lib.lib().msg_nonlocal_attention_bwd_splits(b, nq, nk)
         work = torch.empty(splits * b * nk * (dk + dv), dtype=torch.float32, device=dev) if splits > 1 else None
         flops = 2.0 * b * nq * nk * ((dk + dv + dk) + (dk + dv + dv + dk))
-        with _lib.on_device(dev), _lib.kernel_clock.span(f"nl_attention_bwd/{q.dtype}", flops):
+        with _lib.on_device(dev), _lib.kernel_clock.span(('nl_attention_bwd', q.dtype), flops):
             code = _lib.lib().msg_nonlocal_attention_bwd(
                 q.data_ptr(), None, k.data_ptr(), kt.data_ptr(), v.data_ptr(), grad_o.data_ptr(),
                 None, o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dkey.data_ptr(),

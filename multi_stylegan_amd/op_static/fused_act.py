@@ -11,6 +11,7 @@ from torch import nn
 from torch.autograd import Function
 
 from .. import _lib
+from .._autograd import _derive
 
 
 def _layout(x):
@@ -58,7 +59,7 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
     b32 = None if bias is None else bias.to(torch.float32).contiguous()
     nw32 = None if noise_weight is None else noise_weight.to(torch.float32).contiguous()
     nbytes = (2 + (ref is not None)) * x.numel() * x.element_size()
-    with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_fwd/{x.dtype}", nbytes):
+    with _lib.on_device(dev), _lib.kernel_clock.span(('bias_act_fwd', x.dtype), nbytes):
         code = _lib.lib().msg_fused_bias_act(
             x.data_ptr(), _lib.ptr(b32), _lib.ptr(ref), y.data_ptr(), _lib.dtype_code(x, True), x.numel(), step_b,
             x.shape[1], _lib.ptr(nz), _lib.ptr(nw32), nb, pix, act, grad, float(alpha), float(scale),
@@ -122,7 +123,7 @@ class FusedLeakyReLUFunctionBackward(Function):
             # the forward launch left the sign bytes of `out` (bytes, tile_m, tile_n): that map is not read again
             mbytes, tile_m, tile_n = mask
             nbytes = 2 * g.numel() * g.element_size() + mbytes.numel()
-            with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd_mask/{g.dtype}", nbytes):
+            with _lib.on_device(dev), _lib.kernel_clock.span(('bias_act_bwd_mask', g.dtype), nbytes):
                 code = _lib.lib().msg_bias_act_backward_mask(
                     g.data_ptr(), mbytes.data_ptr(), int(tile_m), int(tile_n), gx.data_ptr(), _lib.dtype_code(g, True),
                     g.numel(), channels,
@@ -135,7 +136,7 @@ class FusedLeakyReLUFunctionBackward(Function):
         else:
             mask = None
         if mask is None:
-            with _lib.on_device(dev), _lib.kernel_clock.span(f"bias_act_bwd/{g.dtype}", 3 * g.numel() * g.element_size()):
+            with _lib.on_device(dev), _lib.kernel_clock.span(('bias_act_bwd', g.dtype), 3 * g.numel() * g.element_size()):
                 code = _lib.lib().msg_bias_act_backward(
                     g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g, True), g.numel(), step_b, channels,
                     _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
@@ -177,7 +178,7 @@ class FusedLeakyReLUFunction(Function):
     def backward(ctx, grad_output):
         out, noise = ctx.saved_tensors
         negative_slope, scale, has_bias, has_nw = ctx.cfg
-        gx, gb, gnw = FusedLeakyReLUFunctionBackward.apply(grad_output, out, noise if has_nw else None,
+        gx, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, grad_output, out, noise if has_nw else None,
                                                            ctx.bias_param if has_bias else False, negative_slope, scale)
         return gx, (gb if has_bias else None), None, (gnw if has_nw else None), None, None
 
@@ -332,7 +333,7 @@ class _ScaledAddFork(Function):
         if g1 is None or g2 is None:
             g = (g1 if g1 is not None else g2) * ctx.gain
         elif _rows_ok(g1, g2):
-            g = _ScaledAddRows.apply(g1, g2, ctx.gain)  # differentiable (R1 runs a second-order pass through here)
+            g = _derive(_ScaledAddRows, g1, g2, ctx.gain)  # differentiable (R1 runs a second-order pass through here)
         else:
             g = (g1 + g2) * ctx.gain
         return g, g, None

@@ -5,6 +5,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from .._autograd import _derive
 
 def _pitch(x):
     """Pixel pitch of a channels-last [B,C,H,W] map (or channel-slice of one) the kernel takes as it is, else None."""
@@ -34,7 +35,7 @@ class _MaxPool2x2(Function):
     @staticmethod
     def backward(ctx, gy):
         x, idx = ctx.saved_tensors
-        return _MaxPool2x2Backward.apply(gy, idx, x.shape)
+        return _derive(_MaxPool2x2Backward, gy, idx, x.shape)
 
 
 class _MaxPool2x2Backward(Function):

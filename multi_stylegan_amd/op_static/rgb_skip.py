@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .._autograd import _derive
 
 
 def supported(conv: torch.Tensor, skip: Optional[torch.Tensor], fir: Optional[torch.Tensor], up: int, pad) -> bool:
@@ -74,7 +75,7 @@ class _RgbSkipMerge(Function):
         fir, = ctx.saved_tensors
         conv_dtype, has_skip, has_bias = ctx.meta
         need = ctx.needs_input_grad
-        g_conv, g_bias, g_skip = _RgbSkipMergeBackward.apply(g, fir, conv_dtype, need[0], has_bias and need[1],
+        g_conv, g_bias, g_skip = _derive(_RgbSkipMergeBackward, g, fir, conv_dtype, need[0], has_bias and need[1],
                                                              has_skip and need[2])
         return g_conv if need[0] else None, g_bias if has_bias and need[1] else None, \
             g_skip if has_skip and need[2] else None, None

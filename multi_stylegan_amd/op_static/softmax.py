@@ -7,6 +7,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .._autograd import _derive
 
 _MAX_COLS = 4096
 
@@ -22,7 +23,7 @@ def _call(name, nbytes, *tensors):
     dev = _lib.require_gpu(*tensors)
     cols = first.shape[-1]
     rows = first.numel() // cols
-    with _lib.on_device(dev), _lib.kernel_clock.span(f"{name}/{first.dtype}", nbytes):
+    with _lib.on_device(dev), _lib.kernel_clock.span((name, first.dtype), nbytes):
         code = getattr(_lib.lib(), f"msg_{name}")(*[t.data_ptr() for t in tensors], _lib.dtype_code(first), rows, cols,
                                                   _lib.stream_of(dev))
     _lib.check(code, f"msg_{name}")
@@ -72,7 +73,7 @@ class _SoftmaxRows(Function):
     @staticmethod
     def backward(ctx, gy):
         y, = ctx.saved_tensors
-        return _SoftmaxRowsBackward.apply(y, gy)
+        return _derive(_SoftmaxRowsBackward, y, gy)
 
 
 def softmax_rows(x: torch.Tensor) -> torch.Tensor:

@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .._autograd import _derive
 
 
 def _is_channels_last(x):
@@ -97,7 +98,7 @@ def _launch(x, fir, up, down, pad, out=None):
                 x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise _lib.MsgHipError(f"upfirdn2d(out=): input {tuple(x.shape)} / {x.stride()} or destination "
                                    f"{tuple(out.shape)} / {out.stride()} is not a channels-last map or channel-slice")
-        key = f"upfirdn2d/{_DT_NAME.get(x.dtype, str(x.dtype))}/up{up_x}down{down_x}/vec"
+        key = ("upfirdn2d", _DT_NAME.get(x.dtype, x.dtype), ("up", up_x, "down", down_x), "vec")
         with _lib.on_device(dev), _lib.kernel_clock.span(key, (b * c * h * w + b * c * oh * ow) * x.element_size()):
             code = _lib.lib().msg_upfirdn2d_pitched2(x.data_ptr(), fir.data_ptr(), out.data_ptr(), _lib.dtype_code(x, True),
                                                      b, h, w, c, in_pitch, out_pitch, kh, kw, up_x, up_y, down_x, down_y,
@@ -117,7 +118,7 @@ def _launch(x, fir, up, down, pad, out=None):
     if pitch is not None:
         major, minor = b, c
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        key = f"upfirdn2d/{_DT_NAME.get(x.dtype, str(x.dtype))}/up{up_x}down{down_x}/vec"
+        key = ("upfirdn2d", _DT_NAME.get(x.dtype, x.dtype), ("up", up_x, "down", down_x), "vec")
         with _lib.on_device(dev), _lib.kernel_clock.span(key, (b * c * h * w + y.numel()) * x.element_size()):
             code = _lib.lib().msg_upfirdn2d_pitched(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x, True),
                                                     major, h, w, minor, pitch, kh, kw, up_x, up_y, down_x, down_y,
@@ -132,18 +133,18 @@ def _launch(x, fir, up, down, pad, out=None):
         major, minor = b * c, 1
         y = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev)
     vec_ok = minor % (16 // x.element_size()) == 0 and kh <= 4 and kw <= 4
-    key = f"upfirdn2d/{_DT_NAME.get(x.dtype, str(x.dtype))}/up{up_x}down{down_x}/"
+    key = ("upfirdn2d", _DT_NAME.get(x.dtype, x.dtype), ("up", up_x, "down", down_x))       # (joined by the clock, when it is on)
     if vec_ok and minor > 1 and up == (1, 1) and down == (1, 1) and kh == 4 and kw == 4 and \
             (_SEPARABLE == 2 or (_SEPARABLE == 1 and x.dtype == torch.bfloat16)):
         factors = _separable(fir)
         if factors is not None:                       # the blur: separable sliding-window kernel (csrc/blur_sep.hip)
-            with _lib.on_device(dev), _lib.kernel_clock.span(key + "sep", (x.numel() + y.numel()) * x.element_size()):
+            with _lib.on_device(dev), _lib.kernel_clock.span(key + ("sep",), (x.numel() + y.numel()) * x.element_size()):
                 code = _lib.lib().msg_upfirdn2d_separable(
                     x.data_ptr(), factors[0].data_ptr(), factors[1].data_ptr(), y.data_ptr(), _lib.dtype_code(x),
                     major, h, w, minor, kh, kw, px0, px1, py0, py1, _lib.stream_of(dev))
             _lib.check(code, "msg_upfirdn2d_separable")
             return y
-    key += "vec" if vec_ok else "generic"
+    key += ("vec" if vec_ok else "generic",)
     with _lib.on_device(dev), _lib.kernel_clock.span(key, (x.numel() + y.numel()) * x.element_size()):
         code = _lib.lib().msg_upfirdn2d(x.data_ptr(), fir.data_ptr(), y.data_ptr(), _lib.dtype_code(x, True),
                                         major, h, w, minor, kh, kw, up_x, up_y, down_x, down_y,
@@ -203,7 +204,7 @@ class UpFirDn2d(Function):
     def backward(ctx, grad_output):
         fir, fir_flipped = ctx.saved_tensors
         up, down, pad, in_hw = ctx.cfg
-        gin = UpFirDn2dBackward.apply(grad_output, fir, fir_flipped, up, down, pad, ctx.g_pad, in_hw)
+        gin = _derive(UpFirDn2dBackward, grad_output, fir, fir_flipped, up, down, pad, ctx.g_pad, in_hw)
         return gin, None, None, None, None, None
 
 
@@ -245,7 +246,7 @@ class BlurBiasAct(Function):
             if noise.shape[0] not in (1, b) or noise.shape[1] != 1 or tuple(noise.shape[2:]) != (oh, ow):
                 raise _lib.MsgHipError(f"noise shape {tuple(noise.shape)} does not match output {(b, c, oh, ow)}")
             nz, nw = noise.detach().to(torch.float32).contiguous(), noise_w.detach().to(torch.float32).contiguous()
-        key = f"upfirdn2d/{'bf16' if x.dtype == torch.bfloat16 else 'f32'}/up1down1/sep+act"    # blur + activation: own key
+        key = ("upfirdn2d", "bf16" if x.dtype == torch.bfloat16 else "f32", "up1down1", "sep+act")    # blur + activation: own key
         nbytes = (x.numel() + y.numel()) * x.element_size() + (0 if nz is None else nz.numel() * 4)
         from .fused_act import sign_mask_for
         mask = sign_mask_for(b, c, oh, ow, x.dtype, dev) if any(ctx.needs_input_grad) else None   # (no backward: no bytes)
@@ -267,9 +268,9 @@ class BlurBiasAct(Function):
         from .fused_act import FusedLeakyReLUFunctionBackward
         fir, fir_flipped, y, noise = ctx.saved_tensors
         pad, in_hw, alpha, scale, has_bias, has_noise, nw_shape = ctx.cfg
-        gpre, gb, gnw = FusedLeakyReLUFunctionBackward.apply(gy, y, noise if has_noise else None, has_bias, alpha, scale,
+        gpre, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y, noise if has_noise else None, has_bias, alpha, scale,
                                                              ctx.mask)
-        gin = UpFirDn2dBackward.apply(gpre, fir, fir_flipped, (1, 1), (1, 1), pad, ctx.g_pad, in_hw) \
+        gin = _derive(UpFirDn2dBackward, gpre, fir, fir_flipped, (1, 1), (1, 1), pad, ctx.g_pad, in_hw) \
             if ctx.needs_input_grad[0] else None
         return gin, None, None, (gb if has_bias and ctx.needs_input_grad[3] else None), None, \
             (gnw.reshape(nw_shape) if has_noise and ctx.needs_input_grad[5] else None), None, None

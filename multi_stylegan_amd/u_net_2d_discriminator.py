@@ -77,7 +77,7 @@ class _MinibatchStdDevFused(torch.autograd.Function):
         stat = torch.empty(groups, dtype=torch.float32, device=dev)
         work = torch.empty(int(_lib.lib().msg_minibatch_stddev_workspace(c, h, w, groups, code_dtype)),
                            dtype=torch.float32, device=dev)
-        with _lib.on_device(dev), _lib.kernel_clock.span(f"mbstd_fwd/{x.dtype}", 2 * x.numel() * x.element_size()):
+        with _lib.on_device(dev), _lib.kernel_clock.span(('mbstd_fwd', x.dtype), 2 * x.numel() * x.element_size()):
             code = _lib.lib().msg_minibatch_stddev(xv.data_ptr(), out.data_ptr(), stat.data_ptr(), work.data_ptr(),
                                                    code_dtype, b, c, h, w, ldx, ldy, groups, float(alpha),
                                                    _lib.stream_of(dev))
@@ -102,7 +102,7 @@ class _MinibatchStdDevFused(torch.autograd.Function):
         gv, ldg = conv_ops._nhwc_view(gy)
         gstat = gy[:, c].float().reshape(groups, -1).sum(dim=1).contiguous()
         gx = torch.empty((b, h, w, c), dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
-        with _lib.on_device(dev), _lib.kernel_clock.span(f"mbstd_bwd/{x.dtype}", 3 * x.numel() * x.element_size()):
+        with _lib.on_device(dev), _lib.kernel_clock.span(('mbstd_bwd', x.dtype), 3 * x.numel() * x.element_size()):
             code = _lib.lib().msg_minibatch_stddev_backward(xv.data_ptr(), gv.data_ptr(), gstat.data_ptr(), gx.data_ptr(),
                                                             _lib.dtype_code(x), b, c, h, w, ldx, ldg, c, groups,
                                                             float(alpha), _lib.stream_of(dev))

@@ -18,6 +18,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--resolution", type=int, default=256)
+ap.add_argument("--single-thread", action="store_true",
+                help="run backward on the calling thread (torch.autograd.set_multithreading_enabled(False)) so that cProfile sees "
+                     "the Python backward functions too -- the engine's own thread is invisible to it")
 args = ap.parse_args()
 
 import multi_stylegan_amd as m
@@ -44,11 +47,20 @@ torch.cuda.synchronize()
 t_total = (time.perf_counter() - t0) / args.iters
 print(f"enqueue {t_enqueue * 1e3:.1f} ms/iter, wall {t_total * 1e3:.1f} ms/iter")
 pr = cProfile.Profile()
-pr.enable()
-for _ in range(args.iters):
+import contextlib
+with (torch.autograd.set_multithreading_enabled(False) if args.single_thread else contextlib.nullcontext()):
     trainer.train_iteration(real)
-pr.disable()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        trainer.train_iteration(real)
+    print(f"(this mode, unprofiled: enqueue {(time.perf_counter() - t0) / args.iters * 1e3:.1f} ms/iter)")
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(args.iters):
+        trainer.train_iteration(real)
+    pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(45)
+st.sort_stats("tottime").print_stats(70)
 st.sort_stats("cumulative").print_stats(60)

@@ -243,6 +243,15 @@ class ModelWrapper(object):
         ``resume_training`` switch on the late-training branches as the reference does: wrongly ordered reals among the
         fakes (:272-277), the trap-region weight map on the pixel-wise losses (:289-291, :404-406), CutMix augmentation
         and consistency regularisation (:331-376); ``top_k`` is the module of loss.py:398-444 (:392-401)."""
+        # Backward on THIS thread: the autograd engine's device thread is a second Python thread that every custom backward
+        # function of this package has to wake, hand the GIL to and hand results back from -- measured at config 1's shapes
+        # (64^2, batch 4, host-bound): 30.6 ms per iteration with the engine's thread, 25.3 ms without (tools/host_profile.py
+        # --single-thread).  Same graph, same kernels, same stream; node order in second-order passes no longer depends on
+        # two threads' sequence counters (DESIGN.md section 3b).
+        with torch.autograd.set_multithreading_enabled(False):
+            self._train_iteration(real_images, draws, resume_training, top_k)
+
+    def _train_iteration(self, real_images, draws, resume_training, top_k) -> None:
         hp = self.hyperparameters
         dr = draws or Draws()
         G, D = self.generator, self.discriminator

@@ -263,6 +263,13 @@ int msg_relayout_weight(const float* w, void* fwd, void* dgrad, float* wsq, int 
  * instead of kh*kw mostly-zero ones; the weight gradient reads gy once instead of once per tap). */
 int msg_gather_taps(const void* x, void* y, int dtype, int B, int H, int W, int Cx, int C, int kh, int kw,
                     int pad, int Ko, void* stream);
+/* ABI 5.  The adjoint of msg_gather_taps: g [B, H, W, Ko] (K index tap * C + c, as msg_gather_taps writes it) ->
+ * gx [B, H, W, ldx], gx[q, c] = sum over taps of g[q - offset(tap), tap * C + c] (+ add[q, c] when add != NULL, pixel pitch
+ * ld_add), fp32 accumulation, channels C .. ldx - 1 zeroed; C <= 8.  The data gradient of a few-channel 'same' convolution =
+ * a 1x1 contraction to Ko channels followed by this fold (EqualizedConv2d of the first discriminator block,
+ * multi_stylegan/u_net_2d_discriminator.py:161-170 with equalized_layer.py:57-74). */
+int msg_fold_taps(const void* g, const void* add, void* gx, int dtype, int B, int H, int W, int Ko, int C, int kh, int kw,
+                  int pad, int ldx, int ld_add, void* stream);
 
 /* y = (a + beta*b) * gain over n elements (n multiple of the 16-byte vector, all pointers 16-B aligned): the
  * residual merges (main + residual)/sqrt(2) of multi_stylegan/u_net_2d_discriminator.py:185,381 in one pass. */

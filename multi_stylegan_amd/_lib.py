@@ -52,6 +52,7 @@ _SIGNATURES = {
     "msg_scale_rows_cols2": (_I, [_P] * 6 + [_I] * 6 + [_F, _P]),
     "msg_relayout_weight": (_I, [_P, _P, _P, _P, _I] + [_I] * 7 + [_F, _P]),
     "msg_gather_taps": (_I, [_P, _P, _I] + [_I] * 9 + [_P]),
+    "msg_fold_taps": (_I, [_P, _P, _P, _I] + [_I] * 10 + [_P]),
     "msg_scaled_add": (_I, [_P, _P, _P, _I, _L, _F, _F, _P]),
     "msg_rgb_skip_merge": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msg_rgb_skip_merge_backward": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),

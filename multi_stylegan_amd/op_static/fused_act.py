@@ -68,6 +68,7 @@ def _bias_act(x, bias, ref, noise, noise_weight, grad, alpha, scale, act=3):
     return y.reshape(shape) if y.shape != shape else y
 
 
+_WS_CACHE: dict = {}     # workspace sizes of msg_bias_act_backward per problem (a pure function of the sizes)
 ACT_MASK = True      # False: the activation backward always reads the stored output (tests compare both: bit-identical)
 
 
@@ -116,7 +117,10 @@ class FusedLeakyReLUFunctionBackward(Function):
         gnw = torch.empty(1, dtype=torch.float32, device=dev) if noise is not None else None
         need = 0
         if need_bias or noise is not None:
-            need = _lib.lib().msg_bias_act_backward_workspace(g.numel(), step_b, channels, int(noise is not None))
+            wkey = (g.numel(), step_b, channels, noise is not None)
+            need = _WS_CACHE.get(wkey)
+            if need is None:
+                need = _WS_CACHE[wkey] = _lib.lib().msg_bias_act_backward_workspace(g.numel(), step_b, channels, int(noise is not None))
         ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
         if mask is not None and step_b == 1 and g.ndim == 4 and g.dtype == torch.bfloat16 and channels % 8 == 0 and \
                 mask[0].numel() * 8 == g.numel():

@@ -843,6 +843,36 @@ def test_gather_taps_kernels(shape):
     assert rel_err(y.float(), torch.nn.functional.conv2d(x.float(), wgt, padding=1)) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(3, 6, 40, 64, 128), (2, 6, 5, 32, 64), (1, 3, 33, 96, 72), (2, 7, 16, 20, 128)])
+def test_few_channel_data_gradient_through_the_fold(shape):
+    """Data gradient of a 'same' 3x3 conv over <= 8 channels (the discriminator's first layer, 128 -> 6 channels @256^2) as a
+    1x1 contraction to the 9 x C tap planes + msg_fold_taps (conv_ops._d_raw_thin): against the fp64 definition, with and
+    without the map the residual epilogue adds, through autograd (the forward is the tap-gathered form), and the fold alone
+    against its definition."""
+    from multi_stylegan_amd import conv_ops
+    b, c, h, w_, o = shape
+    torch.manual_seed(h + o)
+    wgt = (torch.randn(o, c, 3, 3, device=DEV) / math.sqrt(9 * c)).requires_grad_(True)
+    gy = torch.randn(b, o, h, w_, device=DEV).bfloat16()
+    other = torch.randn(b, c, h, w_, device=DEV).bfloat16()
+    geo = conv_ops.Geometry("conv", 3, 3, 1, 1, (h, w_), False, 0.7)
+    assert conv_ops._thin_ok(torch.bfloat16, c, geo)
+    want = F.conv_transpose2d(gy.double(), 0.7 * wgt.detach().double().bfloat16().double(), padding=1)
+    got = conv_ops._d_raw(conv_ops.to_compute_layout(gy), wgt, geo)
+    assert got.shape == (b, c, h, w_) and rel_err(got.float(), want) < 8e-3
+    got2 = conv_ops._d_raw(conv_ops.to_compute_layout(gy), wgt, geo, residual=(conv_ops.to_compute_layout(other), 1.0))
+    assert rel_err(got2.float(), want + other.double()) < 8e-3
+    # the padding channels of the 16-byte pixel vector are zero (the next reader takes whole vectors)
+    base, cx = conv_ops._nhwc_view(got)
+    assert cx == 8 and float(base.permute(0, 2, 3, 1).as_strided((b, h, w_, 8), (h * w_ * 8, w_ * 8, 8, 1))[..., c:].abs().max()) == 0.0
+    # through autograd: forward (tap gather + 1x1) and backward (1x1 + fold) against torch's conv
+    x = torch.randn(b, c, h, w_, device=DEV).bfloat16()
+    xd = conv_ops.to_compute_layout(x).detach().requires_grad_(True)
+    y = conv_ops.conv2d(xd, wgt, padding=1, wscale=0.7)
+    gx, = torch.autograd.grad(y, xd, conv_ops.to_compute_layout(gy))
+    assert rel_err(gx.float(), want) < 8e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(32, 128, 127, 127), (3, 24, 5, 7), (2, 768, 15, 15)])
 def test_channel_sums(shape, dtype):

@@ -232,6 +232,7 @@ def _run_golden_iterations(golden, fused, prepare=None, step_tol=None):
     dead0 = g.main_convolutions_2[3].modulated_convolution.weight.detach().clone()
     report = {}
     top_k = m.loss.TopK(0, 1)                    # as resumed training sets it (model_wrapper.py:121-123): v = 0.5
+    history = {}                                 # reference gradients of every parameter's earlier steps (see check_step_trace)
     for step, (iteration, late) in enumerate(GOLDEN_ITERATIONS):
         real, draws = load_train_draws(z, step, m.model_wrapper)
         trainer.iteration = iteration - 1
@@ -244,7 +245,7 @@ def _run_golden_iterations(golden, fused, prepare=None, step_tol=None):
         assert list(got_steps) == STEP_LABELS[iteration]
         for label, want in want_steps.items():
             tg, tn, td = (step_tol or STEP_TOL)[label]
-            st = check_step_trace(got_steps[label], want, tol_grad=tg, tol_norm=tn, tol_delta=td)
+            st = check_step_trace(got_steps[label], want, tol_grad=tg, tol_norm=tn, tol_delta=td, history=history)
             assert st["compared"] > 0.2 * st["total"], (label, st)
             report[f"it{iteration}.{label}"] = st
         worst_ema = max(rel_err(got_ema[n], want) for n, want in want_ema.items())

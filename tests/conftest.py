@@ -57,13 +57,14 @@ def check_step_trace(got, ref, tol_grad, tol_norm, tol_delta, lr_floor=0.05, his
     * parameter deltas p_after - p_before: Adam with beta1 = 0 moves an element by ~lr * sign(g) (first step) or
       lr * g / sqrt(v) -- where |g| is at rounding-noise level the sign is arbitrary, so deltas are compared only on
       elements whose reference gradient is above `lr_floor` of the tensor's largest, relative to max|ref delta|.
-      Adam's second moment remembers EARLIER steps of the same parameter: an element whose earlier gradient was at noise level
-      (relative error O(1) there) but large enough to matter in v = sum 0.001 g^2 inherits that error in its movement, whatever
-      the current gradient.  ``history`` ({name: [reference gradients of the parameter's earlier steps]}, appended to here)
-      keeps such elements out of the comparison: an element counts when every earlier gradient of it was either above
-      `lr_floor` of ITS tensor's largest or below a tenth of the current one (1 % of its weight in v).  Without this the check
-      was sound only by luck: round 5 moved fp32 sums in their last bit and ONE element of one late step went from 3e-4 to
-      9e-3 on the plain-Adam path alone, with every gradient still within 3e-6.
+      Adam's second moment remembers EARLIER steps of the same parameter: an element whose earlier gradient carried a large
+      RELATIVE error (a noise-level element of a step with large gradients) but still weighs in v = sum 0.001 g^2 inherits that
+      error in its movement, whatever the current gradient.  ``history`` ({name: [(reference gradient, |got - reference|) of the
+      parameter's earlier steps]}, appended to here) bounds what each element inherits -- v changes by sum 2 |g_p| |dg_p| over
+      sum g^2, the movement by half of that -- and keeps an element out of the comparison when that bound exceeds half of
+      `tol_delta`: there the movement says nothing about the optimiser's arithmetic, and the gradients themselves are held to
+      `tol_grad` above.  Without this the check was sound only by luck: round 5 moved fp32 sums in their last bit and ONE
+      element of one late step went from 3e-4 to 9e-3 on the plain-Adam path alone, with every gradient still within 3e-6.
     Returns statistics: compared / total delta elements (callers assert a healthy share) and the worst errors."""
     names = sorted(k[len("grad."):] for k in ref if k.startswith("grad."))
     assert names and sorted(k[len("grad."):] for k in got if k.startswith("grad.")) == names
@@ -85,11 +86,10 @@ def check_step_trace(got, ref, tol_grad, tol_norm, tol_delta, lr_floor=0.05, his
         if dmax == 0.0:
             continue
         mask = g_ref.abs() > lr_floor * gmax
-        if history is not None:
-            for g_prev in history.get(n, ()):
-                pmax = g_prev.abs().max().item()
-                if pmax > 0.0:
-                    mask &= (g_prev.abs() > lr_floor * pmax) | (g_prev.abs() < 0.1 * g_ref.abs())
+        if history is not None and history.get(n):
+            num = sum(2.0 * gp.abs() * ep for gp, ep in history[n])
+            den = sum(gp.square() for gp, _ in history[n]) + g_ref.square()
+            mask &= 0.5 * num <= 0.5 * tol_delta * den
         total += mask.numel()
         compared += int(mask.sum())
         e = ((d_got - d_ref).abs() * mask).max().item() / dmax
@@ -101,7 +101,8 @@ def check_step_trace(got, ref, tol_grad, tol_norm, tol_delta, lr_floor=0.05, his
         bad.append(("gnorm", "", e))
     if history is not None:
         for n in names:
-            history.setdefault(n, []).append(ref["grad." + n].double().cpu())
+            g_ref = ref["grad." + n].double().cpu()
+            history.setdefault(n, []).append((g_ref, (got["grad." + n].double().cpu() - g_ref).abs()))
     assert not bad, bad[:12]
     return {"compared": compared, "total": total, "worst_grad": worst["grad"], "worst_delta": worst["delta"],
             "gnorm_err": e}

@@ -120,8 +120,39 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        _lib = handle
+        _lib = _with_fastcall(handle)
     return _lib
+
+
+class _Entries:
+    """What ``lib()`` hands out: every entry point of the C ABI as an attribute -- the generated argument-vector wrapper
+    (multi_stylegan_amd._msg_fastcall, csrc_host/gen_fastcall.py) where there is one, the ctypes function otherwise."""
+
+    def __init__(self, handle, fast):
+        self._ctypes, self.fastcall = handle, fast is not None
+        for name in _SIGNATURES:
+            setattr(self, name, getattr(fast, name, None) or getattr(handle, name))
+
+    def __getattr__(self, name):                    # (anything else the library exports: resolved by ctypes on first use)
+        return getattr(self._ctypes, name)
+
+
+def _with_fastcall(handle):
+    """ctypes boxes and converts every argument of a call (2.3-2.5 us per 24-argument launch); the generated wrappers read the
+    Python ints / floats straight off the argument vector and call the SAME symbols of the SAME dlopen handle.  Optional:
+    MSG_NO_FASTCALL=1 or a missing module (an interpreter the build did not see) leaves the ctypes binding in place."""
+    if os.environ.get("MSG_NO_FASTCALL"):
+        return _Entries(handle, None)
+    try:
+        from . import _msg_fastcall as fast
+    except ImportError:
+        return _Entries(handle, None)
+    bound = fast.bind(handle._handle)
+    want = sum(1 for res, args in _SIGNATURES.values() if res in (_I, _L))
+    if bound != want:
+        raise MsgHipError(f"_msg_fastcall resolved {bound} of {want} entry points of {LIB_PATH}: rebuild with "
+                          "`python -m multi_stylegan_amd.build --force`")
+    return _Entries(handle, fast)
 
 
 def check(code, what):

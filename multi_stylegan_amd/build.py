@@ -43,6 +43,7 @@ def build(force=False, verbose=True, extra_flags=(), variant=None):
     --flags=-DMSG_ROW3_STAMPS``.  The product library (no variant) is what tests, smoke and bench.py load."""
     lib = lib_path(variant)
     if not force and not is_stale(variant):
+        build_fastcall(verbose=verbose)
         return lib
     objs = []
     objdir = os.path.join(HERE, "build" if not variant else f"build_{variant}")
@@ -66,7 +67,38 @@ def build(force=False, verbose=True, extra_flags=(), variant=None):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_fastcall(force=force, verbose=verbose)
     return lib
+
+
+FASTCALL = os.path.join(HERE, "_msg_fastcall.so")
+
+
+def build_fastcall(force=False, verbose=True):
+    """The host-side call wrappers (csrc_host/gen_fastcall.py): C source generated from _lib._SIGNATURES, compiled with gcc
+    against this interpreter's headers into multi_stylegan_amd/_msg_fastcall.so.  One module serves the product library and
+    every variant build (it binds to whatever handle _lib loaded)."""
+    import sysconfig
+    gen = os.path.join(HERE, "csrc_host", "gen_fastcall.py")
+    deps = [gen, os.path.join(HERE, "_lib.py")]
+    if not force and os.path.exists(FASTCALL) and all(os.path.getmtime(FASTCALL) > os.path.getmtime(d) for d in deps):
+        return FASTCALL
+    sys.path.insert(0, os.path.dirname(HERE))
+    try:
+        from multi_stylegan_amd import _lib
+        from multi_stylegan_amd.csrc_host.gen_fastcall import generate
+    finally:
+        sys.path.pop(0)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    src = os.path.join(objdir, "msg_fastcall.c")
+    with open(src, "w") as f:
+        f.write(generate(_lib._SIGNATURES))
+    cmd = [shutil.which("gcc") or "gcc", "-O2", "-shared", "-fPIC", f"-I{sysconfig.get_paths()['include']}", src, "-o", FASTCALL, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return FASTCALL
 
 
 if __name__ == "__main__":

@@ -239,13 +239,16 @@ def _run_golden_iterations(golden, fused, prepare=None, step_tol=None):
         trainer.step_trace = {}
         trainer.train_iteration(real.to(DEV), draws.to(DEV), resume_training=late, top_k=top_k if late else None)
         log = trainer.pop_logs()
+        # one unit in the last place of every parameter (fp32): the resolution of a movement p_after - p_before
+        ulp = {n: p.detach().abs().double().cpu() * 2.0 ** -23 for mod in (g, d) for n, p in mod.named_parameters()}
         pre = f"train.it{step}."
         want_steps, want_ema = step_traces(z, pre)
         got_steps, got_ema = split_trace(trainer.step_trace)
         assert list(got_steps) == STEP_LABELS[iteration]
         for label, want in want_steps.items():
             tg, tn, td = (step_tol or STEP_TOL)[label]
-            st = check_step_trace(got_steps[label], want, tol_grad=tg, tol_norm=tn, tol_delta=td, history=history)
+            st = check_step_trace(got_steps[label], want, tol_grad=tg, tol_norm=tn, tol_delta=td, history=history,
+                                  resolution=ulp)
             assert st["compared"] > 0.2 * st["total"], (label, st)
             report[f"it{iteration}.{label}"] = st
         worst_ema = max(rel_err(got_ema[n], want) for n, want in want_ema.items())

@@ -372,7 +372,20 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
     const long long tiles = (long long)p.o_tiles * p.i_tiles * kh;
     long long zs, chunks_per_out;
     if (per_sample) {
-        // the caller chose k_chunks
+        // the caller's k_chunks, or -- when it has no opinion (1) -- the same wave-quantisation model as below over this
+        // kernel's ONE workgroup per CU: B * tiles workgroups in rounds of 256.  Batch 16 x 512 -> 512 is 768 workgroups = three
+        // full rounds; batch 8 (the path-length pass works on half a batch) is 384 = one and a half, i.e. a quarter of the
+        // launch on half-empty hardware (round 5: 1 101 TFLOP/s against 1 352 at batch 16); two K-slices per sample make it
+        // three full rounds again, for one extra pass over the 9.4-MB slabs.
+        if (k_chunks <= 1) {
+            static const int slab_cost_ps = msg_tunable("MSG_WGRAD3_SLAB_COST_PS", 6);
+            long long best = -1;
+            for (long long c = 1; c <= 4 && c * 8 <= steps_per_sample; ++c) {
+                const long long rounds = ((long long)B * tiles * c + 255) / 256;
+                const long long cost = rounds * ((steps_per_sample + c - 1) / c + 3 + (c > 1 ? slab_cost_ps : 0));
+                if (best < 0 || cost < best) { best = cost; k_chunks = (int)c; }
+            }
+        }
         p.chunks_per_sample = k_chunks;
         p.steps_per_chunk = (int)((steps_per_sample + k_chunks - 1) / k_chunks);
         zs = (long long)B * k_chunks;

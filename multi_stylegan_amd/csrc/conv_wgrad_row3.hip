@@ -376,9 +376,9 @@ extern "C" int msg_conv2d_wgrad_row3_try(const void* gy, const void* x, float* g
         // kernel's ONE workgroup per CU: B * tiles workgroups in rounds of 256.  Batch 16 x 512 -> 512 is 768 workgroups = three
         // full rounds; batch 8 (the path-length pass works on half a batch) is 384 = one and a half, i.e. a quarter of the
         // launch on half-empty hardware (round 5: 1 101 TFLOP/s against 1 352 at batch 16); two K-slices per sample make it
-        // three full rounds again, for one extra pass over the 9.4-MB slabs.
+        // three full rounds again, for one extra pass over the 9.4-MB slabs (priced at 12 K-steps: with 6 the 64-step sweeps of the 64^2 maps were split too and lost 17 %).
         if (k_chunks <= 1) {
-            static const int slab_cost_ps = msg_tunable("MSG_WGRAD3_SLAB_COST_PS", 6);
+            static const int slab_cost_ps = msg_tunable("MSG_WGRAD3_SLAB_COST_PS", 12);
             long long best = -1;
             for (long long c = 1; c <= 4 && c * 8 <= steps_per_sample; ++c) {
                 const long long rounds = ((long long)B * tiles * c + 255) / 256;

@@ -485,7 +485,8 @@ def main():
             # which shared library produced the numbers: the product build unless MSG_LIB_VARIANT named an A/B or diagnostic
             # build (tools only; a line that carries a variant is not the product's)
             "library": {"file": os.path.basename(_lib.LIB_PATH), "abi": int(_lib.lib().msg_abi_version()),
-                        "variant": os.environ.get("MSG_LIB_VARIANT") or None},
+                        "variant": os.environ.get("MSG_LIB_VARIANT") or None,
+                        "call_wrappers": "generated (_msg_fastcall)" if _lib.lib().fastcall else "ctypes"},
         }
         if world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and not args.rehearse_on_one_gpu:
             del trainer, gen, dis, real

@@ -641,6 +641,33 @@ def test_validation_statistics_are_shared_over_ranks_gloo_world2():
     _run_ranks(_validation_worker, 2, 29100 + os.getpid() % 300, 120)
 
 
+def test_generated_call_wrappers_bind_every_entry_point():
+    """multi_stylegan_amd._msg_fastcall (generated by csrc_host/gen_fastcall.py, built by build()): one wrapper per entry point
+    that returns a status / size, bound to the dlopen handle ctypes holds; same results as ctypes on the entry points that
+    need no GPU, argument-count and range errors raised like ctypes raises them."""
+    from multi_stylegan_amd import _lib
+    h = _lib.lib()
+    assert h.fastcall, "build() did not produce _msg_fastcall.so (or MSG_NO_FASTCALL is set)"
+    from multi_stylegan_amd import _msg_fastcall as fast
+    ints = [n for n, (res, _a) in _lib._SIGNATURES.items() if res in (_lib._I, _lib._L)]
+    assert all(callable(getattr(fast, n)) for n in ints)
+    assert all(getattr(h, n) is getattr(fast, n) for n in ints)            # lib() hands out the wrappers ...
+    assert h.msg_build_arch() == b"gfx950"                                # ... and ctypes for the string-valued entries
+    assert h.msg_abi_version() == h._ctypes.msg_abi_version() == _lib.ABI_VERSION
+    geoms = [(1, 16, 256, 256, 512, 512, 256, 256, 512, 3, 3, 0), (1, 32, 256, 256, 128, 128, 256, 256, 128, 3, 3, 0),
+             (1, 16, 4, 4, 512, 512, 4, 4, 512, 3, 3, 512 * 9 * 512), (0, 2, 9, 9, 16, 32, 9, 9, 24, 3, 3, 0)]
+    for g in geoms:
+        assert h.msg_conv2d_fprop_plan(*g) == h._ctypes.msg_conv2d_fprop_plan(*g)
+    assert h.msg_bias_act_backward_workspace(1 << 20, 1, 512, 1) == h._ctypes.msg_bias_act_backward_workspace(1 << 20, 1, 512, 1)
+    assert h.msg_softmax_rows(None, None, 0, 4, 1024, None) == -1         # MSG_EINVAL: None is a NULL pointer, as with ctypes
+    with pytest.raises(TypeError):
+        h.msg_conv2d_fprop_plan(1, 2, 3)
+    with pytest.raises(OverflowError):
+        h.msg_conv2d_fprop_plan(1 << 40, *geoms[0][1:])
+    with pytest.raises(TypeError):
+        h.msg_conv2d_fprop_plan("1", *geoms[0][1:])
+
+
 def test_bench_multi_rank_fields():
     """What bench.py's JSON line reports about the ranks (the fields the 8-GPU run is read by), on canned timings."""
     import importlib.util

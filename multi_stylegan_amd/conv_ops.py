@@ -946,10 +946,12 @@ class _ConvResidualF(Function):
         x, w = ctx.saved_tensors
         g1 = grads[0]
         g2 = grads[1] if ctx.fork else None
-        if (g1 is None or g2 is None) and ctx.main_scale is not None and not torch.is_grad_enabled() and \
-                ctx.needs_input_grad[2]:
+        if (g1 is None or g2 is None) and ctx.main_scale is not None and ctx.needs_input_grad[2]:
             # one incoming gradient: nothing to add, and the rescaling is deferred -- `main`'s activation backward
-            # multiplies the gain in (GradScale), the two contractions take it through their weight scale
+            # multiplies the gain in (GradScale), the two contractions take it through their weight scale.  Second-order graphs
+            # too (round 5): every piece the gain moves into is a differentiable node with the factor as a constant (_ConvD /
+            # _ConvG through their geometry's wscale, the activation backward through its scale), and a create_graph backward
+            # runs its nodes in the same order, so `pending` meets the same consumer
             gs = g1 if g1 is not None else g2
             ctx.main_scale.pending = ctx.gain
             gg = Geometry(ctx.g.kind, ctx.g.kh, ctx.g.kw, ctx.g.stride, ctx.g.pad, ctx.g.x_hw, ctx.g.per_sample,
@@ -1018,7 +1020,8 @@ class GradScale:
     instead of being applied in a pass of its own: the residual merge y = (conv1x1(x) + main) * gain sends `main` the
     gradient gy * gain; when `main` is the output of a fused conv + leaky ReLU whose ONLY consumer is that merge (the
     discriminator block), the merge's backward passes gy on untouched and leaves `gain` here, and the activation
-    backward -- a pass over the same map anyway -- multiplies it in (its `scale` argument).  First-order only."""
+    backward -- a pass over the same map anyway -- multiplies it in (its `scale` argument).  First- and (round 5) second-order
+    graphs alike: the factor only ever enters differentiable nodes as a constant."""
     __slots__ = ("pending",)
 
     def __init__(self):

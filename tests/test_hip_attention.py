@@ -233,3 +233,21 @@ def test_max_pool2x2_matches_library(shape, dtype):
         g1, = torch.autograd.grad(pool(t), t, gy, create_graph=True)
         t.second = torch.autograd.grad(g1.square().sum(), gy)[0]
     assert torch.equal(a.second, b.second)
+
+
+def test_max_pool2x2_declined_shapes_take_the_library():
+    """Shapes the pooling kernel declines -- odd height / width, a channel count that is not a whole number of 16-byte vectors,
+    a map that is not channels-last -- go to F.max_pool2d on the same device: same values, differentiable (review, round 4:
+    the branch existed untested)."""
+    import torch.nn.functional as F
+    from multi_stylegan_amd.op_static import max_pool2x2
+    torch.manual_seed(3)
+    for shape, cl in (((2, 8, 5, 6), True), ((2, 8, 6, 7), True), ((1, 6, 4, 4), True), ((2, 16, 8, 8), False)):
+        x = torch.randn(*shape, device=DEV)
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = max_pool2x2(a), F.max_pool2d(b, kernel_size=2, stride=2)
+        assert ya.shape == yb.shape and torch.equal(ya, yb), shape
+        gy = torch.randn_like(yb)
+        assert torch.equal(torch.autograd.grad(ya, a, gy)[0], torch.autograd.grad(yb, b, gy)[0]), shape

@@ -1275,6 +1275,13 @@ class _GroupedLinear(Function):
         g = len(slot)
         lat, ws, bs = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + g], ctx.saved_tensors[1 + g:]
         need = ctx.needs_input_grad
+        if torch.is_grad_enabled() and need[0] and not any(_consumed(ctx, 4 + j, 1 + j) for j in range(2 * g) if need[4 + j]):
+            # a second-order graph that wants the LATENT's gradient only (the path-length regulariser differentiates
+            # d image / d latent: multi_stylegan_generator.py:193-200): one differentiable node on the grouped kernels instead
+            # of 20 per-layer linears recomputed and differentiated one by one (round 5: ~230 launches of 13-22 us per
+            # regularised iteration on an otherwise idle chip)
+            glat = _GroupedLinD.apply(gy, slot, wscale, lat.shape[1], *ws)
+            return (glat, None, None, None, *([None] * (2 * g)))
         if torch.is_grad_enabled():
             with torch.enable_grad():
                 ins = [t for t, nd in zip((lat, *ws, *bs), (need[0], *need[4:])) if nd]
@@ -1287,17 +1294,7 @@ class _GroupedLinear(Function):
         b, l, k = lat.shape
         n = ws[0].shape[0]
         slot_t = _ptr_table_ints(slot, dev)
-        glat = None
-        if need[0]:
-            gx = torch.empty((g + 1, b, k), dtype=torch.float32, device=dev)
-            gx[g].zero_()                                   # (the row the padding entries of the gather table point at)
-            with _lib.on_device(dev):
-                code = _lib.lib().msg_linear_grouped_dgrad(gy.data_ptr(), _ptr_table(ws, dev).data_ptr(), gx.data_ptr(),
-                                                           g, b, n, k, wscale, _lib.stream_of(dev))
-            _lib.check(code, "msg_linear_grouped_dgrad")
-            # layers that read the same latent slot: gather + ordered sum (index_add_ adds with float atomics, i.e. in an
-            # order that changes from run to run)
-            glat = gx[_slot_gather_table(slot, l, dev)].sum(dim=1).transpose(0, 1)
+        glat = _grouped_dgrad(gy, ws, slot, wscale, l) if need[0] else None
         grads_w, grads_b = [None] * g, [None] * g
         if any(need[4:]):
             # every layer's results go straight to the parameter's slice of the flat gradient store where that is free
@@ -1338,6 +1335,60 @@ class _GroupedLinear(Function):
             grads_w = [dw[j] if need[4 + j] else None for j in range(g)]
             grads_b = [db[j] if need[4 + g + j] else None for j in range(g)]
         return (glat, None, None, None, *grads_w, *grads_b)
+
+
+def _grouped_dgrad(gy, ws, slot, wscale, n_slots):
+    """glat [B, L, K] = for every latent slot the ordered sum over the layers that read it of wscale * gy[g] @ W_g."""
+    dev = gy.device
+    g = len(slot)
+    (gy,) = _dense32(gy)
+    b, n, k = gy.shape[1], ws[0].shape[0], ws[0].shape[1]
+    gx = torch.empty((g + 1, b, k), dtype=torch.float32, device=dev)
+    gx[g].zero_()                                   # (the row the padding entries of the gather table point at)
+    with _lib.on_device(dev):
+        code = _lib.lib().msg_linear_grouped_dgrad(gy.data_ptr(), _ptr_table(ws, dev).data_ptr(), gx.data_ptr(),
+                                                   g, b, n, k, wscale, _lib.stream_of(dev))
+    _lib.check(code, "msg_linear_grouped_dgrad")
+    # layers that read the same latent slot: gather + ordered sum (index_add_ adds with float atomics, i.e. in an
+    # order that changes from run to run)
+    return gx[_slot_gather_table(slot, n_slots, dev)].sum(dim=1).transpose(0, 1)
+
+
+class _GroupedLinD(Function):
+    """The latent's gradient of _GroupedLinear as an op of its own, differentiable once more: for a cotangent v [B, L, K] of
+    glat,  d/d gy[g] = wscale * v[:, slot g] @ W_g^T  (the grouped forward without bias)  and  d/d W_g = wscale * gy[g]^T @
+    v[:, slot g]  (the grouped weight gradient with v in the latent's place)."""
+
+    @staticmethod
+    def forward(ctx, gy, slot, wscale, n_slots, *ws):
+        _lib.require_gpu(gy, *ws)
+        ctx.save_for_backward(gy, *ws)
+        ctx.cfg = (tuple(slot), float(wscale), int(n_slots))
+        return _grouped_dgrad(gy, ws, slot, wscale, n_slots)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v):
+        gy, *ws = ctx.saved_tensors
+        slot, wscale, l = ctx.cfg
+        g, dev = len(slot), gy.device
+        gy, v = _dense32(gy, v)
+        b, n, k = gy.shape[1], ws[0].shape[0], ws[0].shape[1]
+        slot_t = _ptr_table_ints(slot, dev)
+        d_gy, d_ws = None, [None] * g
+        with _lib.on_device(dev):
+            if ctx.needs_input_grad[0]:
+                d_gy = torch.empty((g, b, n), dtype=torch.float32, device=dev)
+                code = _lib.lib().msg_linear_grouped_fprop(v.data_ptr(), slot_t.data_ptr(), _ptr_table(ws, dev).data_ptr(), None,
+                                                           d_gy.data_ptr(), g, b, n, k, l, wscale, 1.0, _lib.stream_of(dev))
+                _lib.check(code, "msg_linear_grouped_fprop")
+            if any(ctx.needs_input_grad[4:]):
+                gw = torch.empty((g, n, k), dtype=torch.float32, device=dev)
+                code = _lib.lib().msg_linear_grouped_wgrad(gy.data_ptr(), v.data_ptr(), slot_t.data_ptr(), gw.data_ptr(), None, g, b,
+                                                           n, k, l, wscale, 1.0, _lib.stream_of(dev))
+                _lib.check(code, "msg_linear_grouped_wgrad")
+                d_ws = [gw[j] if ctx.needs_input_grad[4 + j] else None for j in range(g)]
+        return (d_gy, None, None, None, *d_ws)
 
 
 _INT_TABLES: dict = {}

@@ -619,12 +619,21 @@ def test_grouped_linear_matches_per_layer(g, b, l, n, k):
     grads_p = torch.autograd.grad(out_p, [latent, *ws, *bs], gy)
     for a, c in zip(grads_g, grads_p):
         assert rel_err(a, c) < 1e-5
-    # second order (path-length style): d/dW of |d out / d latent|^2
+    # second order (path-length style): d/dW and d/d(cotangent) of |d out / d latent|^2 -- the latent-only first pass runs on
+    # the grouped kernels' own differentiable node (_GroupedLinD, round 5) ...
+    gyr = gy.clone().requires_grad_(True)
     def second(fn):
         o = fn()
-        gl, = torch.autograd.grad(o, latent, gy, create_graph=True)
-        return torch.autograd.grad(gl.square().sum(), ws)
+        gl, = torch.autograd.grad(o, latent, gyr, create_graph=True)
+        return torch.autograd.grad(gl.square().sum(), [*ws, gyr])
     for a, c in zip(second(lambda: conv_ops.grouped_linear(latent, slots, ws, bs, wscale, bscale)), second(per_layer)):
+        assert rel_err(a, c) < 1e-5
+    # ... and a first pass that also wants weight gradients takes the per-layer composite
+    def second_full(fn):
+        o = fn()
+        gl, gw0 = torch.autograd.grad(o, [latent, ws[0]], gyr, create_graph=True)
+        return torch.autograd.grad(gl.square().sum() + gw0.square().sum(), [ws[-1], gyr])
+    for a, c in zip(second_full(lambda: conv_ops.grouped_linear(latent, slots, ws, bs, wscale, bscale)), second_full(per_layer)):
         assert rel_err(a, c) < 1e-5
 
 

@@ -390,7 +390,9 @@ class Generator(nn.Module):
         else:
             noise_start, layer_noise = noise[0], list(noise[1:])
         dt = self.compute_dtype
-        pre = self._all_styles(latent) if not return_path_length_grads else None
+        # (the path-length pass too since round 5: the grouped op's latent gradient is a differentiable node of its own,
+        #  conv_ops._GroupedLinD -- before, that pass ran the 20 affines layer by layer through three orders of autograd)
+        pre = self._all_styles(latent)
         w_of = (lambda group, slot: _Premodulated(pre[group])) if pre is not None else \
             (lambda group, slot: latent[:, slot])
         out1 = conv_ops.to_compute_layout(self.constant_input_1(latent), dt)

@@ -168,6 +168,20 @@ int msg_bias_act_backward_mask(const void* gy, const unsigned char* mask, int ti
                                float* grad_bias, const float* noise, float* grad_noise_weight,
                                int noise_batch, int pix, float alpha, float scale,
                                float* ws, long long ws_floats, void* stream);
+/* (ABI 5) msg_bias_act_backward_mask for the output of a styled layer that ALSO feeds the level's image head -- a 1x1 modulated
+ * conv without demodulation to n_head <= 8 planes (reference: OutputBlock, multi_stylegan_generator.py:513-523, reading the
+ * StyledConv2d output of :384-411).  The head's data gradient is formed inside this pass instead of being written as a full map
+ * and summed by autograd:
+ *     gx = (gy + h) * scale * (out > 0 ? 1 : alpha),   h[q][c] = wscale * style[b][c] * sum_o ghead[q][o] * whead[o][c]
+ * gy: the other consumer's gradient (bf16 [pixels][size_b]) or NULL; ghead: bf16 [pixels][8], planes >= n_head padding; whead fp32
+ * [n_head][size_b]; style fp32 [pixels / pix][size_b]; pix = pixels per sample (a workgroup's pixel range must lie inside one
+ * sample: MSG_EUNSUPPORTED otherwise, as for anything but bf16).  Sums, workspace and determinism as msg_bias_act_backward_mask. */
+int msg_bias_act_backward_mask_head(const void* gy, const void* ghead, const float* whead, const float* style,
+                                    float wscale, int n_head, const unsigned char* mask, int tile_m, int tile_n,
+                                    void* gx, int dtype, long long size_x, int size_b,
+                                    float* grad_bias, const float* noise, float* grad_noise_weight,
+                                    int noise_batch, int pix, float alpha, float scale,
+                                    float* ws, long long ws_floats, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a3/a4  dense contractions on the matrix cores (channels-last, implicit GEMM).

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "msg_bias_act_backward": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P]),
     "msg_channel_sums": (_I, [_P, _P, _I, _L, _I, _P, _L, _P]),
     "msg_bias_act_backward_mask": (_I, [_P, _P, _I, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P]),
+    "msg_bias_act_backward_mask_head": (_I, [_P, _P, _P, _P, _F, _I, _P, _I, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _F, _F,
+                                             _P, _L, _P]),
     "msg_bias_act_backward_workspace": (_L, [_L, _I, _I, _I]),
     "msg_conv2d_fprop": (_I, [_P, _P, _P, _P, _I] + [_I] * 15 + [_L, _P]),
     "msg_conv2d_fprop_act": (_I, [_P, _P, _P, _I] + [_I] * 13 + [_L, _P, _P, _P, _I, _F, _F, _P]),

@@ -1036,6 +1036,25 @@ class GradSlot:
         self.g, self.merged = None, False
 
 
+class HeadGradSlot:
+    """Hand-over between the two consumers' producer and the image head of a generator level (first-order backward only).
+    The styled layer's output feeds the next level and the level's head, a 1x1 modulated conv to <= 8 planes; the head's
+    backward runs first (it is a consumer) and, instead of writing its data gradient as a full map for autograd to sum,
+    leaves here what that gradient is made of -- its own incoming gradient, base weights, style, scale.  The styled
+    layer's activation backward forms it on the fly (op_static.fused_act.act_backward_with_head).  `head` is consumed
+    once; `dgrad` computes the ordinary data gradient for the cases the fused kernel declines."""
+    __slots__ = ("head", "dgrad", "armed")
+
+    def __init__(self):
+        self.head = None
+        self.dgrad = None
+        self.armed = False          # set by the producer's forward: a head only hands over to a producer that will look
+
+    def take(self):
+        head, dgrad, self.head, self.dgrad = self.head, self.dgrad, None, None
+        return head, dgrad
+
+
 class _ForkInput(Function):
     """x -> two aliases for a discriminator block input read by the main branch's first conv AND by the 1x1 residual
     conv.  In backward the residual conv runs first (it is the last node of the block), leaves its input gradient in
@@ -1675,8 +1694,14 @@ class _ModulatedConv(Function):
 
     @staticmethod
     def forward(ctx, x, weight, style, demodulate, upsample, act_bias=None, noise=None, noise_w=None, alpha=0.2,
-                act_scale=1.0, fuse_act=False):
+                act_scale=1.0, fuse_act=False, head_slot=None):
         dev = _lib.require_gpu(x, weight, style)
+        # head_slot (HeadGradSlot): on a styled layer WITH its activation, the slot its level's image head fills in backward;
+        # on the head itself (no activation), the slot to fill.  The producer may then see no incoming gradient at all.
+        ctx.head_slot = head_slot
+        if head_slot is not None and fuse_act:
+            ctx.set_materialize_grads(False)
+            head_slot.armed = True
         _, o, i, kh, kw = weight.shape
         b, t = x.shape[0], kh * kw
         scale = math.sqrt(2.0) / math.sqrt(i * t)
@@ -1732,17 +1757,39 @@ class _ModulatedConv(Function):
         need = list(ctx.needs_input_grad)
         need[1], need[2] = _consumed(ctx, 1, 1), _consumed(ctx, 2, 2)       # (weight, style: see _consumed)
         gb = gnw = None
+        slot = ctx.head_slot
         if ctx.act is not None:
             # activation stage first (slope from the sign of the saved OUTPUT); a differentiable Function, so the
             # second-order graph of path-length regularisation runs through it exactly as in the two-pass form
-            from .op_static.fused_act import FusedLeakyReLUFunctionBackward
+            from .op_static.fused_act import FusedLeakyReLUFunctionBackward, act_backward_with_head
             alpha, act_scale, has_bias, has_noise, nw_shape = ctx.act
-            gy, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y_act, noise if has_noise else None,
-                                                               ctx.bias_param if has_bias else False, alpha, act_scale,
-                                                               ctx.mask)
+            head, head_dgrad = slot.take() if slot is not None else (None, None)
+            fused = None
+            if head is not None:
+                # the level's image head left its gradient here instead of writing it as a map: formed inside the pass
+                fused = act_backward_with_head(gy, head, y_act.shape, noise if has_noise else None,
+                                               ctx.bias_param if has_bias else None, has_bias, alpha, act_scale, ctx.mask)
+                if fused is None:
+                    gh = head_dgrad()
+                    gy = gh if gy is None else gy + gh
+            if fused is not None:
+                gy, gb, gnw = fused
+            elif gy is None:
+                return (None,) * 12
+            else:
+                gy, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y_act, noise if has_noise else None,
+                                      ctx.bias_param if has_bias else False, alpha, act_scale, ctx.mask)
             gb = gb if has_bias and need[5] else None
             gnw = gnw.reshape(nw_shape) if has_noise and need[7] else None
-        tail = (None, None, gb, None, gnw, None, None, None)
+        tail = (None, None, gb, None, gnw, None, None, None, None)
+        if ctx.act is None and slot is not None and slot.armed and need[0] and not torch.is_grad_enabled() and \
+                fused_head_ok(gy, weight, b, demodulate, upsample):
+            # this IS the head: weight / style gradients as always, the data gradient handed to the producer's activation backward
+            gyc, wt, st = gy, weight, style
+            slot.head = (gyc, weight.detach().reshape(o, i).float().contiguous(), style.detach().float().contiguous(), scale)
+            slot.dgrad = lambda: _modconv_backward(x, wt, st, d, gyc, demodulate, upsample, g, scale,
+                                                   [True, False, False])[0]
+            need[0] = False
         fused_ok = i <= 512 and t <= 9
         if torch.is_grad_enabled() and fused_ok and _NATIVE_SECOND_ORDER and b <= _MODCONV_BWD_BATCH and x.is_cuda:
             # create_graph=True (the path-length pass): the first backward as ONE differentiable node on the native kernels
@@ -1774,17 +1821,33 @@ class _ModulatedConv(Function):
         return (gx, gw, gs) + tail
 
 
+def fused_head_ok(gy, weight, b, demodulate, upsample) -> bool:
+    """Whether a modulated conv is an image head whose data gradient the producer's activation backward can form itself
+    (HeadGradSlot): 1x1, no demodulation, at most 8 planes, bf16 gradient, one modconv-backward batch."""
+    _, o, _, kh, kw = weight.shape
+    return gy is not None and gy.is_cuda and gy.dtype == torch.bfloat16 and kh == 1 and kw == 1 and o <= 8 and \
+        not demodulate and not upsample and b <= _MODCONV_BWD_BATCH and HEAD_GRAD_FUSION
+
+
+HEAD_GRAD_FUSION = bool(int(os.environ.get("MSG_HEAD_GRAD_FUSION", "1")))   # 0 / False: the head writes its data gradient as a map (A/B; tests compare the two forms)
+
+
 def modulated_conv2d_bias_act(x, weight, style, demodulate, act_bias, noise, noise_weight, negative_slope=0.2,
-                              scale=1.0):
+                              scale=1.0, head_slot=None):
     """modulated_conv2d (no upsampling) -> noise injection -> bias -> leaky ReLU, the activation stage fused into the
-    contraction's epilogue (multi_stylegan_generator.py:267-292 + 384-411 in one pass over the output map)."""
+    contraction's epilogue (multi_stylegan_generator.py:267-292 + 384-411 in one pass over the output map).
+    head_slot: the HeadGradSlot the level's image head fills in backward (see there)."""
     return _ModulatedConv.apply(x, weight, style, bool(demodulate), False, act_bias, noise, noise_weight,
-                                float(negative_slope), float(scale), True)
+                                float(negative_slope), float(scale), True, head_slot)
 
 
-def modulated_conv2d(x, weight, style, demodulate, upsample):
+def modulated_conv2d(x, weight, style, demodulate, upsample, head_slot=None):
     """x [B,I,H,W]; weight [1,O,I,kh,kw] fp32; style [B,I] fp32 -> conv result (before any blur).
 
     One weight set per sample, w_b = d[b,o] * scale * W[o,i,k] * s[b,i] (multi_stylegan_generator.py:384-388), and
-    one batched contraction (grid.z = sample) instead of the reference's groups=batch library conv."""
-    return _ModulatedConv.apply(x, weight, style, bool(demodulate), bool(upsample))
+    one batched contraction (grid.z = sample) instead of the reference's groups=batch library conv.
+    head_slot: this conv is an image head and `x` the output of the styled layer that holds the same HeadGradSlot."""
+    if head_slot is None:
+        return _ModulatedConv.apply(x, weight, style, bool(demodulate), bool(upsample))
+    return _ModulatedConv.apply(x, weight, style, bool(demodulate), bool(upsample), None, None, None, 0.2, 1.0, False,
+                                head_slot)

@@ -529,6 +529,211 @@ extern "C" int msg_bias_act_backward_mask(const void* gy, const unsigned char* m
                                 tile_m, tile_n);
 }
 
+// ---- the same backward with the data gradient of a FEW-CHANNEL 1x1 modulated head computed on the fly -------------------
+// The output of a styled 3x3 layer of the generator feeds the next level AND the level's image head, a 1x1 modulated conv
+// without demodulation to n_head <= 8 planes (multi_stylegan_generator.py:513-523).  Its gradient was: the head's data
+// gradient written as a 512-channel map (a streaming kernel, write-bound), autograd's sum with the other consumer's gradient,
+// then the activation backward over that sum -- at 256^2 x 512 channels three passes over a gigabyte for six planes of
+// information.  Here the activation backward forms the head's contribution itself,
+//     h[q][c] = wscale * style[b][c] * sum_o ghead[q][o] * whead[o][c]           (the per-sample 1x1 weights, never stored)
+// and takes the other consumer's gradient `gy` (or none: the last level) as the second term:
+//     gx = (gy + h) * scale * (out > 0 ? 1 : alpha), sums as above.
+// h is a K = 8 contraction per (pixel, channel): on the vector ALU it made the pass compute-bound (64 FMAs per stored 16 bytes:
+// 2.3 TB/s); the matrix cores are idle in this kernel, so ONE v_mfma_f32_32x32x16_bf16 (upper half of K zero) forms the
+// 32 pixels x 32 channels of a step.  The accumulator's layout -- a lane holds 16 channels of ONE pixel in groups of four --
+// is the wrong one for the map (a store instruction would touch 32 rows with 32 bytes each: measured, half the bandwidth), so
+// the 32 x 64 fp32 patch of a wave's step goes through a wave-private LDS patch and the streaming part runs in the layout of
+// the plain kernel: eight lanes x 16 bytes = one 128-byte line of a row, eight rows per instruction.
+// A workgroup = 8 waves x 64 consecutive channels, walking its pixel slice 32 pixels at a time; the per-sample head weights
+// (rounded to bf16 like the weights of the launch this replaces) are built once per workgroup in registers.
+typedef __bf16 ba_bf16v8 __attribute__((ext_vector_type(8)));
+constexpr int HEAD_PITCH = 68;                              // floats per patch row (64 + 4: rows 16 bytes apart in the banks)
+template <bool HAS_NOISE, bool HAS_GY>
+__global__ __launch_bounds__(512) void bias_act_bwd_head_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ ghead,
+                                                                const float* __restrict__ whead, const float* __restrict__ style,
+                                                                float wscale, int n_head, const unsigned char* __restrict__ mask,
+                                                                bf16_t* __restrict__ gx, float* __restrict__ part_b,
+                                                                const float* __restrict__ noise, float* __restrict__ part_n,
+                                                                BiasActParams p, int pix_per_block, int tile_m, int tm_shift,
+                                                                int tile_n) {
+    __shared__ __attribute__((aligned(16))) float patch[8][32 * HEAD_PITCH];
+    __shared__ float red_n[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;              // MFMA view: row / column lp, K half lh
+    const int lr = lane >> 3, lv = lane & 7;               // streaming view: row lr of a pass, 16-byte vector lv of the wave's 64 channels
+    const int C = p.size_b;
+    const int c_wave = blockIdx.x * 512 + wid * 64;        // this wave's first channel
+    const bool wave_live = c_wave < C;                     // (C % 64 == 0: a wave's channels are all inside or all outside)
+    const long long p0 = (long long)blockIdx.y * pix_per_block;       // (a multiple of 32 pixels, inside ONE sample: the launcher checks)
+    const int b = (int)(p0 / p.pix);
+    float* hp = patch[wid];
+    ba_bf16v8 afrag[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = c_wave + 32 * k + lp;                // MFMA row lp of block k carries this channel
+        const float sc = (lh == 0 && c < C) ? style[(long long)b * C + c] * wscale : 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float wv = (lh == 0 && c < C && o < n_head) ? whead[(long long)o * C + c] * sc : 0.f;
+            afrag[k][o] = __builtin_bit_cast(__bf16, f2bf(wv));
+        }
+    }
+    // planes >= n_head of the head's gradient are padding and may hold anything (NaN x 0 is NaN inside the MFMA): cleared
+    unsigned keep[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        keep[d] = (lh == 0 ? ((2 * d < n_head ? 0x0000ffffu : 0u) | (2 * d + 1 < n_head ? 0xffff0000u : 0u)) : 0u);
+    // Everything inside the slice is addressed with 32-bit offsets from the slice's own base pointers.  Sign bytes:
+    // index = ((tm * (C / tile_n) + tn) * tile_m + r) * vpt + c for pixel tile tm, row r, channel vector tn * vpt + c -- a
+    // per-pixel part and a part that depends on the lane's channel vector only.
+    const int vpt = tile_n >> 3;
+    const int cv = (c_wave >> 3) + lv;
+    const int m_col = (cv / vpt) * tile_m * vpt + cv % vpt;
+    const int m_tile_stride = (C / tile_n) * tile_m * vpt;
+    const int q_first = (int)p0;                            // (fewer than 2^31 elements: the launcher checks)
+    const int c_lane = c_wave + 8 * lv;
+    const bf16_t* gy_s = HAS_GY ? gy + p0 * C + c_lane : nullptr;
+    bf16_t* gx_s = gx + p0 * C + c_lane;
+    const bf16_t* gh_s = ghead + p0 * 8;
+    const float* nz_s = HAS_NOISE ? noise + (p.noise_batch == 1 ? p0 - (long long)b * p.pix : p0) : nullptr;
+    float sb[8], sn = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sb[e] = 0.f;
+    const float pos_s = p.scale, neg_s = p.scale * p.alpha;
+    if (wave_live) {
+        for (int t0 = 0; t0 < pix_per_block; t0 += 32) {
+#pragma clang fp contract(off)
+            u32x4 hraw = *reinterpret_cast<const u32x4*>(gh_s + (t0 + lp) * 8);
+            u32x4 g[4];
+            unsigned mb[4];
+            float nz[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int ql = t0 + 8 * ps + lr, qg = q_first + ql;
+                if constexpr (HAS_GY) g[ps] = *reinterpret_cast<const u32x4*>(gy_s + ql * C);
+                const int tm = tm_shift >= 0 ? qg >> tm_shift : qg / tile_m;
+                mb[ps] = mask[tm * m_tile_stride + (qg - tm * tile_m) * vpt + m_col];
+                nz[ps] = HAS_NOISE ? nz_s[ql] : 0.f;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) hraw[d] &= keep[d];
+            const ba_bf16v8 bfrag = __builtin_bit_cast(ba_bf16v8, hraw);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[k], bfrag, acc, 0, 0, 0);
+#endif
+                // lane (lp, lh): pixel lp, channels 32 k + 8 i + 4 lh + (0..3), i = 0..3
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4*>(hp + lp * HEAD_PITCH + 32 * k + 8 * i + 4 * lh) =
+                        f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = 8 * ps + lr;
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(hp + row * HEAD_PITCH + 8 * lv);
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(hp + row * HEAD_PITCH + 8 * lv + 4);
+                float f[8], rowsum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float gsum = e < 4 ? h0[e & 3] : h1[e & 3];
+                    if constexpr (HAS_GY) {
+                        const unsigned w = g[ps][e >> 1];
+                        gsum += (e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+                    }
+                    f[e] = gsum * (((mb[ps] >> e) & 1u) ? pos_s : neg_s);
+                    sb[e] += f[e];
+                    rowsum += f[e];
+                }
+                if (HAS_NOISE) sn = fmaf(rowsum, nz[ps], sn);
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f2bf(f[2 * e]) | ((uint32_t)f2bf(f[2 * e + 1]) << 16);
+                *reinterpret_cast<u32x4*>(gx_s + (t0 + row) * C) = pk;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                  // (the next step's patch writes stay behind these reads)
+        }
+    }
+    // channel sums: over the eight row lanes that share a channel vector (lane = 8 lr + lv), fixed order
+    if (part_b && wave_live) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = sb[e];
+#pragma unroll
+            for (int off = 32; off >= 8; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lr == 0) part_b[(long long)blockIdx.y * C + c_lane + e] = s;
+        }
+    }
+    if (HAS_NOISE) {
+        sn = wave_sum(sn);
+        if (lane == 0) red_n[wid] = sn;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            part_n[(long long)blockIdx.y * gridDim.x + blockIdx.x] =
+                ((red_n[0] + red_n[1]) + (red_n[2] + red_n[3])) + ((red_n[4] + red_n[5]) + (red_n[6] + red_n[7]));
+    }
+}
+
+// gy: the other consumer's gradient, bf16 [pixels][size_b], or NULL; ghead: the head's gradient, bf16 [pixels][8] (planes
+// n_head .. 7 are padding and may hold anything); whead fp32
+// [n_head][size_b]; style fp32 [B][size_b]; `pix` pixels per sample.  Workspace as msg_bias_act_backward_workspace(size_x, 1,
+// size_b, noise != NULL).  size_b a multiple of 64, pix a multiple of 32 (MSG_EUNSUPPORTED otherwise).
+extern "C" int msg_bias_act_backward_mask_head(const void* gy, const void* ghead, const float* whead, const float* style,
+                                               float wscale, int n_head, const unsigned char* mask, int tile_m, int tile_n,
+                                               void* gx, int dtype, long long size_x, int size_b,
+                                               float* grad_bias, const float* noise, float* grad_noise_weight,
+                                               int noise_batch, int pix, float alpha, float scale,
+                                               float* ws, long long ws_floats, void* stream) {
+    if (size_x <= 0 || size_b <= 0 || !ghead || !whead || !style || !mask || !gx || size_x % size_b || pix <= 0) return MSG_EINVAL;
+    if (dtype != MSG_BF16 || size_b % 64 || pix % 32 || n_head < 1 || n_head > 8) return MSG_EUNSUPPORTED;
+    if (tile_m <= 0 || tile_n <= 0 || tile_n % 8 || size_b % tile_n || (size_x / size_b) % tile_m) return MSG_EINVAL;
+    if (noise && grad_noise_weight && noise_batch <= 0) return MSG_EINVAL;
+    if ((((uintptr_t)gy | (uintptr_t)ghead | (uintptr_t)gx) & 15u) != 0) return MSG_EUNSUPPORTED;
+    const long long npix = size_x / size_b;
+    if (npix % pix) return MSG_EINVAL;
+    if (size_x >= (1ll << 31)) return MSG_EUNSUPPORTED;                  // 32-bit offsets inside a pixel slice, 32-bit pixel index
+    BiasActParams p{size_x, 1, size_b, noise_batch, pix, 3, 1, alpha, scale};
+    const bool has_noise = noise && grad_noise_weight;
+    // pixel slices: the plan of the plain backward (whose workspace the caller allocated), its slice rounded up to whole
+    // 32-pixel steps that divide a sample -- never more slices than that plan has
+    const BwdPlan q = bwd_plan(size_x, 1, size_b, 8);
+    if (q.path != 0) return MSG_EUNSUPPORTED;
+    long long ppb = ((q.ppb + 31) / 32) * 32;
+    while (ppb < pix && pix % ppb) ppb += 32;
+    if (ppb > pix) ppb = pix;
+    const long long gy_blocks = npix / ppb;
+    const int gx_blocks = (size_b + 511) / 512;
+    if (gy_blocks > 65535 * 32ll || gy_blocks > q.gy_blocks) return MSG_EUNSUPPORTED;
+    const long long need_b = grad_bias ? gy_blocks * size_b : 0, need_n = has_noise ? gy_blocks * gx_blocks : 0;
+    if (need_b + need_n > 0 && (!ws || ws_floats < need_b + need_n)) return MSG_EINVAL;
+    float* part_b = grad_bias ? ws : nullptr;
+    float* part_n = has_noise ? ws + need_b : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(gx_blocks, (unsigned)gy_blocks);
+    int tm_shift = 0;
+    while ((1 << tm_shift) < tile_m) ++tm_shift;
+    if ((1 << tm_shift) != tile_m) tm_shift = -1;
+#define HEAD_LAUNCH(N_, G_)                                                                                             \
+    hipLaunchKernelGGL((bias_act_bwd_head_kernel<N_, G_>), grid, dim3(512), 0, s, (const bf16_t*)gy, (const bf16_t*)ghead, \
+                       whead, style, wscale, n_head, mask, (bf16_t*)gx, part_b, noise, part_n, p, (int)ppb, tile_m, tm_shift, tile_n)
+    if (has_noise) { if (gy) HEAD_LAUNCH(true, true); else HEAD_LAUNCH(true, false); }
+    else { if (gy) HEAD_LAUNCH(false, true); else HEAD_LAUNCH(false, false); }
+#undef HEAD_LAUNCH
+    if (MSG_CHECK_LAUNCH() != MSG_OK) return MSG_ELAUNCH;
+    if (need_b + need_n == 0) return MSG_OK;
+    const int bias_blocks = grad_bias ? (size_b + BRC - 1) / BRC : 0;
+    hipLaunchKernelGGL(bias_act_bwd_reduce_kernel, dim3(bias_blocks + (has_noise ? 1 : 0)), dim3(256), 0, s, part_b, grad_bias,
+                       size_b, gy_blocks, part_n, grad_noise_weight, gy_blocks * gx_blocks, bias_blocks);
+    return MSG_CHECK_LAUNCH();
+}
+
 // ---- y = (a + beta * b) * gain : the residual merges of the discriminator blocks ((main + residual) / sqrt(2),
 // u_net_2d_discriminator.py:185,381) in one pass instead of an add and a mul --------------------------------------
 template <typename T>

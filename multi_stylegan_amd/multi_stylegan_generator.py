@@ -146,7 +146,7 @@ class StyledConv2d(nn.Module):
         self.noise_injection = NoiseInjection()
         self.activation = FusedLeakyReLU(out_channels)
 
-    def forward(self, input: torch.Tensor, style: torch.Tensor, noise: torch.Tensor = None):
+    def forward(self, input: torch.Tensor, style: torch.Tensor, noise: torch.Tensor = None, head_slot=None):
         mc = self.modulated_convolution
         if not mc.upsampling and input.is_cuda:
             # conv -> noise -> bias -> leaky ReLU in one launch (the upsampling layers blur in between: two passes)
@@ -156,7 +156,7 @@ class StyledConv2d(nn.Module):
                 noise = torch.randn(bsz, 1, input.shape[2], input.shape[3], device=input.device, dtype=torch.float32)
             output = conv_ops.modulated_conv2d_bias_act(
                 input, mc.weight, style_out.reshape(bsz, mc.in_channels), mc.demodulate, self.activation.bias, noise,
-                self.noise_injection.weight, self.activation.negative_slope, self.activation.scale)
+                self.noise_injection.weight, self.activation.negative_slope, self.activation.scale, head_slot=head_slot)
             return (output, style_out) if self.modulation_mapping else output
         if mc.upsampling and input.is_cuda:
             # transposed conv -> [blur -> noise -> bias -> leaky ReLU] with the bracket in one launch
@@ -331,7 +331,8 @@ class Generator(nn.Module):
         return True
 
     @staticmethod
-    def _paired_heads(head1: "OutputBlock", head2: "OutputBlock", features: torch.Tensor, latent_w, skip: torch.Tensor):
+    def _paired_heads(head1: "OutputBlock", head2: "OutputBlock", features: torch.Tensor, latent_w, skip: torch.Tensor,
+                      head_slot=None):
         """output_blocks_1[i](features, w) and output_blocks_2[i](features, style_1) as ONE block on a 2 x 3-channel
         map: the reference's second head reads stream 1's features with stream 1's modulated style
         (multi_stylegan_generator.py:184-189) and neither head demodulates, so the two 1x1 modulated convs are one
@@ -343,7 +344,8 @@ class Generator(nn.Module):
         bsz, o1, o2 = features.shape[0], mc1.out_channels, mc2.out_channels
         style = _modulated_style(mc1, latent_w, bsz)
         both = conv_ops.modulated_conv2d(features, torch.cat([mc1.weight, mc2.weight], dim=1),
-                                         style.reshape(bsz, mc1.in_channels), demodulate=False, upsample=False)
+                                         style.reshape(bsz, mc1.in_channels), demodulate=False, upsample=False,
+                                         head_slot=head_slot)
         bias = torch.cat([head1.bias.expand(1, o1, 1, 1), head2.bias.expand(1, o2, 1, 1)], dim=1)
         return _merge_rgb(both, bias, skip, head1.upsampling), style
 
@@ -409,13 +411,17 @@ class Generator(nn.Module):
                                                            noise=layer_noise[2 * i])
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i](out2, style, noise=(layer_noise_2 or layer_noise)[2 * i])
+            # (the level's image heads read out1 and nothing else does but the next level: their data gradient is formed
+            #  inside out1's activation backward instead of being written as a map and summed, conv_ops.HeadGradSlot)
+            slot = conv_ops.HeadGradSlot() if paired and out1.dtype == torch.bfloat16 and torch.is_grad_enabled() and \
+                not return_path_length_grads else None
             out1, style = self.main_convolutions_1[2 * i + 1](out1, w_of(3 + 3 * i, 2 * i + 2),
-                                                               noise=layer_noise[2 * i + 1])
+                                                               noise=layer_noise[2 * i + 1], head_slot=slot)
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i + 1](out2, style, noise=(layer_noise_2 or layer_noise)[2 * i + 1])
             if paired:
                 skip, style = self._paired_heads(self.output_blocks_1[i], self.output_blocks_2[i], out1,
-                                                 w_of(4 + 3 * i, 2 * i + 3), skip)
+                                                 w_of(4 + 3 * i, 2 * i + 3), skip, head_slot=slot)
             else:
                 skip1, style = self.output_blocks_1[i](out1, w_of(4 + 3 * i, 2 * i + 3), skip=skip1)
                 skip2 = self.output_blocks_2[i](out1, style, skip=skip2)     # reads stream 1, as the reference does

@@ -81,6 +81,57 @@ def sign_mask_for(b, c, h, w, dtype, device):
     return torch.empty((b * h * w, c // 8), dtype=torch.uint8, device=device)
 
 
+def act_backward_with_head(gy, head, out_shape, noise, bias_param, need_bias, negative_slope, scale, mask):
+    """The activation backward of a styled layer whose output also feeds the level's image head, with the head's data
+    gradient formed inside the pass (msg_bias_act_backward_mask_head; first-order backward only):
+        gpre = (gy + h) * scale * slope(mask),   h = the head's 1x1 per-sample weights applied to `head.gy`
+    gy: the gradient from the layer's other consumer or None; head: conv_ops.HeadGradSlot contents (gy [B, n, H, W] bf16
+    channels-last with an 8-channel pitch, base weights [n, C] fp32, style [B, C] fp32, scale).  Returns (gpre, grad_bias,
+    grad_noise_weight) like FusedLeakyReLUFunctionBackward, or None when the kernel declines (the caller then takes the
+    head's gradient the ordinary way)."""
+    from .. import conv_ops
+    b, c, h, w = out_shape
+    hgy, whead, style, wscale = head
+    if mask is None or hgy.dtype != torch.bfloat16 or c % 8 or hgy.shape[1] > 8 or not hgy.is_cuda:
+        return None
+    mbytes, tile_m, tile_n = mask
+    hv, ldh = conv_ops._nhwc_view(hgy)
+    if ldh != 8 or mbytes.numel() * 8 != b * c * h * w:
+        return None
+    dev = hgy.device
+    g = None
+    if gy is not None:
+        if gy.dtype != torch.bfloat16 or tuple(gy.shape) != tuple(out_shape):
+            return None
+        g = gy if gy.is_contiguous(memory_format=torch.channels_last) else gy.contiguous(memory_format=torch.channels_last)
+    gx = torch.empty((b, c, h, w), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    gb = None
+    if bias_param is not None and bias_param.dtype == torch.float32 and bias_param.shape == (c,):
+        gb = conv_ops._grad_dest(bias_param)
+    if gb is None and need_bias:
+        gb = torch.empty(c, dtype=torch.float32, device=dev)
+    nz, nb = _noise_args(noise, gx)
+    gnw = torch.empty(1, dtype=torch.float32, device=dev) if noise is not None else None
+    need = 0
+    if gb is not None or noise is not None:
+        wkey = (gx.numel(), 1, c, noise is not None)
+        need = _WS_CACHE.get(wkey)
+        if need is None:
+            need = _WS_CACHE[wkey] = _lib.lib().msg_bias_act_backward_workspace(gx.numel(), 1, c, int(noise is not None))
+    ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+    nbytes = (1 + (g is not None)) * gx.numel() * 2 + mbytes.numel() + b * h * w * 16
+    with _lib.on_device(dev), _lib.kernel_clock.span(('bias_act_bwd_mask_head', gx.dtype), nbytes):
+        code = _lib.lib().msg_bias_act_backward_mask_head(
+            _lib.ptr(g), hv.data_ptr(), whead.data_ptr(), style.data_ptr(), float(wscale), int(hgy.shape[1]),
+            mbytes.data_ptr(), int(tile_m), int(tile_n), gx.data_ptr(), _lib.MSG_BF16, gx.numel(), c,
+            _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, h * w, float(negative_slope), float(scale),
+            _lib.ptr(ws), need, _lib.stream_of(dev))
+    if code == -2:                      # MSG_EUNSUPPORTED (shapes whose workgroups would straddle samples, alignment)
+        return None
+    _lib.check(code, "msg_bias_act_backward_mask_head")
+    return gx, (gb if gb is not None else torch.zeros(0, device=dev)), (gnw if gnw is not None else torch.zeros(0, device=dev))
+
+
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, noise, need_bias, negative_slope, scale, mask=None):

@@ -898,3 +898,86 @@ def test_channel_sums(shape, dtype):
     assert rel_err(a.double(), want) < 1e-5
     assert rel_err(conv_ops._channel_sums(g.contiguous()).double(), want) < 1e-5          # (NCHW: library path)
 
+
+
+@pytest.mark.parametrize("b,c,hw,n_head,other,noise_batch", [(2, 512, 32, 6, True, 2), (3, 128, 16, 6, False, 1),
+                                                             (2, 384, 8, 3, True, 0), (1, 512, 64, 8, False, 1)])
+def test_activation_backward_forms_the_head_gradient(b, c, hw, n_head, other, noise_batch):
+    """msg_bias_act_backward_mask_head against its definition in fp32 torch ops: gx = (gy + h) * scale * slope with
+    h[q][c] = wscale * style[b][c] * sum_o ghead[q][o] * W[o][c], slope from the sign bytes; bias / noise-weight sums of the
+    UNROUNDED gx.  bf16 head weights and one bf16 rounding of gx (2^-7 of max|gx| per element), sums at 2e-3; garbage in the padding planes of the head's
+    gradient must not reach the result."""
+    from multi_stylegan_amd.op_static import fused_act
+    torch.manual_seed(b * 1000 + c + hw)
+    bf = torch.bfloat16
+    y = torch.randn(b, c, hw, hw, device=DEV)
+    pos = (y > 0)
+    bits = pos.permute(0, 2, 3, 1).reshape(b * hw * hw, c // 8, 8).to(torch.int32)
+    mbytes = (bits * (1 << torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous()
+    gy = torch.randn(b, c, hw, hw, device=DEV).to(bf).contiguous(memory_format=torch.channels_last) if other else None
+    hbuf = torch.full((b, hw, hw, 8), float("nan"), device=DEV, dtype=bf)             # padding planes: NaN
+    hbuf[..., :n_head] = torch.randn(b, hw, hw, n_head, device=DEV).to(bf)
+    ghead = hbuf.permute(0, 3, 1, 2)[:, :n_head]
+    whead = torch.randn(n_head, c, device=DEV)
+    style = 1 + 0.3 * torch.randn(b, c, device=DEV)
+    wscale, alpha, scale = 0.044, 0.2, math.sqrt(2)
+    noise = torch.randn(noise_batch, 1, hw, hw, device=DEV) if noise_batch else None
+    bias = torch.zeros(c, device=DEV)
+    got = fused_act.act_backward_with_head(gy, (ghead, whead, style, wscale), (b, c, hw, hw), noise, None, True, alpha, scale,
+                                           (mbytes, 1, c))
+    assert got is not None
+    gx, gb, gnw = got
+    h = torch.einsum("bohw,oc,bc->bchw", ghead.float(), whead, style) * wscale
+    ref = ((gy.float() if other else 0) + h) * scale * torch.where(pos, 1.0, alpha)
+    assert gx.dtype == bf and gx.is_contiguous(memory_format=torch.channels_last)
+    err = (gx.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2 ** -7, err            # (the per-sample head weights enter the MFMA rounded to bf16, then one rounding of gx)
+    assert rel_err(gb, ref.sum(dim=(0, 2, 3))) < 2e-3
+    if noise is not None:
+        assert rel_err(gnw, (ref * noise).sum().reshape(1)) < 5e-3
+    else:
+        assert gnw.numel() == 0
+
+
+def test_image_head_gradient_handed_to_the_producer(monkeypatch):
+    """A styled 3x3 layer (fused activation, sign bytes) whose output feeds a second consumer and a 6-plane image head: with
+    the hand-over (conv_ops.HeadGradSlot) the head's data gradient is formed inside the layer's activation backward; every
+    leaf gradient agrees with the form that writes it as a map and lets autograd add (bf16 roundings of two intermediate maps
+    apart: 1e-2 norm-wise on the bf16 input gradient, 5e-3 on the fp32 sums), the fused kernel is the one that ran; without a second consumer the producer sees no incoming gradient at all."""
+    from multi_stylegan_amd import _lib, conv_ops
+    bf = torch.bfloat16
+
+    def run(fuse, second_consumer):
+        monkeypatch.setattr(conv_ops, "HEAD_GRAD_FUSION", fuse)
+        torch.manual_seed(5)
+        x = conv_ops.to_compute_layout(torch.randn(8, 512, 64, 64, device=DEV), bf).requires_grad_(True)   # (8: the row-sharing kernel)
+        w = torch.randn(1, 512, 512, 3, 3, device=DEV).requires_grad_(True)
+        style = (1 + 0.1 * torch.randn(8, 512, device=DEV)).requires_grad_(True)
+        bias = (0.1 * torch.randn(512, device=DEV)).requires_grad_(True)
+        noise = torch.randn(8, 1, 64, 64, device=DEV)
+        nw = torch.full((1,), 0.3, device=DEV, requires_grad=True)
+        wh = torch.randn(1, 6, 512, 1, 1, device=DEV).requires_grad_(True)
+        sh = (1 + 0.1 * torch.randn(8, 512, device=DEV)).requires_grad_(True)
+        slot = conv_ops.HeadGradSlot()
+        y = conv_ops.modulated_conv2d_bias_act(x, w, style, True, bias, noise, nw, scale=math.sqrt(2), head_slot=slot)
+        rgb = conv_ops.modulated_conv2d(y, wh, sh, False, False, head_slot=slot)
+        g_rgb = torch.randn(rgb.shape, device=DEV)
+        loss = (rgb.float() * g_rgb).sum()
+        if second_consumer:
+            g_y = torch.randn(y.shape, device=DEV).to(bf).contiguous(memory_format=torch.channels_last)
+            loss = loss + (y * g_y).float().sum()
+        _lib.kernel_clock.reset(enabled=True)
+        grads = torch.autograd.grad(loss, (x, w, style, bias, nw, wh, sh))
+        torch.cuda.synchronize()
+        keys = set(_lib.kernel_clock.summary())
+        _lib.kernel_clock.reset(enabled=False)
+        return grads, keys
+
+    for second in (True, False):
+        g1, k1 = run(True, second)
+        g0, k0 = run(False, second)
+        assert any(k.startswith("bias_act_bwd_mask_head/") for k in k1), k1
+        assert not any(k.startswith("bias_act_bwd_mask_head/") for k in k0)
+        for name, a, r in zip(("x", "w", "style", "bias", "noise_w", "w_head", "style_head"), g1, g0):
+            e = ((a.float() - r.float()).norm() / r.float().norm()).item()
+            assert e < (1e-2 if a.dtype == bf else 2e-2 if name == "noise_w" else 5e-3), (name, second, e)   # (noise_w: one cancelling sum)

@@ -442,6 +442,28 @@ int msg_conv2d_fprop_residual(const void* x, const void* w, void* y, int dtype,
                               int kh, int kw, int stride, int pad, long long w_batch_stride,
                               const void* residual, int res_ld, float gain, void* stream);
 
+/* (ABI 5) The DATA GRADIENT of a 3x3 'same' conv whose input was the output of a fused bias (+ noise) + leaky-ReLU stage, with
+ * that stage's backward in the epilogue -- what the reference runs as conv2d_backward_input followed by
+ * FusedLeakyReLUFunctionBackward (op_static/fused_act.py:24-42) on the map in between, which here is never written:
+ *   y = (conv(x, w) [+ residual]) * (s > 0 ? scale : scale * alpha),  grad_bias[n] = sum_pixels y,  grad_noise_weight = sum y * noise
+ * x: the gradient arriving at the conv's output, w: its data-gradient weight image (as for msg_conv2d_fprop).  s = the stage's
+ * stored output, given by `sign_mask` (the bytes of msg_conv2d_fprop_act_mask / msg_upfirdn2d_separable_act_mask, tiles
+ * mask_tile_m x mask_tile_n with mask_tile_m 1 or a multiple of 64, mask_tile_n a multiple of 128) or by `sign_map` (that output itself, bf16, channel pitch
+ * sign_ld) -- exactly one of the two.  residual: a second gradient of the same map (added first), or NULL.  noise [noise_batch]
+ * [OH*OW] fp32 with grad_noise_weight, or both NULL.  Sums: fp32, overwritten, deterministic (per-tile partials in `ws`, summed in
+ * index order; ws_floats >= msg_conv2d_fprop_act_backward_workspace(...)).  Only the row-sharing kernels have this epilogue:
+ * MSG_EUNSUPPORTED unless msg_conv2d_fprop_plan(...) is 3 or 4 (the workspace query then returns 0), bf16, ldy == N. */
+long long msg_conv2d_fprop_act_backward_workspace(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW,
+                                                  int N, int kh, int kw, long long w_batch_stride, int has_noise);
+int msg_conv2d_fprop_act_backward(const void* x, const void* w, void* y, int dtype,
+                                  int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                  int kh, int kw, int stride, int pad, long long w_batch_stride,
+                                  const void* residual, int res_ld,
+                                  const unsigned char* sign_mask, int mask_tile_m, int mask_tile_n,
+                                  const void* sign_map, int sign_ld, float alpha, float scale,
+                                  float* grad_bias, const float* noise, int noise_batch, float* grad_noise_weight,
+                                  float* ws, long long ws_floats, void* stream);
+
 /* -------------------------------------------------------------------------
  * Equalized-lr fully connected layers with few rows (mapping network, style affines, classification head), fp32,
  * dense row-major operands.  Replaces F.linear(input, weight * scale, bias * scale_bias) of

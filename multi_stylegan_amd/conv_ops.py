@@ -693,7 +693,120 @@ def _act_operands(bias, noise, noise_w, y_shape):
     return b32, nz, nw
 
 
-def _d_raw(gy, w, g: Geometry, residual=None):
+ACT_BACKWARD_IN_DGRAD = bool(int(os.environ.get("MSG_ACT_BACKWARD_IN_DGRAD", "1")))   # 0: off (A/B; tests compare the two forms)
+
+
+class ActHandle:
+    """Hand-over between a layer that ends in a fused bias (+ noise) + leaky-ReLU stage (the PRODUCER of a map) and the 3x3
+    'same' conv that is the map's ONLY consumer, for first-order backward passes: the consumer's data-gradient launch applies
+    the stage's backward in its epilogue (msg_conv2d_fprop_act_backward) -- the gradient map between the two backward nodes
+    is never written, the stage's bias / noise-weight gradients come out of the same launch -- and leaves them in `done`;
+    the producer's backward then takes its incoming gradient as already masked.  The producer fills the fields in forward
+    (`arm`); a consumer only hands over to an armed handle; anything the kernel declines keeps the two-pass form."""
+    __slots__ = ("armed", "sign", "alpha", "scale", "bias_param", "has_bias", "noise", "done")
+
+    def __init__(self):
+        self.armed, self.sign, self.done = False, None, None
+        self.alpha = self.scale = 0.0
+        self.bias_param, self.has_bias, self.noise = None, False, None
+
+    def arm(self, y, mask, alpha, scale, bias_param, has_bias, noise):
+        """y: the stage's stored output; mask: (bytes, tile_m, tile_n) when the forward launch left sign bytes, else None."""
+        if not ACT_BACKWARD_IN_DGRAD or y.dtype != torch.bfloat16 or not y.is_cuda:
+            return
+        self.sign = ("mask",) + tuple(mask) if mask is not None else ("map", y)
+        self.alpha, self.scale = float(alpha), float(scale)
+        self.bias_param, self.has_bias, self.noise = bias_param, bool(has_bias), noise
+        self.armed, self.done = True, None
+
+
+_ACTBWD_WS_CACHE: dict = {}
+
+
+def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle: ActHandle, residual=None, mode=None):
+    """The data-gradient contraction (a 3x3 'same' conv of gy with the data-gradient weight image) with the backward of the
+    activation stage described by `handle` in its epilogue.  Returns the masked gradient and fills handle.done = (grad_bias,
+    grad_noise_weight), or returns None when the library declines (another kernel would run this problem, odd layouts)."""
+    if torch.is_grad_enabled() or gy.dtype != torch.bfloat16 or kh != 3 or kw != 3 or n % 8:
+        return None
+    if mode is not None and _contraction_code(gy, mode) != _lib.MSG_BF16:
+        return None
+    dev = gy.device
+    xv, cx = _nhwc_view(gy)
+    b, _, h, w_ = xv.shape
+    wstride = wk.stride(0) if per_sample else 0
+    noise = handle.noise
+    wkey = (b, h, w_, cx, ck, n, wstride, noise is not None)
+    need = _ACTBWD_WS_CACHE.get(wkey)
+    if need is None:
+        need = _ACTBWD_WS_CACHE[wkey] = _lib.lib().msg_conv2d_fprop_act_backward_workspace(
+            _lib.MSG_BF16, b, h, w_, cx, ck, h, w_, n, kh, kw, wstride, int(noise is not None))
+    if not need:
+        return None
+    sign = handle.sign
+    smask = smap = None
+    tm = tn = sld = 0
+    if sign[0] == "mask":
+        smask, tm, tn = sign[1], int(sign[2]), int(sign[3])
+        if smask.numel() * 8 != b * n * h * w_ or (tm != 1 and tm % 64):
+            return None
+    else:
+        smap, sld = _nhwc_view(sign[1])
+        if smap is not sign[1] or tuple(smap.shape) != (b, n, h, w_):
+            return None
+    rv, res_ld = (None, 0)
+    if residual is not None:
+        assert residual[1] == 1.0
+        rv, res_ld = _nhwc_view(residual[0])
+        if rv.shape != (b, n, h, w_) or rv.dtype != gy.dtype:
+            return None
+    y, ldy = _alloc_out(b, n, h, w_, gy.dtype, dev)
+    gb = None
+    if handle.has_bias:
+        bp = handle.bias_param
+        if bp is not None and bp.dtype == torch.float32 and bp.shape == (n,):
+            gb = _grad_dest(bp)
+        if gb is None:
+            gb = torch.empty(n, dtype=torch.float32, device=dev)
+    nz = gnw = None
+    nb = 1
+    if noise is not None:
+        if noise.shape[0] not in (1, b) or tuple(noise.shape[1:]) != (1, h, w_):
+            return None
+        nz, nb = noise.detach().to(torch.float32).contiguous(), noise.shape[0]
+        gnw = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(need, dtype=torch.float32, device=dev)
+    flops = 2.0 * b * h * w_ * n * kh * kw * c_real
+    key = "conv_fprop_row3_actbwd"
+    if _lib.kernel_clock.enabled and _CLOCK_SHAPES:
+        key += f"|B{b} {h}x{w_} {c_real}->{n} 3x3{' per-sample' if per_sample else ''}|"
+    with _lib.on_device(dev), _lib.kernel_clock.span((key, 'bf16'), flops):
+        code = _lib.lib().msg_conv2d_fprop_act_backward(
+            xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.MSG_BF16, b, h, w_, cx, ck, h, w_, n, ldy, kh, kw, 1, 1, wstride,
+            _lib.ptr(rv), res_ld, _lib.ptr(smask), tm, tn, _lib.ptr(smap), sld, handle.alpha, handle.scale,
+            _lib.ptr(gb), _lib.ptr(nz), nb, _lib.ptr(gnw), ws.data_ptr(), need, _lib.stream_of(dev))
+    if code == -2:
+        _ACTBWD_WS_CACHE[wkey] = 0          # (not asked again for this geometry)
+        return None
+    _lib.check(code, "msg_conv2d_fprop_act_backward")
+    handle.done = (gb, gnw)
+    return y
+
+
+def _d_raw(gy, w, g: Geometry, residual=None, act_bwd: Optional["ActHandle"] = None):
+    if act_bwd is not None and act_bwd.armed and not g.per_sample and g.kind == "conv" and g.stride == 1 and g.kh == 3 and \
+            g.kw == 3 and g.pad == 1 and w.ndim == 4:
+        i = _oi(w)[1]
+        img = _param_images(w, gy.dtype, g.wscale, g.kind)
+        wk, ok = img["d"] if img is not None else \
+            _cached(w, "d" + g.kind, gy.dtype, g.wscale, lambda: _relay_dgrad(w, gy.dtype, flip=True))
+        out = _launch_dgrad_act_backward(gy, wk, ok, i, 3, 3, False, _oi(w)[0], act_bwd, residual=residual, mode=g.mode)
+        if out is not None:
+            return out
+    return _d_raw_plain(gy, w, g, residual)
+
+
+def _d_raw_plain(gy, w, g: Geometry, residual=None):
     """Data gradient; residual = (map shaped like the result, gain): (dgrad + map) * gain in the epilogue (plain
     stride-1 convs only -- the caller checks)."""
     assert residual is None or (g.kind == "conv" and g.stride == 1)
@@ -884,13 +997,22 @@ class _ConvActF(Function):
     D / G contractions), so first- and second-order gradients are those of conv followed by FusedLeakyReLU."""
 
     @staticmethod
-    def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale, slot=None, out_scale=None):
+    def forward(ctx, x, w, act_bias, noise, noise_w, g, alpha, scale, slot=None, out_scale=None, act_handle=None,
+                input_act=None):
         o = _oi(w)[0]
         b32, nz, nw = _act_operands(act_bias, noise, noise_w, (x.shape[0], o, *g.y_hw))
         holder = [] if any(ctx.needs_input_grad) else None   # (a forward that no backward follows writes no sign bytes)
         y = _f_raw(x, w, None, g, act=(b32, nz, nw, alpha, scale, holder))
         ctx.mask = holder[0] if holder else None            # sign bytes of y, when the forward kernel wrote them
         ctx.slot, ctx.out_scale = slot, out_scale
+        # act_handle: this layer's output has ONE consumer, a 3x3 conv that may apply this activation's backward in its
+        # data-gradient epilogue (ActHandle); input_act: the handle of the layer that produced x
+        ctx.act_handle = ctx.input_act = None
+        if act_handle is not None and out_scale is None and noise is None and holder is not None:
+            act_handle.arm(y, ctx.mask, alpha, scale, act_bias, act_bias is not None, None)
+            ctx.act_handle = act_handle if act_handle.armed else None
+        if input_act is not None and input_act.armed:
+            ctx.input_act = input_act
         ctx.bias_param = act_bias
         ctx.g, ctx.cfg = g, (alpha, scale, act_bias is not None, noise is not None)
         ctx.nw_shape = None if noise_w is None else noise_w.shape
@@ -906,23 +1028,32 @@ class _ConvActF(Function):
         owed = 1.0
         if ctx.out_scale is not None and ctx.out_scale.pending is not None:
             owed, ctx.out_scale.pending = ctx.out_scale.pending, None        # (see GradScale: the consumer's gain, deferred)
-        gpre, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y, noise if has_noise else None,
-                                                             ctx.bias_param if has_bias else False, alpha, scale * owed,
-                                                             ctx.mask)
+        handed = ctx.act_handle.done if ctx.act_handle is not None else None
+        if handed is not None:
+            # the consumer's data-gradient launch applied this activation's backward in its epilogue (ActHandle): gy IS gpre
+            ctx.act_handle.done = None
+            gpre, (gb, gnw) = gy, handed
+        else:
+            gpre, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y, noise if has_noise else None,
+                                    ctx.bias_param if has_bias else False, alpha, scale * owed, ctx.mask)
         gx = None
         if ctx.needs_input_grad[0]:
             other = ctx.slot.g if ctx.slot is not None else None
+            pre = ctx.input_act if not torch.is_grad_enabled() else None      # (x's producer: its activation backward rides along)
             if _dgrad_add_ok(other, x.shape, gpre.dtype, g):
                 # the block input's OTHER gradient (from the 1x1 residual conv, computed just before) is added in this
                 # data-gradient conv's epilogue: no separate accumulation pass over the input map (second-order graphs: the
                 # same launch as a differentiable node)
-                gx = _derive(_ConvD, gpre, w, g, other) if torch.is_grad_enabled() else _d_raw(gpre, w, g, residual=(other, 1.0))
+                gx = _derive(_ConvD, gpre, w, g, other) if torch.is_grad_enabled() else \
+                    _d_raw(gpre, w, g, residual=(other, 1.0), act_bwd=pre)
                 ctx.slot.merged = True
+            elif pre is not None:
+                gx = _d_raw(gpre, w, g, act_bwd=pre)
             else:
                 gx = _derive(_ConvD, gpre, w, g)
         gw = _derive(_ConvG, gpre, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, \
-            (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None, None
+            (gnw.reshape(ctx.nw_shape) if has_noise and ctx.needs_input_grad[4] else None), None, None, None, None, None, None, None
 
 
 class _ConvResidualF(Function):
@@ -1105,13 +1236,14 @@ def conv2d_add_residual(x, weight, main, gain, stride=1, padding=0, wscale=1.0, 
 
 # ------------------------------------------------------------------------------------------------- public entry
 def conv2d_bias_act(x, weight, act_bias, stride=1, padding=0, wscale=1.0, negative_slope=0.2, scale=1.0,
-                    grad_slot=None, out_grad_scale=None):
+                    grad_slot=None, out_grad_scale=None, act_handle=None, input_act=None):
     """leaky_relu(conv(x, wscale * weight) + act_bias) * scale in one launch (EqualizedConv2d -> FusedLeakyReLU).
-    ``out_grad_scale``: a GradScale shared with the output's only consumer (see there)."""
+    ``out_grad_scale``: a GradScale shared with the output's only consumer (see there).  ``act_handle``: an ActHandle shared
+    with the output's only consumer, a 3x3 conv that receives it as ``input_act`` (see ActHandle)."""
     s, p = _square(stride, "stride"), _square(padding, "padding")
     g = Geometry("conv", weight.shape[2], weight.shape[3], s, p, x.shape[2:], False, wscale)
     return _ConvActF.apply(x, weight, act_bias, None, None, g, float(negative_slope), float(scale), grad_slot,
-                           out_grad_scale)
+                           out_grad_scale, act_handle, input_act)
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, wscale=1.0):
@@ -1501,8 +1633,13 @@ def _tap_square_sums(weight, w3, kind):
         _cached(weight, "wsq", torch.float32, 1.0, lambda: (w3.square().sum(dim=2).contiguous(), 0))[0]
 
 
-def _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g):
-    """Data-gradient contraction of the modulated conv with a per-sample data-gradient weight image."""
+def _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g, act_bwd=None):
+    """Data-gradient contraction of the modulated conv with a per-sample data-gradient weight image; act_bwd: the ActHandle
+    of the layer that produced the conv's input (its activation backward then runs in this launch's epilogue)."""
+    if act_bwd is not None and act_bwd.armed and not upsample and kh == 3 and kw == 3:
+        out = _launch_dgrad_act_backward(gy, wd, okp, i, kh, kw, True, o, act_bwd, mode=g.mode)
+        if out is not None:
+            return out
     if upsample:
         return _launch_fprop(gy, wd, okp, None, i, g.x_hw, 2, 2, 2, 0, 1, False, True, o, mode=g.mode)
     return _launch_fprop(gy, wd, okp, None, i, g.x_hw, kh, kw, 1, kh - 1 - kh // 2, 1, False, True, o, mode=g.mode)
@@ -1549,7 +1686,8 @@ def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=Non
     return (out if out is not None else gw3), gs_part.sum(dim=0).to(style_dtype)
 
 
-def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, keep_gwk=False, direct=False):
+def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, keep_gwk=False, direct=False,
+                      act_bwd=None):
     """First-order backward of the modulated convolution for at most 16 samples: data gradient with re-laid per-sample
     weights, per-sample weight gradient, and the kernel that folds it into dL/dW and dL/ds (see _ModulatedConv)."""
     _, o, i, kh, kw = weight.shape
@@ -1564,7 +1702,7 @@ def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, n
         okp = _round_up(o, 128 // esz)
         wd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
         _scale_rows_cols(_dgrad_image_base(weight, w3, upsample, g.kind), s, dd, wd, scale)
-        gx = _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g)
+        gx = _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g, act_bwd=act_bwd)
     gw = gs = gwk = None
     if need[1] or need[2]:
         gwk, ldg = _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g)
@@ -1694,8 +1832,9 @@ class _ModulatedConv(Function):
 
     @staticmethod
     def forward(ctx, x, weight, style, demodulate, upsample, act_bias=None, noise=None, noise_w=None, alpha=0.2,
-                act_scale=1.0, fuse_act=False, head_slot=None):
+                act_scale=1.0, fuse_act=False, head_slot=None, input_act=None):
         dev = _lib.require_gpu(x, weight, style)
+        ctx.input_act = input_act if input_act is not None and input_act.armed else None     # (ActHandle of x's producer)
         # head_slot (HeadGradSlot): on a styled layer WITH its activation, the slot its level's image head fills in backward;
         # on the head itself (no activation), the slot to fill.  The producer may then see no incoming gradient at all.
         ctx.head_slot = head_slot
@@ -1775,13 +1914,13 @@ class _ModulatedConv(Function):
             if fused is not None:
                 gy, gb, gnw = fused
             elif gy is None:
-                return (None,) * 12
+                return (None,) * 13
             else:
                 gy, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y_act, noise if has_noise else None,
                                       ctx.bias_param if has_bias else False, alpha, act_scale, ctx.mask)
             gb = gb if has_bias and need[5] else None
             gnw = gnw.reshape(nw_shape) if has_noise and need[7] else None
-        tail = (None, None, gb, None, gnw, None, None, None, None)
+        tail = (None, None, gb, None, gnw, None, None, None, None, None)
         if ctx.act is None and slot is not None and slot.armed and need[0] and not torch.is_grad_enabled() and \
                 fused_head_ok(gy, weight, b, demodulate, upsample):
             # this IS the head: weight / style gradients as always, the data gradient handed to the producer's activation backward
@@ -1817,7 +1956,8 @@ class _ModulatedConv(Function):
             gw = torch.stack(gws).sum(dim=0) if gws[0] is not None else None
             gs = torch.cat(gss) if gss[0] is not None else None
             return (gx, gw, gs) + tail
-        gx, gw, gs = _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, direct=True)
+        gx, gw, gs = _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, direct=True,
+                                       act_bwd=ctx.input_act)
         return (gx, gw, gs) + tail
 
 
@@ -1833,12 +1973,13 @@ HEAD_GRAD_FUSION = bool(int(os.environ.get("MSG_HEAD_GRAD_FUSION", "1")))   # 0 
 
 
 def modulated_conv2d_bias_act(x, weight, style, demodulate, act_bias, noise, noise_weight, negative_slope=0.2,
-                              scale=1.0, head_slot=None):
+                              scale=1.0, head_slot=None, input_act=None):
     """modulated_conv2d (no upsampling) -> noise injection -> bias -> leaky ReLU, the activation stage fused into the
     contraction's epilogue (multi_stylegan_generator.py:267-292 + 384-411 in one pass over the output map).
-    head_slot: the HeadGradSlot the level's image head fills in backward (see there)."""
+    head_slot: the HeadGradSlot the level's image head fills in backward (see there); input_act: the ActHandle of the layer
+    that produced x, when this conv is x's only consumer."""
     return _ModulatedConv.apply(x, weight, style, bool(demodulate), False, act_bias, noise, noise_weight,
-                                float(negative_slope), float(scale), True, head_slot)
+                                float(negative_slope), float(scale), True, head_slot, input_act)
 
 
 def modulated_conv2d(x, weight, style, demodulate, upsample, head_slot=None):

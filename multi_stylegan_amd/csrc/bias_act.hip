@@ -373,6 +373,18 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(const float* _
     if (threadIdx.x == 0) *grad_nw = red[0];
 }
 
+// The second stage on its own: for partial sums another kernel left (the activation backward in a conv epilogue,
+// conv_fprop_row3.hip): grad_bias[c] = sum over n_b rows of part_b[.][C], *grad_nw = sum of n_n entries of part_n.
+extern "C" int msg_bias_act_reduce_launch(const float* part_b, float* grad_bias, int C, long long n_b, const float* part_n,
+                                          float* grad_nw, long long n_n, void* stream) {
+    const int bias_blocks = (part_b && grad_bias) ? (C + BRC - 1) / BRC : 0;
+    const bool has_noise = part_n && grad_nw;
+    if (bias_blocks + (has_noise ? 1 : 0) == 0) return MSG_OK;
+    hipLaunchKernelGGL(bias_act_bwd_reduce_kernel, dim3(bias_blocks + (has_noise ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, part_b,
+                       grad_bias, C, n_b, part_n, grad_nw, n_n, bias_blocks);
+    return MSG_CHECK_LAUNCH();
+}
+
 // The launch geometry of the backward, a function of the SHAPE only (the workspace query and the launch must agree).
 struct BwdPlan {
     int path;                   // 0 channels-last vectors, 1 planar, 2 strided

@@ -590,6 +590,76 @@ extern "C" int msg_conv2d_fprop_residual(const void* x, const void* w, void* y, 
                              w_batch_stride, act, stream);
 }
 
+extern "C" int msg_bias_act_reduce_launch(const float* part_b, float* grad_bias, int C, long long n_b, const float* part_n,
+                                          float* grad_nw, long long n_n, void* stream);
+
+// Partial-sum rows / entries of msg_conv2d_fprop_act_backward for this problem: rows of [N] floats (one per sample, pixel tile
+// and wave row of the row-sharing kernel) and noise entries (one per sample, tile and wave); 0 rows = the problem does not go to
+// that kernel (no fusion).
+static void act_backward_partials(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int kh, int kw,
+                                  long long w_batch_stride, long long* rows, long long* entries) {
+    *rows = *entries = 0;
+    const int plan = msg_conv2d_fprop_plan(dtype, B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride);
+    if (dtype != MSG_BF16 || (plan != 3 && plan != 4)) return;
+    const int hm = plan == 3 ? 256 : 128;
+    const long long mtot = w_batch_stride ? (long long)OH * OW : (long long)B * OH * OW;
+    const long long tiles = (mtot / hm) * (w_batch_stride ? B : 1);
+    *rows = tiles * 2;
+    *entries = tiles * (N / hm) * 4;
+}
+
+extern "C" long long msg_conv2d_fprop_act_backward_workspace(int dtype, int B, int IH, int IW, int Cx, int Ck, int OH, int OW,
+                                                             int N, int kh, int kw, long long w_batch_stride, int has_noise) {
+    long long rows, entries;
+    act_backward_partials(dtype, B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride, &rows, &entries);
+    return rows ? rows * N + (has_noise ? entries : 0) : 0;
+}
+
+// The data gradient of a 3x3 'same' conv whose INPUT was the output of a fused bias (+ noise) + leaky-ReLU stage, with that
+// stage's backward in the epilogue (ActEpilogue::enabled == 3): y = (conv(x, w) [+ residual]) * (s > 0 ? scale : scale * alpha)
+// and the stage's bias / noise-weight gradients -- the map between the two backward nodes is never written.  s: `sign_mask`
+// (bytes of msg_conv2d_fprop_act_mask / msg_upfirdn2d_separable_act_mask in tiles mask_tile_m x mask_tile_n; tile_m 1 or a
+// multiple of 64) or `sign_map` (the stage's stored output, bf16, channel pitch sign_ld).  Only the row-sharing kernels
+// (msg_conv2d_fprop_plan == 3 or 4) have this epilogue: MSG_EUNSUPPORTED otherwise, as for anything but bf16.
+extern "C" int msg_conv2d_fprop_act_backward(const void* x, const void* w, void* y, int dtype,
+                                             int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
+                                             int kh, int kw, int stride, int pad, long long w_batch_stride,
+                                             const void* residual, int res_ld,
+                                             const unsigned char* sign_mask, int mask_tile_m, int mask_tile_n,
+                                             const void* sign_map, int sign_ld, float alpha, float scale,
+                                             float* grad_bias, const float* noise, int noise_batch, float* grad_noise_weight,
+                                             float* ws, long long ws_floats, void* stream) {
+    if (B == 0) return MSG_OK;
+    if (!x || !w || !y || B < 0) return MSG_EINVAL;
+    if (!sign_mask == !sign_map) return MSG_EINVAL;                         // exactly one sign source
+    if (stride != 1 || pad != 1 || kh != 3 || kw != 3 || ldy != N) return MSG_EUNSUPPORTED;
+    long long rows, entries;
+    act_backward_partials(dtype, B, IH, IW, Cx, Ck, OH, OW, N, kh, kw, w_batch_stride, &rows, &entries);
+    if (!rows) return MSG_EUNSUPPORTED;
+    if (sign_mask && (mask_tile_m <= 0 || mask_tile_n <= 0 || mask_tile_n % 128 || N % mask_tile_n || (((uintptr_t)sign_mask) & 15u) ||
+                      (mask_tile_m != 1 && mask_tile_m % 64) || ((long long)B * OH * OW) % mask_tile_m))
+        return MSG_EINVAL;
+    if (sign_map && (sign_ld < N || sign_ld % 8 || (((uintptr_t)sign_map) & 15u))) return MSG_EINVAL;
+    if (residual && (res_ld < N || res_ld % 8 || (((uintptr_t)residual) & 15u))) return MSG_EINVAL;
+    const bool has_noise = noise && grad_noise_weight;
+    if (has_noise && noise_batch != 1 && noise_batch != B) return MSG_EINVAL;
+    const long long need_b = grad_bias ? rows * N : 0, need_n = has_noise ? entries : 0;
+    if (need_b + need_n > 0 && (!ws || ws_floats < need_b + need_n)) return MSG_EINVAL;
+    ActEpilogue act{};
+    act.enabled = 3; act.alpha = alpha; act.scale = scale;
+    act.residual = residual; act.res_ld = res_ld; act.res_gain = 1.f;
+    act.mask = const_cast<unsigned char*>(sign_mask); act.mask_tile_m = mask_tile_m; act.mask_tile_n = mask_tile_n;
+    act.sign_src = sign_map; act.sign_ld = sign_ld;
+    act.noise = has_noise ? noise : nullptr; act.noise_batch = noise_batch;
+    act.part_b = grad_bias ? ws : nullptr;
+    act.part_n = has_noise ? ws + need_b : nullptr;
+    if (!msg_conv2d_fprop_row3_try(x, w, nullptr, y, B, IH, IW, Cx, Ck, OH, OW, N, ldy, kh, kw, stride, pad, 1, 0, w_batch_stride,
+                                   &act, stream))
+        return MSG_EUNSUPPORTED;
+    if (MSG_CHECK_LAUNCH() != MSG_OK) return MSG_ELAUNCH;
+    return msg_bias_act_reduce_launch(act.part_b, grad_bias, N, rows, act.part_n, grad_noise_weight, entries, stream);
+}
+
 static int conv2d_fprop_impl(const void* x, const void* w, const float* bias, void* y, int dtype,
                              int B, int IH, int IW, int Cx, int Ck, int OH, int OW, int N, int ldy,
                              int kh, int kw, int stride, int pad, int in_up, int pixel_shuffle,

@@ -71,7 +71,9 @@ extern "C" int msg_row3_clock_read(void* host_dst, int nbytes) {
 // MI / NCOLB = 32-row / 32-column blocks per wave (waves are 2 x 2): <4,4> the 256 x 256 tile with 128 x 128 wave tiles, one
 // workgroup per CU; <2,2> a 128 x 128 tile with 64 x 64 wave tiles and TWO workgroups per CU for layers with 128 / 384
 // output channels (<4,2>, 256 x 128 with one workgroup per CU, measured no better than the plain 128x128 kernel).
-template <int MI, int NCOLB, bool S16>
+// EPI = 1: the epilogue is the backward of the activation in front of this conv's input (ActEpilogue::enabled == 3, see
+// msg_common.h) -- its own instantiation, so that the kernels of the forward / plain data-gradient launches are the code they were.
+template <int MI, int NCOLB, bool S16, int EPI = 0>
 __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                                  bf16_t* __restrict__ y, const float* __restrict__ bias,
                                                                  ConvParamsR3 p) {
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     //  per-pixel noise, twice per tile -- sat in front of every half patch with their full latency; tools/layer_probe.py:
     //  the fused stage cost 330 us of a 3 300 us launch)
     constexpr int EP_OFF = 2 * HA + 2 * HB;
-    __shared__ __attribute__((aligned(16))) char smem[EP_OFF + (HM + HN) * 4];
+    // (EPI 1: + the tile's sign bytes, [HM rows][HN / 8], fetched at kernel start like the noise: see the epilogue)
+    constexpr int SIGN_OFF = EP_OFF + (HM + HN) * 4;
+    __shared__ __attribute__((aligned(16))) char smem[SIGN_OFF + (EPI == 1 ? HM * (HN / 8) : 0)];
     float* const ep_noise = reinterpret_cast<float*>(smem + EP_OFF);
     float* const ep_bias = ep_noise + HM;
 
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     const int ohw = p.OH * p.OW;
     const int seg = p.seg_len;
     R3_CLOCK(0);
-    if (p.act.enabled == 1) {
+    if (p.act.enabled == 1 || (EPI == 1 && p.act.noise)) {
         const bool want_noise = p.act.noise != nullptr;
-        const float nw = want_noise ? p.act.noise_w[0] : 0.f;
+        const float nw = EPI == 1 ? 1.f : (want_noise ? p.act.noise_w[0] : 0.f);     // (EPI 1: the noise itself, for the noise-weight gradient)
         for (int t = tid; t < HM; t += 256) {
             const int m = m0 + t;
             const bool ok = want_noise && m < p.Mtot;
@@ -124,7 +128,28 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
             if (!p.per_sample && p.act.noise_batch == 1) idx = p.ohw_shift >= 0 ? mm & (ohw - 1) : mm % ohw;
             ep_noise[t] = ok ? nw * p.act.noise[idx] : 0.f;
         }
-        for (int t = tid; t < HN; t += 256) ep_bias[t] = (p.act.bias && n0 + t < p.N) ? p.act.bias[n0 + t] : 0.f;
+        if (EPI == 0)
+            for (int t = tid; t < HN; t += 256) ep_bias[t] = (p.act.bias && n0 + t < p.N) ? p.act.bias[n0 + t] : 0.f;
+    }
+    if constexpr (EPI == 1) {
+        // The sign bytes of this tile (written by ANOTHER launch in tiles of mask_tile_m x mask_tile_n, act_mask_index) into LDS
+        // now, in 16-byte units = one row x 128 channels, which lie inside one tile of the producer (mask_tile_n is a multiple
+        // of 128, or the whole row): fetched in the epilogue they sat in front of every half patch with their full latency,
+        // +29 % on the 128-channel layers.
+        if (p.act.mask) {
+            constexpr int UPR = HN / 128;                                    // units per row
+            const int vpt = p.act.mask_tile_n >> 3, ntn = p.N / p.act.mask_tile_n;
+            for (int t = tid; t < HM * UPR; t += 256) {
+                const int row = t / UPR, un = t - row * UPR;
+                const long long qg = (p.per_sample ? (long long)bz * ohw : 0) + m0 + row;
+                const int cvg = (n0 >> 3) + 16 * un;
+                const long long trow = qg / p.act.mask_tile_m;
+                const int tn = cvg / vpt;
+                const unsigned char* src = p.act.mask +
+                    ((trow * ntn + tn) * p.act.mask_tile_m + (qg - trow * p.act.mask_tile_m)) * vpt + (cvg - tn * vpt);
+                *reinterpret_cast<u32x4*>(smem + SIGN_OFF + row * (HN / 8) + 16 * un) = *reinterpret_cast<const u32x4*>(src);
+            }
+        }
     }
 
     // ---- staging (LDS-DMA through buffer loads): one wave-instruction fills 1 KiB = 8 consecutive rows in lane order.
@@ -469,6 +494,104 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_fprop_row3_kernel(c
     // pixel m is row m: no bounds predicates and no coordinates here.  (One wave per SIMD: every epilogue instruction is four
     // cycles that nothing overlaps; the stepped (b, oh, ow) coordinates and 16 predicated stores per half were a third of them.)
     // half-patches of 64 rows: all rows / residual vectors of a half requested before any is used
+    if constexpr (EPI == 1) {
+        // ---- activation backward in the epilogue (ActEpilogue::enabled == 3).  Per half patch: sign source (bytes or the stored
+        // output), optional residual, y = (conv + residual) * slope in fp32 from the ROUNDED conv result, one rounding; the lane's
+        // eight channel sums and its noise-weighted sum run across the halves.
+        float cs[VEC], sn = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) cs[e] = 0.f;
+        const unsigned char* ep_sign = reinterpret_cast<const unsigned char*>(smem + SIGN_OFF) + (wn * WN + ec) / 8;
+#pragma unroll 1
+        for (int half = 0; half < MI / 2; ++half) {
+            const int m_first = m0 + wm * WM + half * 64 + er;
+            const long long qg = (p.per_sample ? (long long)bz * ohw : 0) + m_first;     // pixel index over the whole batch
+            float a_noise[NP];
+            if (p.act.noise) {
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) a_noise[pass] = ep_noise[wm * WM + half * 64 + pass * RPP + er];
+            }
+            if (half == 0) __syncthreads();
+            u32x4 v[NP];
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int row = half * 64 + pass * RPP + er;
+                v[pass] = *reinterpret_cast<const u32x4*>(ep + row * PITCH + ((u16 ^ ((row & 15) >> 1)) << 4));
+            }
+            unsigned sbits[NP];
+            if (p.act.mask) {
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) sbits[pass] = ep_sign[(wm * WM + half * 64 + pass * RPP + er) * (HN / 8)];
+            } else {
+                const bf16_t* srow = reinterpret_cast<const bf16_t*>(p.act.sign_src) + n + qg * p.act.sign_ld;
+                u32x4 sv[NP];
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass)
+                    sv[pass] = *reinterpret_cast<const u32x4*>(srow + (long long)(pass * RPP) * p.act.sign_ld);
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) sbits[pass] = act_sign_byte(sv[pass]);
+            }
+            u32x4 r[NP];
+            const bool has_res = p.act.residual != nullptr;
+            if (has_res) {
+                const bf16_t* rrow = reinterpret_cast<const bf16_t*>(p.act.residual) + n + qg * p.act.res_ld;
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass)
+                    r[pass] = *reinterpret_cast<const u32x4*>(rrow + (long long)(pass * RPP) * p.act.res_ld);
+            }
+            if (er & 1) {
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) v[pass] = u32x4{v[pass][2], v[pass][3], v[pass][0], v[pass][1]};
+            }
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+#pragma clang fp contract(off)
+                float f[VEC], rowsum = 0.f;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const unsigned w = v[pass][e >> 1];
+                    float val = (e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+                    if (has_res) {
+                        const unsigned wr = r[pass][e >> 1];
+                        val += (e & 1) ? __uint_as_float(wr & 0xffff0000u) : __uint_as_float(wr << 16);
+                        val = bf2f(f2bf(val));         // (the two-pass form stores the sum before the activation backward reads it)
+                    }
+                    f[e] = val * p.act.scale * (((sbits[pass] >> e) & 1u) ? 1.f : p.act.alpha);   // (the stand-alone kernel's order: same bits)
+                    cs[e] += f[e];
+                    rowsum += f[e];
+                }
+                if (p.act.noise) sn = fmaf(rowsum, a_noise[pass], sn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[pass][e] = (unsigned)f2bf(f[2 * e]) | ((unsigned)f2bf(f[2 * e + 1]) << 16);
+            }
+            bf16_t* yrow = y + (p.per_sample ? (long long)bz * p.y_bstride : 0) + n + (long long)m_first * p.ldy;
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) *reinterpret_cast<u32x4*>(yrow + (long long)(pass * RPP) * p.ldy) = v[pass];
+        }
+        // partial sums: the lanes that share a channel vector (lane = er * LPR + u16) in a fixed butterfly; one row of part_b per
+        // (sample, pixel tile, wave row), one entry of part_n per (sample, tile, wave) -- summed in index order by the reduce launch
+        const long long mt = (long long)(p.per_sample ? bz : 0) * p.m_tiles + L / p.n_tiles;
+        if (p.act.part_b) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float t = cs[e];
+#pragma unroll
+                for (int off = 32; off >= LPR; off >>= 1) t += __shfl_xor(t, off, 64);
+                cs[e] = t;
+            }
+            if (er == 0) {
+                float* dst = p.act.part_b + (mt * 2 + wm) * p.N + n;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dst[e] = cs[e];
+            }
+        }
+        if (p.act.part_n) {
+            sn = wave_sum(sn);
+            if (lane == 0) p.act.part_n[(mt * p.n_tiles + L % p.n_tiles) * 4 + wid] = sn;
+        }
+        R3_CLOCK(3);
+        return;
+    }
 #pragma unroll 1
     for (int half = 0; half < MI / 2; ++half) {
         const int m_first = m0 + wm * WM + half * 64 + er;              // this lane's first pixel of the half (inside the sample)
@@ -609,6 +732,16 @@ extern "C" int msg_conv2d_fprop_row3_try(const void* x, const void* w, const flo
     // MSG_CONV_ROW3_S16=0: the 256 x 256 tile on v_mfma_f32_32x32x16_bf16 (A/B)
     static const int s16 = msg_tunable("MSG_CONV_ROW3_S16", 1);
     static const int s16n = msg_tunable("MSG_CONV_ROW3N_S16", 1);    // (the 128 x 128 tile: +2..6 %)
+    if (p.act.enabled == 3) {
+        if (bias) return 0;
+        if (hn == 256)
+            hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)w, (bf16_t*)y, bias, p);
+        else
+            hipLaunchKernelGGL((conv_fprop_row3_kernel<2, 2, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)w, (bf16_t*)y, bias, p);
+        return 1;
+    }
     if (hn == 256 && s16)
         hipLaunchKernelGGL((conv_fprop_row3_kernel<4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)y, bias, p);

@@ -109,6 +109,17 @@ struct ActEpilogue {
                              // write it: conv_fprop_row3.hip, blur_sep.hip; the others ignore the field).  Layout: the
                              // producer's OUTPUT TILES one after the other (act_mask_index below), so that a workgroup writes
                              // one contiguous block instead of byte-granular pieces of lines it shares with other workgroups.
+    // enabled == 3 (conv_fprop_row3.hip only; msg_conv2d_fprop_act_backward): this launch is the data gradient of the conv BEHIND an
+    // activation and applies that activation's backward in its epilogue -- y = (conv [+ residual]) * (s > 0 ? scale : scale *
+    // alpha), s = the activation's stored OUTPUT, known from `mask` (sign bytes another launch wrote in tiles of mask_tile_m x
+    // mask_tile_n, act_mask_index) or from the output map itself (`sign_src`, channel pitch sign_ld) -- and leaves the partial sums
+    // of the activation's bias / noise-weight gradients: part_b [rows][N] (one row per sample, pixel tile and wave row), part_n
+    // (one value per sample, tile and wave; `noise` as for enabled == 1, without its weight).
+    int mask_tile_m, mask_tile_n;
+    const void* sign_src;
+    int sign_ld;
+    float* part_b;
+    float* part_n;
 };
 
 // Byte index of (global pixel q, channel vector cv) in the sign-byte map of a [pixels][C] output produced in tiles of

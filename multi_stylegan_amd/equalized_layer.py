@@ -34,14 +34,16 @@ class EqualizedConv2d(nn.Module):
         b = None if self.bias is None else self.bias * self.scale_bias
         return conv_ops.conv2d(input, self.weight, b, stride=self.stride, padding=self.padding, wscale=self.scale)
 
-    def forward_activated(self, input: torch.Tensor, activation, grad_slot=None, out_grad_scale=None) -> torch.Tensor:
+    def forward_activated(self, input: torch.Tensor, activation, grad_slot=None, out_grad_scale=None, act_handle=None,
+                          input_act=None) -> torch.Tensor:
         """``activation(self(input))`` for a following FusedLeakyReLU, its bias + leaky ReLU fused into this conv's
         epilogue (one pass over the output map instead of two; same result bit for bit)."""
         if self.bias is not None or not input.is_cuda:
             return activation(self(input))
         return conv_ops.conv2d_bias_act(input, self.weight, activation.bias, stride=self.stride, padding=self.padding,
                                         wscale=self.scale, negative_slope=activation.negative_slope,
-                                        scale=activation.scale, grad_slot=grad_slot, out_grad_scale=out_grad_scale)
+                                        scale=activation.scale, grad_slot=grad_slot, out_grad_scale=out_grad_scale,
+                                        act_handle=act_handle, input_act=input_act)
 
 
 class EqualizedTransposedConv2d(nn.Module):

@@ -146,7 +146,8 @@ class StyledConv2d(nn.Module):
         self.noise_injection = NoiseInjection()
         self.activation = FusedLeakyReLU(out_channels)
 
-    def forward(self, input: torch.Tensor, style: torch.Tensor, noise: torch.Tensor = None, head_slot=None):
+    def forward(self, input: torch.Tensor, style: torch.Tensor, noise: torch.Tensor = None, head_slot=None, act_handle=None,
+                input_act=None):
         mc = self.modulated_convolution
         if not mc.upsampling and input.is_cuda:
             # conv -> noise -> bias -> leaky ReLU in one launch (the upsampling layers blur in between: two passes)
@@ -156,7 +157,8 @@ class StyledConv2d(nn.Module):
                 noise = torch.randn(bsz, 1, input.shape[2], input.shape[3], device=input.device, dtype=torch.float32)
             output = conv_ops.modulated_conv2d_bias_act(
                 input, mc.weight, style_out.reshape(bsz, mc.in_channels), mc.demodulate, self.activation.bias, noise,
-                self.noise_injection.weight, self.activation.negative_slope, self.activation.scale, head_slot=head_slot)
+                self.noise_injection.weight, self.activation.negative_slope, self.activation.scale, head_slot=head_slot,
+                input_act=input_act)
             return (output, style_out) if self.modulation_mapping else output
         if mc.upsampling and input.is_cuda:
             # transposed conv -> [blur -> noise -> bias -> leaky ReLU] with the bracket in one launch
@@ -167,7 +169,8 @@ class StyledConv2d(nn.Module):
             if noise is None:
                 noise = torch.randn(output.shape[0], 1, oh, ow, device=input.device, dtype=torch.float32)
             output = blur_bias_act(output, mc.blur.kernel, mc.blur.padding, self.activation.bias, noise,
-                                   self.noise_injection.weight, self.activation.negative_slope, self.activation.scale)
+                                   self.noise_injection.weight, self.activation.negative_slope, self.activation.scale,
+                                   act_handle=act_handle)
             return (output, style_out) if self.modulation_mapping else output
         result = self.modulated_convolution(input, style)
         output, style_out = result if self.modulation_mapping else (result, None)
@@ -407,8 +410,11 @@ class Generator(nn.Module):
         paired = n_main >= 2 and skip1.shape == skip2.shape and self._heads_pairable(out1)
         skip = torch.cat([skip1, skip2], dim=1) if paired else None
         for i in range(n_main // 2):
+            # (the upsampling layer's output feeds the level's 3x3 layer and nothing else: its activation backward rides in that
+            #  layer's data-gradient epilogue, conv_ops.ActHandle)
+            handle = conv_ops.ActHandle() if out1.is_cuda and torch.is_grad_enabled() and not return_path_length_grads else None
             out1, style = self.main_convolutions_1[2 * i](out1, w_of(2 + 3 * i, 2 * i + 1),
-                                                           noise=layer_noise[2 * i])
+                                                           noise=layer_noise[2 * i], act_handle=handle)
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i](out2, style, noise=(layer_noise_2 or layer_noise)[2 * i])
             # (the level's image heads read out1 and nothing else does but the next level: their data gradient is formed
@@ -416,7 +422,7 @@ class Generator(nn.Module):
             slot = conv_ops.HeadGradSlot() if paired and out1.dtype == torch.bfloat16 and torch.is_grad_enabled() and \
                 not return_path_length_grads else None
             out1, style = self.main_convolutions_1[2 * i + 1](out1, w_of(3 + 3 * i, 2 * i + 2),
-                                                               noise=layer_noise[2 * i + 1], head_slot=slot)
+                                                               noise=layer_noise[2 * i + 1], head_slot=slot, input_act=handle)
             if run_stream2:
                 out2 = self.main_convolutions_2[2 * i + 1](out2, style, noise=(layer_noise_2 or layer_noise)[2 * i + 1])
             if paired:

@@ -233,7 +233,7 @@ class BlurBiasAct(Function):
     adjoint FIR pass), so second-order terms are those of the two-pass form."""
 
     @staticmethod
-    def forward(ctx, x, fir, pad, bias, noise, noise_w, alpha, scale):
+    def forward(ctx, x, fir, pad, bias, noise, noise_w, alpha, scale, act_handle=None):
         px0, px1, py0, py1 = pad
         dev = _lib.require_gpu(x, fir, bias, noise, noise_w)
         b, c, h, w = x.shape
@@ -261,6 +261,12 @@ class BlurBiasAct(Function):
         ctx.cfg = (pad, (h, w), float(alpha), float(scale), bias is not None, noise is not None,
                    None if noise_w is None else noise_w.shape)
         ctx.save_for_backward(fir, _flipped(fir), y, noise)
+        # act_handle (conv_ops.ActHandle): the output's only consumer is a 3x3 conv that may run this activation's backward in
+        # the epilogue of its data-gradient launch
+        ctx.act_handle = None
+        if act_handle is not None and mask is not None:
+            act_handle.arm(y, ctx.mask, alpha, scale, None, bias is not None, noise)
+            ctx.act_handle = act_handle if act_handle.armed else None
         return y
 
     @staticmethod
@@ -268,18 +274,24 @@ class BlurBiasAct(Function):
         from .fused_act import FusedLeakyReLUFunctionBackward
         fir, fir_flipped, y, noise = ctx.saved_tensors
         pad, in_hw, alpha, scale, has_bias, has_noise, nw_shape = ctx.cfg
-        gpre, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y, noise if has_noise else None, has_bias, alpha, scale,
-                                                             ctx.mask)
+        handed = ctx.act_handle.done if ctx.act_handle is not None else None
+        if handed is not None:                 # the consumer's data-gradient launch applied the activation's backward: gy IS gpre
+            ctx.act_handle.done = None
+            gpre, (gb, gnw) = gy, handed
+        else:
+            gpre, gb, gnw = _derive(FusedLeakyReLUFunctionBackward, gy, y, noise if has_noise else None, has_bias, alpha, scale,
+                                    ctx.mask)
         gin = _derive(UpFirDn2dBackward, gpre, fir, fir_flipped, (1, 1), (1, 1), pad, ctx.g_pad, in_hw) \
             if ctx.needs_input_grad[0] else None
         return gin, None, None, (gb if has_bias and ctx.needs_input_grad[3] else None), None, \
-            (gnw.reshape(nw_shape) if has_noise and ctx.needs_input_grad[5] else None), None, None
+            (gnw.reshape(nw_shape) if has_noise and ctx.needs_input_grad[5] else None), None, None, None
 
 
-def blur_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, scale=1.0):
-    """leaky_relu(upfirdn2d(input, kernel, pad=pad) + noise_weight * noise + bias) * scale; one launch when eligible."""
+def blur_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, scale=1.0, act_handle=None):
+    """leaky_relu(upfirdn2d(input, kernel, pad=pad) + noise_weight * noise + bias) * scale; one launch when eligible.
+    act_handle: see BlurBiasAct.forward."""
     if _blur_act_eligible(input, kernel, pad):
         return BlurBiasAct.apply(input, kernel, (pad[0], pad[1], pad[0], pad[1]), bias, noise, noise_weight,
-                                 float(negative_slope), float(scale))
+                                 float(negative_slope), float(scale), act_handle)
     from .fused_act import fused_bias_noise_leaky_relu
     return fused_bias_noise_leaky_relu(upfirdn2d(input, kernel, pad=pad), bias, noise, noise_weight, negative_slope, scale)

@@ -169,7 +169,10 @@ class ResNetBlock(nn.Module):
         # and the block output has a single consumer (conv_ops.GradScale)
         owed = conv_ops.GradScale() if fuse_res and \
             merge is not scaled_add_fork and conv2.bias is None and input.is_cuda else None
-        output = conv2.forward_activated(conv1.forward_activated(x_main, act1, grad_slot=slot), act2, out_grad_scale=owed)
+        # act1's output feeds conv2 and nothing else: its backward rides in conv2's data-gradient epilogue (conv_ops.ActHandle)
+        handle = conv_ops.ActHandle() if input.is_cuda and torch.is_grad_enabled() else None
+        output = conv2.forward_activated(conv1.forward_activated(x_main, act1, grad_slot=slot, act_handle=handle), act2,
+                                         out_grad_scale=owed, input_act=handle)
         if fuse_res and output.dtype == input.dtype:
             # (main + conv1x1(input)) / sqrt(2) in the epilogue of the 1x1 conv: no separate merge pass
             return conv_ops.conv2d_add_residual(x_res, res.weight, output, 1.0 / math.sqrt(2), stride=res.stride,

@@ -959,9 +959,9 @@ def test_block_input_gradient_merge(dtype):
     gy = conv_ops.to_compute_layout(torch.randn(3, 32, 24, 20, device=DEV), dtype)
     calls = []
     orig = conv_ops._d_raw
-    def spy(gy_, w_, g_, residual=None):
+    def spy(gy_, w_, g_, residual=None, **kw):
         calls.append(residual is not None)
-        return orig(gy_, w_, g_, residual=residual)
+        return orig(gy_, w_, g_, residual=residual, **kw)
     grads = {}
     for flag in (False, True):
         U.FUSE_INPUT_FORK = flag

@@ -464,6 +464,20 @@ int msg_conv2d_fprop_act_backward(const void* x, const void* w, void* y, int dty
                                   float* grad_bias, const float* noise, int noise_batch, float* grad_noise_weight,
                                   float* ws, long long ws_floats, void* stream);
 
+/* (ABI 5) The discriminator's pixel-wise head -- FusedLeakyReLU(C) followed by a bias-free 1x1 equalized conv to one plane
+ * (reference u_net_2d_discriminator.py:93-97, `final_mapping`; op_static/fused_act.py:64-89 + equalized_layer.py:63-74) -- as one
+ * streaming pass per direction over the channels-last bf16 map x [npix][C]:
+ *   y[p] = wscale * sum_c w[c] * a[p][c],  a = lrelu(x[p][c] + bias[c]) * scale            (fp32 out; the activated map is not stored)
+ *   gx[p][c] = gy[p] * wscale * w[c] * slope(x[p][c] + bias[c]);  grad_bias_and_w[0..C) = sum_p gx,  [C..2C) = wscale * sum_p gy[p] a[p][c]
+ * C / 8 a power of two <= 64, bf16 only (MSG_EUNSUPPORTED otherwise).  Sums fp32, overwritten, deterministic
+ * (ws_floats >= msg_act_pointwise_head_backward_workspace(npix, C)). */
+int msg_act_pointwise_head(const void* x, const float* bias, const float* w, float* y, int dtype,
+                           long long npix, int C, float wscale, float alpha, float scale, void* stream);
+long long msg_act_pointwise_head_backward_workspace(long long npix, int C);
+int msg_act_pointwise_head_backward(const void* x, const float* bias, const float* w, const float* gy, void* gx,
+                                    float* grad_bias_and_w, int dtype, long long npix, int C, float wscale,
+                                    float alpha, float scale, float* ws, long long ws_floats, void* stream);
+
 /* -------------------------------------------------------------------------
  * Equalized-lr fully connected layers with few rows (mapping network, style affines, classification head), fp32,
  * dense row-major operands.  Replaces F.linear(input, weight * scale, bias * scale_bias) of

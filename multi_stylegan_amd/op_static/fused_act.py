@@ -199,6 +199,7 @@ class FusedLeakyReLUFunctionBackward(Function):
             _lib.check(code, "msg_bias_act_backward")
         ctx.save_for_backward(out, noise)
         ctx.cfg = (negative_slope, scale)
+        ctx.mask = mask                  # (sign bytes, when this pass used them: its own backward is the same multiplication)
         gx = gx.reshape(grad_output.shape)
         if gb is None:
             gb = torch.zeros(0, device=dev)
@@ -216,6 +217,24 @@ class FusedLeakyReLUFunctionBackward(Function):
         ggw = gg_noise_weight if (noise is not None and gg_noise_weight is not None
                                   and gg_noise_weight.numel()) else None
         # linear in (gg_input, gg_bias, gg_noise_weight); the mask has zero derivative (reference fused_act.py:45-51)
+        mask = getattr(ctx, "mask", None)
+        if ggb is None and ggw is None and mask is not None and gg_input.dtype == torch.bfloat16 and gg_input.ndim == 4 and \
+                gg_input.shape == out.shape and gg_input.shape[1] % 8 == 0 and mask[0].numel() * 8 == gg_input.numel():
+            # the cotangent times the slope, from the sign bytes (2 1/16 maps moved instead of 3: the regularisers' second
+            # backward runs this once per activation)
+            g = gg_input if gg_input.is_contiguous(memory_format=torch.channels_last) else \
+                gg_input.contiguous(memory_format=torch.channels_last)
+            gx = torch.empty_like(g)
+            dev = g.device
+            mbytes, tile_m, tile_n = mask
+            with _lib.on_device(dev), _lib.kernel_clock.span(('bias_act_bwd_mask', g.dtype), 2 * g.numel() * 2 + mbytes.numel()):
+                code = _lib.lib().msg_bias_act_backward_mask(
+                    g.data_ptr(), mbytes.data_ptr(), int(tile_m), int(tile_n), gx.data_ptr(), _lib.MSG_BF16, g.numel(),
+                    g.shape[1], None, None, None, 1, g.shape[2] * g.shape[3], float(negative_slope), float(scale), None, 0,
+                    _lib.stream_of(dev))
+            if code != -2:
+                _lib.check(code, "msg_bias_act_backward_mask")
+                return gx, None, None, None, None, None, None
         gg_out = _bias_act(gg_input, ggb, out, noise if ggw is not None else None, ggw, 1, negative_slope, scale)
         return gg_out, None, None, None, None, None, None
 

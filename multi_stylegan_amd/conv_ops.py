@@ -784,6 +784,9 @@ def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle
     ws = torch.empty(need, dtype=torch.float32, device=dev)
     flops = 2.0 * b * h * w_ * n * kh * kw * c_real
     key = "conv_fprop_row3_actbwd"
+    if _lib.kernel_clock.enabled:                       # (the 256 x 256 tile -- the benchmark's roofline kernel -- or the 128 x 128 one)
+        if _lib.lib().msg_conv2d_fprop_plan(_lib.MSG_BF16, b, h, w_, cx, ck, h, w_, n, kh, kw, wstride) == 4:
+            key = "conv_fprop_row3n_actbwd"
     if _lib.kernel_clock.enabled and _CLOCK_SHAPES:
         key += f"|B{b} {h}x{w_}->{h}x{w_} {c_real}->{n} 3x3 s1 up1{' per-sample' if per_sample else ''}|"
     with _lib.on_device(dev), _lib.kernel_clock.span((key, 'bf16'), flops):

@@ -1024,8 +1024,8 @@ def test_activation_backward_in_the_data_gradient_epilogue(case, monkeypatch):
 
     g1, k1 = run(True)
     g0, k0 = run(False)
-    assert any(k.startswith("conv_fprop_row3_actbwd") for k in k1), k1
-    assert not any(k.startswith("conv_fprop_row3_actbwd") for k in k0)
+    assert any("_actbwd" in k for k in k1), k1
+    assert not any("_actbwd" in k for k in k0)
     for name, a, r in zip(("x", "w1", "w2", "b1", "b2"), g1, g0):
         if name == "b1":
             assert rel_err(a, r) < 1e-5, name
@@ -1082,8 +1082,8 @@ def test_blur_activation_backward_in_the_styled_conv_data_gradient(monkeypatch):
 
     g1, k1 = run(True)
     g0, k0 = run(False)
-    assert any(k.startswith("conv_fprop_row3_actbwd") for k in k1), k1
-    assert not any(k.startswith("conv_fprop_row3_actbwd") for k in k0)
+    assert any("_actbwd" in k for k in k1), k1
+    assert not any("_actbwd" in k for k in k0)
     for name, a, r in zip(("x", "w", "style", "b2", "nw2", "b1", "nw1"), g1, g0):
         if name in ("b1", "nw1"):
             assert rel_err(a, r) < 1e-5, (name, rel_err(a, r))

@@ -434,27 +434,22 @@ def main():
                     "launches": c["launches"],
                     "avg_us": round(c["avg_us"], 2), "algorithmic_work_per_launch": round(c["work"] / c["launches"])}
         mf = args.dtype == "bf16"
-        summary_before_merge = clock
         # (bf16: whichever of the two large-tile conv kernels spent more time in the timed region is the dominant one)
         names = {"conv_fprop_row3": "conv_fprop_row3_kernel<4,4,true> (implicit-GEMM 3x3 conv fwd + data-grad, 256x256 tile, activation "
-                                    "tile shared by the three horizontal taps, MFMA 16x16x32 bf16; incl. the launches of its <4,4,true,1> "
-                                    "instantiation, the same contraction with the activation backward in the epilogue)",
+                                    "tile shared by the three horizontal taps, MFMA 16x16x32 bf16; rocprofv3 symbol "
+                                    "conv_fprop_row3_kernel<4, 4, true, 0>)",
                  "conv_fprop_pp": "conv_fprop_pp_kernel (implicit-GEMM conv fwd + data-grad, 256x256 ping-pong tile, MFMA "
                                   "32x32x16 bf16)"}
         dom = max(names, key=lambda k: clock.get(f"{k}/{args.dtype}", {}).get("total_ms", 0.0))
-        # (the same kernel template with the activation-backward epilogue, conv_fprop_row3_kernel<4,4,true,1>, is the same tile
-        #  doing the same contraction: its launches count with the dominant kernel's)
         dom_key = f"{dom}/{args.dtype}"
-        twin = clock.get(f"{dom}_actbwd/{args.dtype}")
-        if twin is not None and dom_key in clock:
-            both = dict(clock[dom_key])
-            for field in ("work", "total_ms", "launches"):
-                both[field] += twin[field]
-            both["avg_us"] = 1e3 * both["total_ms"] / both["launches"]
-            clock = dict(clock, **{dom_key: both})                 # (the per-kernel listing below keeps the two apart)
         roof = leg(dom_key, "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", names[dom]) \
             if mf else leg(f"conv_fprop_dma/{args.dtype}", "mfma", MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                            "conv_fprop_kernel<float, true> (implicit-GEMM conv, MFMA 32x32x2 f32)")
+        # the same tile doing the same contraction with an activation backward in its epilogue: its own instantiation (rocprofv3
+        # symbol conv_fprop_row3_kernel<4, 4, true, 1>), reported beside the dominant kernel, not inside its average
+        roof_twin = leg(f"conv_fprop_row3_actbwd/{args.dtype}", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
+                        "conv_fprop_row3_kernel<4,4,true,1> (the dominant kernel's contraction + the preceding activation's "
+                        "backward and its bias / noise-weight partial sums in the epilogue)") if mf else None
         # the FIR launches that carry the bytes: the blur behind every upsampling styled conv, which also applies that
         # layer's noise + bias + leaky ReLU (algorithmic bytes: input + output + noise plane)
         roof_fir = leg(f"upfirdn2d/{args.dtype}/up1down1/sep+act", "hbm", HBM_PEAK_GBS, "GB/s",
@@ -467,7 +462,7 @@ def main():
         kernels = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                        ("TFLOP/s" if _is_flops(k) else "GB/s"):
                            round(v["work"] / (v["total_ms"] * 1e-3) / (1e12 if _is_flops(k) else 1e9), 1)}
-                   for k, v in sorted(summary_before_merge.items())}
+                   for k, v in sorted(clock.items())}
         last = {k: v[-1] for k, v in logs.items() if v}
         assert last and all(v == v and abs(v) != float("inf") for v in last.values()), f"non-finite loss: {last}"
         out = {
@@ -490,7 +485,7 @@ def main():
                              "raw_img_per_s": round(world * args.batch * args.steps / elapsed, 3),
                              "value_is": f"{hp_lazy - 1}:1 amortised (plain : regularised iterations, as in training)"
                              if amortise else "raw average of the window (it holds no regularised or no plain iteration)"},
-            "roofline": roof, "roofline_upfirdn2d": roof_fir, "kernels": kernels,
+            "roofline": roof, "roofline_upfirdn2d": roof_fir, "roofline_act_backward_twin": roof_twin, "kernels": kernels,
             "clock_iterations": clock_iterations, "peak_mem_GiB": round(peak_mem, 2),
             "losses": {k: round(v, 5) for k, v in last.items()},
             "h2d": h2d,

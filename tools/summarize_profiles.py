@@ -29,7 +29,8 @@ def short(name):
     return re.sub(r"\(.*", "", name)[:110]
 
 
-KEYS = [("conv_fprop_row3_kernel<4, 4", "conv_fprop_row3/bf16"), ("conv_fprop_row3_kernel<2, 2", "conv_fprop_row3n/bf16"), ("conv_fprop_pp_kernel", "conv_fprop_pp/bf16"), ("conv_fprop_kernel<unsigned short, true", "conv_fprop_dma/bf16"),
+KEYS = [("conv_fprop_row3_kernel<4, 4, true, 1", "conv_fprop_row3_actbwd/bf16"), ("conv_fprop_row3_kernel<2, 2, true, 1", "conv_fprop_row3n_actbwd/bf16"),
+        ("conv_fprop_row3_kernel<4, 4", "conv_fprop_row3/bf16"), ("conv_fprop_row3_kernel<2, 2", "conv_fprop_row3n/bf16"), ("conv_fprop_pp_kernel", "conv_fprop_pp/bf16"), ("conv_fprop_kernel<unsigned short, true", "conv_fprop_dma/bf16"),
         ("conv_fprop_kernel<unsigned short, false", "conv_fprop_reg/bf16"),
         ("conv_wgrad_row3_kernel", "conv_wgrad_row3/bf16"), ("conv_wgrad_row3s_kernel", "conv_wgrad_row3s/bf16"),
         ("conv_upconv_kernel", "conv_fprop_upconv/bf16"),

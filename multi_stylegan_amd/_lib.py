@@ -228,6 +228,26 @@ def on_device(device):
     return torch.cuda.device(device)
 
 
+_SCRATCH: dict = {}
+
+
+def scratch_ptr(nfloats: int, device) -> int:
+    """Device pointer of at least `nfloats` fp32 words of launch-scoped workspace (per-tile partial sums, K-slice slabs): ONE
+    buffer per (device, stream), grown on demand and reused by every launch.  Sound because a workspace lives from a
+    kernel to its reduce launch, both enqueued by the same call on the same stream, and the next user is ordered behind them on
+    that stream; a fresh torch.empty per launch was ~1.5 us of host time x ~300 launches per iteration.  (A buffer that was
+    outgrown stays alive until the process ends: launches already enqueued may still be reading it.)"""
+    if nfloats <= 0:
+        return 0
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_of(device))
+    bufs = _SCRATCH.get(key)
+    if bufs is None or bufs[-1].numel() < nfloats:
+        grown = torch.empty(max(int(nfloats), 1 << 20, 2 * (bufs[-1].numel() if bufs else 0)), dtype=torch.float32, device=device)
+        bufs = (bufs or []) + [grown]
+        _SCRATCH[key] = bufs
+    return bufs[-1].data_ptr()
+
+
 class KernelClock:
     """Optional per-launch timing with HIP events on the stream the kernels are launched on (bench.py's roofline
     leg).  Off by default: when off, ``span`` is a no-op and costs one attribute test."""

@@ -568,7 +568,7 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
         if need < 0:
             _lib.check(int(need), "msg_conv2d_wgrad_workspace")
         _WGRAD_WS_CACHE[geom] = need
-    ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+    ws = _lib.scratch_ptr(need, dev) if need else None        # (launch-scoped: slabs -> the fixed-order sum of the same call)
     if per_sample or raw:
         out = None
     oi_major = (bool(need) or out is not None) and not per_sample and not raw
@@ -585,7 +585,7 @@ def _launch_wgrad(gy, x, o, i, kh, kw, stride, pad, pixel_shuffle, per_sample, l
                f"{' per-sample' if per_sample else ' shared'}{f' slabs{need // (o * taps * ldgw)}' if need else ''}|"
     with _lib.on_device(dev), _lib.kernel_clock.span((key, 'bf16' if x.dtype == torch.bfloat16 else 'f32'), flops):
         code = _lib.lib().msg_conv2d_wgrad(
-            gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), *geom, int(oi_major), float(gain), _lib.ptr(ws), need,
+            gv.data_ptr(), xv.data_ptr(), gw.data_ptr(), *geom, int(oi_major), float(gain), ws, need,
             _lib.stream_of(dev))
     _lib.check(code, "msg_conv2d_wgrad")
     if raw:
@@ -781,7 +781,7 @@ def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle
             return None
         nz, nb = noise.detach().to(torch.float32).contiguous(), noise.shape[0]
         gnw = torch.empty(1, dtype=torch.float32, device=dev)
-    ws = torch.empty(need, dtype=torch.float32, device=dev)
+    ws = _lib.scratch_ptr(need, dev)
     flops = 2.0 * b * h * w_ * n * kh * kw * c_real
     key = "conv_fprop_row3_actbwd"
     if _lib.kernel_clock.enabled:                       # (the 256 x 256 tile -- the benchmark's roofline kernel -- or the 128 x 128 one)
@@ -793,7 +793,7 @@ def _launch_dgrad_act_backward(gy, wk, ck, n, kh, kw, per_sample, c_real, handle
         code = _lib.lib().msg_conv2d_fprop_act_backward(
             xv.data_ptr(), wk.data_ptr(), y.data_ptr(), _lib.MSG_BF16, b, h, w_, cx, ck, h, w_, n, ldy, kh, kw, 1, 1, wstride,
             _lib.ptr(rv), res_ld, _lib.ptr(smask), tm, tn, _lib.ptr(smap), sld, handle.alpha, handle.scale,
-            _lib.ptr(gb), _lib.ptr(nz), nb, _lib.ptr(gnw), ws.data_ptr(), need, _lib.stream_of(dev))
+            _lib.ptr(gb), _lib.ptr(nz), nb, _lib.ptr(gnw), ws, need, _lib.stream_of(dev))
     if code == -2:
         _ACTBWD_WS_CACHE[wkey] = 0          # (not asked again for this geometry)
         return None

@@ -118,14 +118,14 @@ def act_backward_with_head(gy, head, out_shape, noise, bias_param, need_bias, ne
         need = _WS_CACHE.get(wkey)
         if need is None:
             need = _WS_CACHE[wkey] = _lib.lib().msg_bias_act_backward_workspace(gx.numel(), 1, c, int(noise is not None))
-    ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+    ws = _lib.scratch_ptr(need, dev) if need else None
     nbytes = (1 + (g is not None)) * gx.numel() * 2 + mbytes.numel() + b * h * w * 16
     with _lib.on_device(dev), _lib.kernel_clock.span(('bias_act_bwd_mask_head', gx.dtype), nbytes):
         code = _lib.lib().msg_bias_act_backward_mask_head(
             _lib.ptr(g), hv.data_ptr(), whead.data_ptr(), style.data_ptr(), float(wscale), int(hgy.shape[1]),
             mbytes.data_ptr(), int(tile_m), int(tile_n), gx.data_ptr(), _lib.MSG_BF16, gx.numel(), c,
             _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, h * w, float(negative_slope), float(scale),
-            _lib.ptr(ws), need, _lib.stream_of(dev))
+            ws, need, _lib.stream_of(dev))
     if code == -2:                      # MSG_EUNSUPPORTED (shapes whose workgroups would straddle samples, alignment)
         return None
     _lib.check(code, "msg_bias_act_backward_mask_head")
@@ -172,7 +172,7 @@ class FusedLeakyReLUFunctionBackward(Function):
             need = _WS_CACHE.get(wkey)
             if need is None:
                 need = _WS_CACHE[wkey] = _lib.lib().msg_bias_act_backward_workspace(g.numel(), step_b, channels, int(noise is not None))
-        ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+        ws = _lib.scratch_ptr(need, dev) if need else None        # (launch-scoped: partials -> the reduce launch of the same call)
         if mask is not None and step_b == 1 and g.ndim == 4 and g.dtype == torch.bfloat16 and channels % 8 == 0 and \
                 mask[0].numel() * 8 == g.numel():
             # the forward launch left the sign bytes of `out` (bytes, tile_m, tile_n): that map is not read again
@@ -183,7 +183,7 @@ class FusedLeakyReLUFunctionBackward(Function):
                     g.data_ptr(), mbytes.data_ptr(), int(tile_m), int(tile_n), gx.data_ptr(), _lib.dtype_code(g, True),
                     g.numel(), channels,
                     _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
-                    _lib.ptr(ws), need, _lib.stream_of(dev))
+                    ws, need, _lib.stream_of(dev))
             if code == -2:                          # MSG_EUNSUPPORTED: the backward's vector path has stricter conditions
                 mask = None                         # (pointer alignment) than the forward's decision to write the bytes --
             else:                                   # the stored output is still here, take the slower path instead of raising
@@ -195,7 +195,7 @@ class FusedLeakyReLUFunctionBackward(Function):
                 code = _lib.lib().msg_bias_act_backward(
                     g.data_ptr(), o.data_ptr(), gx.data_ptr(), _lib.dtype_code(g, True), g.numel(), step_b, channels,
                     _lib.ptr(gb), _lib.ptr(nz), _lib.ptr(gnw), nb, pix, float(negative_slope), float(scale),
-                    _lib.ptr(ws), need, _lib.stream_of(dev))
+                    ws, need, _lib.stream_of(dev))
             _lib.check(code, "msg_bias_act_backward")
         ctx.save_for_backward(out, noise)
         ctx.cfg = (negative_slope, scale)

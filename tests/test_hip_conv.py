@@ -939,8 +939,11 @@ def test_activation_backward_forms_the_head_gradient(b, c, hw, n_head, other, no
         assert gnw.numel() == 0
 
 
-def test_image_head_gradient_handed_to_the_producer(monkeypatch):
-    """A styled 3x3 layer (fused activation, sign bytes) whose output feeds a second consumer and a 6-plane image head: with
+@pytest.mark.parametrize("batch", [8, 4])
+def test_image_head_gradient_handed_to_the_producer(batch, monkeypatch):
+    """(batch 4: the producer runs on a kernel that leaves no sign bytes -- the hand-over happens, the fused pass declines and
+    the producer takes the head's data gradient the ordinary way: same tolerances, no fused launch.)
+    A styled 3x3 layer (fused activation, sign bytes) whose output feeds a second consumer and a 6-plane image head: with
     the hand-over (conv_ops.HeadGradSlot) the head's data gradient is formed inside the layer's activation backward; every
     leaf gradient agrees with the form that writes it as a map and lets autograd add (bf16 roundings of two intermediate maps
     apart: 1e-2 norm-wise on the bf16 input gradient, 5e-3 on the fp32 sums), the fused kernel is the one that ran; without a second consumer the producer sees no incoming gradient at all."""
@@ -950,14 +953,14 @@ def test_image_head_gradient_handed_to_the_producer(monkeypatch):
     def run(fuse, second_consumer):
         monkeypatch.setattr(conv_ops, "HEAD_GRAD_FUSION", fuse)
         torch.manual_seed(5)
-        x = conv_ops.to_compute_layout(torch.randn(8, 512, 64, 64, device=DEV), bf).requires_grad_(True)   # (8: the row-sharing kernel)
+        x = conv_ops.to_compute_layout(torch.randn(batch, 512, 64, 64, device=DEV), bf).requires_grad_(True)   # (8: the row-sharing kernel)
         w = torch.randn(1, 512, 512, 3, 3, device=DEV).requires_grad_(True)
-        style = (1 + 0.1 * torch.randn(8, 512, device=DEV)).requires_grad_(True)
+        style = (1 + 0.1 * torch.randn(batch, 512, device=DEV)).requires_grad_(True)
         bias = (0.1 * torch.randn(512, device=DEV)).requires_grad_(True)
-        noise = torch.randn(8, 1, 64, 64, device=DEV)
+        noise = torch.randn(batch, 1, 64, 64, device=DEV)
         nw = torch.full((1,), 0.3, device=DEV, requires_grad=True)
         wh = torch.randn(1, 6, 512, 1, 1, device=DEV).requires_grad_(True)
-        sh = (1 + 0.1 * torch.randn(8, 512, device=DEV)).requires_grad_(True)
+        sh = (1 + 0.1 * torch.randn(batch, 512, device=DEV)).requires_grad_(True)
         slot = conv_ops.HeadGradSlot()
         y = conv_ops.modulated_conv2d_bias_act(x, w, style, True, bias, noise, nw, scale=math.sqrt(2), head_slot=slot)
         rgb = conv_ops.modulated_conv2d(y, wh, sh, False, False, head_slot=slot)
@@ -976,7 +979,7 @@ def test_image_head_gradient_handed_to_the_producer(monkeypatch):
     for second in (True, False):
         g1, k1 = run(True, second)
         g0, k0 = run(False, second)
-        assert any(k.startswith("bias_act_bwd_mask_head/") for k in k1), k1
+        assert any(k.startswith("bias_act_bwd_mask_head/") for k in k1) == (batch == 8), k1
         assert not any(k.startswith("bias_act_bwd_mask_head/") for k in k0)
         for name, a, r in zip(("x", "w", "style", "bias", "noise_w", "w_head", "style_head"), g1, g0):
             e = ((a.float() - r.float()).norm() / r.float().norm()).item()

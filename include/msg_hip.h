@@ -168,6 +168,9 @@ int msg_bias_act_backward_mask(const void* gy, const unsigned char* mask, int ti
                                float* grad_bias, const float* noise, float* grad_noise_weight,
                                int noise_batch, int pix, float alpha, float scale,
                                float* ws, long long ws_floats, void* stream);
+/* (ABI 5) out[c] = sum_r part[r][cols], r in index order (fp32, deterministic): the second stage of the partial-sum reductions as an
+ * entry of its own -- e.g. the [groups][B][I] style-gradient partials of msg_modulate_backward. */
+int msg_sum_rows(const float* part, float* out, long long rows, int cols, void* stream);
 /* (ABI 5) msg_bias_act_backward_mask for the output of a styled layer that ALSO feeds the level's image head -- a 1x1 modulated
  * conv without demodulation to n_head <= 8 planes (reference: OutputBlock, multi_stylegan_generator.py:513-523, reading the
  * StyledConv2d output of :384-411).  The head's data gradient is formed inside this pass instead of being written as a full map

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "msg_conv2d_fprop_act_mask": (_I, [_P, _P, _P, _I] + [_I] * 13 + [_L, _P, _P, _P, _I, _F, _F, _P, _P]),
     "msg_conv2d_fprop_residual": (_I, [_P, _P, _P, _I] + [_I] * 13 + [_L, _P, _I, _F, _P]),
     "msg_conv2d_fprop_act_backward_workspace": (_L, [_I] * 11 + [_L, _I]),
+    "msg_sum_rows": (_I, [_P, _P, _L, _I, _P]),
     "msg_act_pointwise_head": (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _F, _F, _P]),
     "msg_act_pointwise_head_backward_workspace": (_L, [_L, _I]),
     "msg_act_pointwise_head_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _F, _F, _P, _L, _P]),

@@ -1721,18 +1721,21 @@ def _fold_weight_gradient(gwk, ldg, w3, s, dd, scale, style_dtype, cotangent=Non
     groups = (o + og - 1) // og
     out = _grad_dest(dest) if cotangent is None else None     # (the parameter's slice of the flat gradient store)
     gw3 = out.view(o, i, t) if out is not None else torch.empty((o, i, t), dtype=torch.float32, device=dev)
-    gs_part = torch.empty((groups, b, i), dtype=torch.float32, device=dev)
+    gs_part = _lib.scratch_ptr(groups * b * i, dev)           # [groups][B][I] partials: live until the row sum two lines below
+    gs = torch.empty((b, i), dtype=torch.float32, device=dev)
     with _lib.on_device(dev):
+        st = _lib.stream_of(dev)
         if cotangent is None:
             code = _lib.lib().msg_modulate_backward(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
-                                                    gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t, ldg, og,
-                                                    scale, _lib.stream_of(dev))
+                                                    gw3.data_ptr(), gs_part, b, o, i, t, ldg, og, scale, st)
         else:
             code = _lib.lib().msg_modulate_backward2(gwk.data_ptr(), w3.data_ptr(), s.data_ptr(), _lib.ptr(dd),
-                                                     cotangent.data_ptr(), gw3.data_ptr(), gs_part.data_ptr(), b, o, i, t,
-                                                     ldg, og, scale, _lib.stream_of(dev))
-    _lib.check(code, "msg_modulate_backward" + ("2" if cotangent is not None else ""))
-    return (out if out is not None else gw3), gs_part.sum(dim=0).to(style_dtype)
+                                                     cotangent.data_ptr(), gw3.data_ptr(), gs_part, b, o, i, t,
+                                                     ldg, og, scale, st)
+        _lib.check(code, "msg_modulate_backward" + ("2" if cotangent is not None else ""))
+        code = _lib.lib().msg_sum_rows(gs_part, gs.data_ptr(), groups, b * i, st)
+    _lib.check(code, "msg_sum_rows")
+    return (out if out is not None else gw3), (gs if style_dtype == torch.float32 else gs.to(style_dtype))
 
 
 def _modconv_backward(x, weight, style, d, gy, demodulate, upsample, g, scale, need, keep_gwk=False, direct=False,

@@ -385,6 +385,14 @@ extern "C" int msg_bias_act_reduce_launch(const float* part_b, float* grad_bias,
     return MSG_CHECK_LAUNCH();
 }
 
+// out[c] = sum over `rows` rows of part[.][cols] in index order (the fixed-order second stage above as an entry of its own: the
+// style-gradient partials of msg_modulate_backward, which the caller summed with a stock reduction -- one more library launch
+// and ~7 us of host time per styled layer and backward).
+extern "C" int msg_sum_rows(const float* part, float* out, long long rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0 || !part || !out) return MSG_EINVAL;
+    return msg_bias_act_reduce_launch(part, out, cols, rows, nullptr, nullptr, 0, stream);
+}
+
 // The launch geometry of the backward, a function of the SHAPE only (the workspace query and the launch must agree).
 struct BwdPlan {
     int path;                   // 0 channels-last vectors, 1 planar, 2 strided
